@@ -1,0 +1,197 @@
+"""CPU oracle for the torchvision_models side of the hot path — TEST INFRASTRUCTURE ONLY.
+
+float32 numpy restatement.  Matcher / BoxCoder / AnchorGenerator follow reference files and are
+pinned by tests/golden/g5_7_tvision.npz (reference outputs).  box_iou / nms / batched_nms /
+clip_boxes_to_image / remove_small_boxes / sigmoid_focal_loss live in torchvision, which is
+NOT vendored in /root/reference and not installed here (torchvision ~0.10, unpinned by the
+reference): they restate the published semantics and are
+**parity unpinned** beyond the reference-owned callers that consume them (Matcher on box_iou).
+
+Reference files restated (under /root/reference/torchvision_models/tvision):
+  _utils.py:79-125,152-223   BoxCoder.encode_single / decode_single
+  _utils.py:271-344          Matcher.__call__ / set_low_quality_matches_
+  anchor_utils.py:60-159     AnchorGenerator
+  retinanet.py:107-143,196-223,401-412   RetinaNet losses
+"""
+import math
+
+import numpy as np
+
+F32 = np.float32
+
+
+def box_iou(a, b):
+    a, b = np.asarray(a, F32), np.asarray(b, F32)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.maximum(rb - lt, F32(0))
+    inter = wh[..., 0] * wh[..., 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def nms(boxes, scores, thr):
+    """Greedy NMS, suppress IoU > thr, kept indices by descending score (ties: lower index first)."""
+    boxes, scores = np.asarray(boxes, F32), np.asarray(scores, F32)
+    order = np.argsort(-scores.astype(np.float64), kind="stable")
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    alive = np.ones(len(order), bool)
+    keep = []
+    for i, idx in enumerate(order):
+        if not alive[i]:
+            continue
+        keep.append(idx)
+        rest = order[i + 1:]
+        lt = np.maximum(boxes[rest, :2], boxes[idx, :2])
+        rb = np.minimum(boxes[rest, 2:], boxes[idx, 2:])
+        wh = np.maximum(rb - lt, F32(0))
+        inter = wh[:, 0] * wh[:, 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (area[idx] + area[rest] - inter)
+        alive[i + 1:] &= ~(iou > F32(thr))
+    return np.array(keep, np.int64)
+
+
+def batched_nms(boxes, scores, idxs, thr):
+    boxes = np.asarray(boxes, F32)
+    if boxes.shape[0] == 0:
+        return np.zeros(0, np.int64)
+    off = np.asarray(idxs).astype(F32) * (boxes.max() + F32(1))
+    return nms(boxes + off[:, None], scores, thr)
+
+
+def clip_boxes_to_image(boxes, size):
+    h, w = size
+    b = np.array(boxes, F32, copy=True)
+    b[..., 0::2] = np.clip(b[..., 0::2], 0, F32(w))
+    b[..., 1::2] = np.clip(b[..., 1::2], 0, F32(h))
+    return b
+
+
+def remove_small_boxes(boxes, min_size):
+    b = np.asarray(boxes, F32)
+    ws, hs = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+    return np.nonzero((ws >= F32(min_size)) & (hs >= F32(min_size)))[0].astype(np.int64)
+
+
+def sigmoid_focal_loss(x, t, alpha=0.25, gamma=2.0):
+    """Unreduced loss and d/dx (float64 internally)."""
+    x = np.asarray(x, np.float64)
+    t = np.asarray(t, np.float64)
+    p = 1 / (1 + np.exp(-x))
+    ce = np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))
+    p_t = p * t + (1 - p) * (1 - t)
+    q = 1 - p_t
+    loss = ce * q ** gamma
+    dpt = (2 * t - 1) * p * (1 - p)
+    grad = (p - t) * q ** gamma - ce * gamma * q ** (gamma - 1) * dpt
+    if alpha >= 0:
+        a_t = alpha * t + (1 - alpha) * (1 - t)
+        loss, grad = a_t * loss, a_t * grad
+    return loss.astype(F32), grad.astype(F32)
+
+
+def matcher(q, high, low, allow_low_quality):
+    """_utils.py:271-344 on a materialised [M,N] quality matrix -> int64 [N]."""
+    q = np.asarray(q, F32)
+    if q.size == 0:
+        raise ValueError("No ground-truth boxes available for one of the images during training"
+                         if q.shape[0] == 0 else
+                         "No proposal boxes available for one of the images during training")
+    vals = q.max(axis=0)
+    matches = q.argmax(axis=0).astype(np.int64)
+    allm = matches.copy()
+    matches[vals < F32(low)] = -1
+    matches[(vals >= F32(low)) & (vals < F32(high))] = -2
+    if allow_low_quality:
+        best = q.max(axis=1)
+        _, pred = np.nonzero(q == best[:, None])
+        matches[pred] = allm[pred]
+    return matches
+
+
+def encode_boxes(ref, prop, weights):
+    ref, prop = np.asarray(ref, F32), np.asarray(prop, F32)
+    wx, wy, ww, wh = [F32(w) for w in weights]
+    ew, eh = prop[:, 2] - prop[:, 0], prop[:, 3] - prop[:, 1]
+    ecx, ecy = prop[:, 0] + F32(0.5) * ew, prop[:, 1] + F32(0.5) * eh
+    gw, gh = ref[:, 2] - ref[:, 0], ref[:, 3] - ref[:, 1]
+    gcx, gcy = ref[:, 0] + F32(0.5) * gw, ref[:, 1] + F32(0.5) * gh
+    return np.stack([wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh,
+                     ww * np.log(gw / ew), wh * np.log(gh / eh)], 1).astype(F32)
+
+
+def decode_boxes(codes, boxes, weights, clip=math.log(1000.0 / 16)):
+    codes, boxes = np.asarray(codes, F32), np.asarray(boxes, F32)
+    wx, wy, ww, wh = [F32(w) for w in weights]
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cx, cy = boxes[:, 0] + F32(0.5) * w, boxes[:, 1] + F32(0.5) * h
+    dx, dy = codes[:, 0::4] / wx, codes[:, 1::4] / wy
+    dw = np.minimum(codes[:, 2::4] / ww, F32(clip))
+    dh = np.minimum(codes[:, 3::4] / wh, F32(clip))
+    pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
+    pw, ph = np.exp(dw) * w[:, None], np.exp(dh) * h[:, None]
+    out = np.stack([pcx - F32(0.5) * pw, pcy - F32(0.5) * ph, pcx + F32(0.5) * pw, pcy + F32(0.5) * ph], 2)
+    return out.reshape(codes.shape[0], -1).astype(F32)
+
+
+def cell_anchors(sizes, ratios):
+    """anchor_utils.py:60-71 (float32 sqrt / reciprocal, round-half-even like torch.round)."""
+    s = np.asarray(sizes, F32)
+    r = np.asarray(ratios, F32)
+    hr = np.sqrt(r)
+    wr = F32(1) / hr
+    ws = (wr[:, None] * s[None, :]).reshape(-1)
+    hs = (hr[:, None] * s[None, :]).reshape(-1)
+    return np.round(np.stack([-ws, -hs, ws, hs], 1) / F32(2)).astype(F32)
+
+
+def anchors(sizes, ratios, image_size, grids):
+    """anchor_utils.py:98-159 -> [sum(H*W*A), 4] xyxy; stride = image // grid."""
+    out = []
+    for sz, ar, (gh, gw) in zip(sizes, ratios, grids):
+        base = cell_anchors(sz, ar)
+        sh, sw = image_size[0] // gh, image_size[1] // gw
+        sx = np.arange(gw, dtype=F32) * F32(sw)
+        sy = np.arange(gh, dtype=F32) * F32(sh)
+        yy, xx = np.meshgrid(sy, sx, indexing="ij")
+        shifts = np.stack([xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)], 1)
+        out.append((shifts[:, None, :] + base[None, :, :]).reshape(-1, 4))
+    return np.concatenate(out, 0).astype(F32)
+
+
+def retinanet_loss(cls_logits, bbox_reg, anchors_xyxy, gts, tfidf=None, high=0.5, low=0.4):
+    """retinanet.py:401-412 + :107-143 + :196-223.  cls_logits [b,N,K], bbox_reg [b,N,4];
+    gts list of (boxes [M,4] xyxy, labels [M]).  Returns (cls_loss, reg_loss, matched_idxs, grads)."""
+    b, N, K = cls_logits.shape
+    cl, rl, mis = [], [], []
+    gcls = np.zeros(cls_logits.shape, np.float64)
+    greg = np.zeros(bbox_reg.shape, np.float64)
+    for i in range(b):
+        boxes, labels = gts[i]
+        if np.asarray(boxes).size == 0:
+            mi = np.full(N, -1, np.int64)
+        else:
+            mi = matcher(box_iou(boxes, anchors_xyxy), high, low, True)
+        mis.append(mi)
+        fg = mi >= 0
+        nfg = max(1, int(fg.sum()))
+        tgt = np.zeros((N, K), F32)
+        tgt[fg, np.asarray(labels)[mi[fg]]] = 1
+        valid = mi != -2
+        x = cls_logits[i] if tfidf is None else np.asarray(tfidf, F32)[None, :] * cls_logits[i]
+        l, g = sigmoid_focal_loss(x[valid], tgt[valid])
+        cl.append(l.astype(np.float64).sum() / nfg)
+        gi = np.zeros((N, K))
+        gi[valid] = g / nfg
+        if tfidf is not None:
+            gi = gi * np.asarray(tfidf, np.float64)[None, :]
+        gcls[i] = gi / b
+        idx = np.nonzero(fg)[0]
+        tr = encode_boxes(np.asarray(boxes, F32)[mi[idx]], anchors_xyxy[idx], (1, 1, 1, 1)) if len(idx) else np.zeros((0, 4), F32)
+        d = bbox_reg[i][idx].astype(np.float64) - tr
+        rl.append(np.abs(d).sum() / nfg)
+        greg[i][idx] = np.sign(d) / nfg / max(1, b)
+    return F32(sum(cl) / b), F32(sum(rl) / max(1, b)), mis, (gcls.astype(F32), greg.astype(F32))

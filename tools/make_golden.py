@@ -1,0 +1,506 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python on seeded inputs.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  The reference is imported as-is from its read-only tree with empty stub
+modules for packages that are not installed (recipe: SURVEY.md Appendix A); nothing
+from the reference is copied.  Outputs are plain data: inputs (or the detrand seed that
+regenerates them) and the reference's outputs.
+
+    python tools/make_golden.py            # writes tests/golden/*.npz
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import detrand  # noqa: E402
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+COCO_ANCHORS = [[[116, 90], [156, 198], [373, 326]],
+                [[30, 61], [62, 45], [59, 119]],
+                [[10, 13], [16, 30], [33, 23]]]
+LVIS_ANCHORS = [[[155.78819651, 244.03609716], [320.272707, 116.94313185], [293.30877626, 232.00399174],
+                 [116, 90], [156, 198], [373, 326]],
+                [[56.46791643, 96.62934705], [89.66263185, 59.3598243], [127.82328124, 40.61556824],
+                 [30, 61], [62, 45], [59, 119]],
+                [[13.5255288, 23.31384949], [31.50078774, 9.86228439], [20.81998901, 13.66625921],
+                 [10, 13], [16, 30], [33, 23]]]
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def import_yolo():
+    sys.path.insert(0, os.path.join(REF, "yolo"))
+    os.environ["owd"] = os.path.join(REF, "yolo")
+    _stub("pycocotools")
+    _stub("pycocotools.coco", COCO=object)
+    _stub("pycocotools.cocoeval", COCOeval=object)
+    _stub("lvis", LVIS=object, LVISEval=object)
+    _stub("hydra")
+    tv = _stub("torchvision")
+    ops = _stub("torchvision.ops", FeaturePyramidNetwork=object)
+    bx = _stub("torchvision.ops.boxes")
+    tv.ops = ops
+    ops.boxes = bx
+    ident = lambda self, *a, **k: self  # noqa: E731
+    torch.Tensor.cuda = ident
+    nn.Module.cuda = ident
+    from utilities import helper, custom
+    from nets import yolo_forw, yolohead
+    from nets.backbone import darknet
+    return helper, custom, yolo_forw, yolohead, darknet
+
+
+def make_yoloforw(yolo_forw, custom, anchors, num_classes, img_size, iou_type=1, idf_logits=None,
+                  gamma=1.0, alpha=0.5, ignore_thr=0.5):
+    F = yolo_forw.YOLOForw.__new__(yolo_forw.YOLOForw)
+    nn.Module.__init__(F)
+    F.anchors = anchors
+    F.num_anchors = len(anchors)
+    F.num_classes = num_classes
+    F.bbox_attrs = 5 + num_classes
+    F.img_size = img_size
+    F.ignore_threshold = ignore_thr
+    F.lambda_iou, F.lambda_xy, F.lambda_wh = 1, 2.5, 2.5
+    F.lambda_conf, F.lambda_no_conf, F.lambda_cls = 1.0, 0.1, 1.0
+    F.reduction = "sum"
+    F.device = torch.device("cpu")
+    F.tfidf_norm, F.tfidf_batch = 0, False
+    F.idf_logits = torch.tensor(1) if idf_logits is None else torch.as_tensor(idf_logits)
+    F.iou_type = iou_type
+    F.wh_loss = nn.MSELoss(reduction="sum")
+    F.xy_loss = nn.MSELoss(reduction="sum")
+    F.pobj_loss = custom.FocalLoss(nn.BCEWithLogitsLoss(reduction="sum"), gamma=gamma, alpha=alpha)
+    F.nobj_loss = custom.FocalLoss(nn.BCEWithLogitsLoss(reduction="None"), gamma=gamma, alpha=alpha)
+    F.class_loss = nn.CrossEntropyLoss(reduction="sum", weight=torch.ones(num_classes))
+    return F
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def synth_targets(seed, ms, num_classes):
+    """Per image: M boxes relative xcycwh (xc,yc~U(.2,.8), w,h~U(.02,.32)), labels."""
+    out = []
+    for b, m in enumerate(ms):
+        xy = detrand.uniform(seed + 17 * b, (m, 2), 0.2, 0.8)
+        wh = detrand.uniform(seed + 17 * b + 5, (m, 2), 0.02, 0.32)
+        lab = detrand.randint(seed + 17 * b + 9, (m,), 0, num_classes)
+        out.append((np.concatenate([xy, wh], 1).astype(np.float32), lab))
+    return out
+
+
+def synth_heads(seed, bs, na, nc, grids):
+    return [detrand.uniform(seed + k, (bs, na * (5 + nc), g, g), -3.0, 3.0) for k, g in enumerate(grids)]
+
+
+# ----------------------------------------------------------------------------- G1 bbox_iou
+def g1_bbox_iou(helper):
+    bb1 = np.concatenate([detrand.uniform(1, (5, 1, 2), 0.2, 0.8), detrand.uniform(2, (5, 1, 2), 0.02, 0.4)], 2)
+    bb2 = np.concatenate([detrand.uniform(3, (1, 7, 2), 0.2, 0.8), detrand.uniform(4, (1, 7, 2), 0.02, 0.4)], 2)
+    # degenerate cases appended as extra rows/cols: zero-area, identical, disjoint
+    deg1 = np.array([[[0.5, 0.5, 0.0, 0.0]], [[0.3, 0.3, 0.1, 0.2]], [[0.1, 0.1, 0.05, 0.05]]], np.float32)
+    deg2 = np.array([[[0.5, 0.5, 0.0, 0.0], [0.3, 0.3, 0.1, 0.2], [0.9, 0.9, 0.05, 0.05]]], np.float32)
+    bb1 = np.concatenate([bb1, deg1], 0).astype(np.float32)
+    bb2 = np.concatenate([bb2, deg2], 1).astype(np.float32)
+    d = {"bb1": bb1, "bb2": bb2}
+    for t in range(4):
+        d[f"iou_type{t}"] = helper.bbox_iou(torch.from_numpy(bb1), torch.from_numpy(bb2), t, CUDA=False).numpy()
+    # elementwise (same-shape) call used by the loss (yolo_forw.py:125), pixel-scale boxes
+    e1 = np.concatenate([detrand.uniform(5, (9, 2), 50, 500), detrand.uniform(6, (9, 2), 5, 200)], 1)
+    e2 = e1 + detrand.uniform(7, (9, 4), -20, 20)
+    e2[:, 2:] = np.abs(e2[:, 2:]) + 1
+    d["e1"], d["e2"] = e1.astype(np.float32), e2.astype(np.float32)
+    for t in range(4):
+        d[f"elem_type{t}"] = helper.bbox_iou(torch.from_numpy(d["e1"]), torch.from_numpy(d["e2"]), t, CUDA=False).numpy()
+    # xyxy mode
+    x1 = detrand.uniform(8, (6, 2), 0, 300)
+    a = np.concatenate([x1, x1 + detrand.uniform(9, (6, 2), 1, 200)], 1).astype(np.float32)
+    x2 = detrand.uniform(10, (6, 2), 0, 300)
+    b = np.concatenate([x2, x2 + detrand.uniform(11, (6, 2), 1, 200)], 1).astype(np.float32)
+    d["xyxy_a"], d["xyxy_b"] = a, b
+    d["xyxy_iou0"] = helper.bbox_iou(torch.from_numpy(a), torch.from_numpy(b), 0, CUDA=False, xcycwh=False).numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_bbox_iou.npz"), **d)
+
+
+# ----------------------------------------------------------------------------- G2 nms_majority
+def nms_case(seed, n, ncls, extent=416.0, quant=None):
+    c = detrand.uniform(seed, (n, 2), 0.1 * extent, 0.9 * extent)
+    s = np.exp(detrand.uniform(seed + 1, (n, 2), math.log(8), math.log(200))).astype(np.float32)
+    sc = detrand.uniform(seed + 2, (n,), 0.1, 1.0)
+    lab = detrand.randint(seed + 3, (n,), 0, ncls).astype(np.float32)
+    P = np.concatenate([c - s / 2, c + s / 2, sc[:, None], lab[:, None]], 1).astype(np.float32)
+    if quant:
+        P[:, :4] = np.round(P[:, :4] / quant) * quant
+    return P
+
+
+def g2_nms_majority(helper):
+    d = {}
+    cases = {
+        "rand200_c5": nms_case(21, 200, 5),
+        "rand1200_c80": nms_case(22, 1200, 80),
+        "cluster_c3": nms_case(23, 300, 3, extent=120.0),        # heavy overlap -> many votes
+        "single_class": nms_case(24, 150, 1, extent=150.0),
+        "quant_ties": nms_case(25, 200, 4, extent=100.0, quant=8.0),  # IoU == thr ties possible
+        "one_box": nms_case(26, 1, 3),
+        "two_same": np.array([[10, 10, 50, 50, 0.9, 1], [10, 10, 50, 50, 0.8, 2]], np.float32),
+        # relabel visible: kept class 0, suppressed {1,1,2} -> majority 1
+        "relabel": np.array([[0, 0, 100, 100, 0.9, 0], [1, 1, 100, 100, 0.8, 1], [0, 1, 99, 100, 0.7, 1],
+                             [2, 0, 100, 99, 0.6, 2], [300, 300, 320, 320, 0.5, 4]], np.float32),
+        # count tie {1,2} -> smallest id 1 ; single class suppressed -> no relabel
+        "count_tie": np.array([[0, 0, 100, 100, 0.9, 5], [1, 1, 100, 100, 0.8, 2], [0, 1, 99, 100, 0.7, 1]], np.float32),
+        "single_supp": np.array([[0, 0, 100, 100, 0.9, 5], [1, 1, 100, 100, 0.8, 2], [0, 1, 99, 100, 0.7, 2]], np.float32),
+        # IoU exactly == 0.6: box [0,0,10,10] vs [0,0,10,6] -> inter 60, union 100
+        "iou_eq_thr": np.array([[0, 0, 10, 10, 0.9, 0], [0, 0, 10, 6, 0.8, 1], [0, 0, 10, 6.5, 0.7, 2]], np.float32),
+    }
+    for name, P in cases.items():
+        d[name + "_in"] = P.copy()
+        for thr, tag in ((0.6, ""), (0.45, "_t45")):
+            if tag and P.shape[0] < 100:
+                continue
+            Pt = torch.from_numpy(P.copy())
+            out = helper.nms_majority(Pt, thr) if tag else helper.nms_majority(Pt)
+            d[name + "_out" + tag] = out.numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_nms_majority.npz"), **d)
+
+
+# ----------------------------------------------------------------------------- G3/G4 YOLOForw
+def run_yolo_train(F, heads, targets):
+    th = [torch.from_numpy(h).clone().requires_grad_(True) for h in heads]
+    tg = [{"bbox": torch.from_numpy(b), "category_id": torch.from_numpy(l)} for b, l in targets]
+    # capture get_target outputs too
+    cap = {}
+    orig = F.get_target
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        cap["r"] = r
+        return r
+    F.get_target = spy
+    loss, sub, stats = F(th, tg)
+    F.get_target = orig
+    loss.backward()
+    tgt, tcls, obj_mask, noobj_mask = cap["r"]
+    return {
+        "loss": loss.detach().numpy(), "sub_losses": sub.numpy(), "stats": stats.numpy(),
+        "tgt": tgt.numpy(), "obj_idx": torch.cat(obj_mask).numpy(),
+        "noobj_bits": np.packbits(noobj_mask.numpy().astype(np.uint8), axis=1, bitorder="little"),
+        "grads": [t.grad.numpy() for t in th],
+    }
+
+
+def g3_yolo(helper, custom, yolo_forw):
+    idf = np.loadtxt(os.path.join(REF, "yolo", "coco_files", "idf.csv"), delimiter=",", skiprows=1,
+                     usecols=(1,)).astype(np.float32)
+    cfgs = [
+        # name, anchors, C, img, grids, Ms, iou_type, idf, full(store inputs+grads) or digest
+        ("coco128", COCO_ANCHORS, 80, 128, (4, 8, 16), (7, 1), 1, None, True),
+        ("coco128_idf", COCO_ANCHORS, 80, 128, (4, 8, 16), (3, 20), 1, idf, True),
+        ("coco128_iou", COCO_ANCHORS, 80, 128, (4, 8, 16), (5, 4), 0, None, True),
+        ("coco128_diou", COCO_ANCHORS, 80, 128, (4, 8, 16), (5, 4), 2, None, True),
+        ("coco128_ciou", COCO_ANCHORS, 80, 128, (4, 8, 16), (5, 4), 3, None, True),
+        ("lvis96_a6", LVIS_ANCHORS, 20, 96, (3, 6, 12), (6, 2, 9), 1, None, True),
+        ("coco416", COCO_ANCHORS, 80, 416, (13, 26, 52), (7, 12), 1, None, False),
+        ("coco640", COCO_ANCHORS, 80, 640, (20, 40, 80), (7, 20), 1, None, False),
+    ]
+    d = {}
+    for i, (name, anchors, C, img, grids, ms, iou_type, idfv, full) in enumerate(cfgs):
+        seed = 1000 + 100 * i
+        na = len(anchors[0])
+        heads = synth_heads(seed, len(ms), na, C, grids)
+        targets = synth_targets(seed + 50, ms, C)
+        if name == "coco128":   # force a duplicate assignment: two GTs of image 0 share a best anchor
+            targets[0][0][1] = targets[0][0][0] + np.float32(1e-3)
+        F = make_yoloforw(yolo_forw, custom, anchors, C, img, iou_type, idfv)
+        r = run_yolo_train(F, heads, targets)
+        meta = np.array([seed, C, img, iou_type, na, len(ms)], np.int64)
+        d[name + "_meta"] = meta
+        d[name + "_grids"] = np.array(grids, np.int64)
+        d[name + "_ms"] = np.array(ms, np.int64)
+        d[name + "_anchors"] = np.array(anchors, np.float64)
+        if idfv is not None:
+            d[name + "_idf"] = idfv
+        for k in ("loss", "sub_losses", "stats", "tgt", "obj_idx", "noobj_bits"):
+            d[f"{name}_{k}"] = r[k]
+        for k, g in enumerate(r["grads"]):
+            if full:
+                d[f"{name}_grad{k}"] = g
+            else:   # digests: sum, abs-sum, and a strided sample
+                flat = g.reshape(-1)
+                d[f"{name}_grad{k}_digest"] = np.array([flat.astype(np.float64).sum(),
+                                                        np.abs(flat).astype(np.float64).sum()])
+                d[f"{name}_grad{k}_sample"] = flat[::997].copy()
+        # inference decode (yolo_forw.py:163-176) on the same heads
+        with torch.no_grad():
+            dec = F([torch.from_numpy(h) for h in heads]).numpy()
+        if full:
+            d[f"{name}_decode"] = dec
+        else:
+            flat = dec.reshape(-1)
+            d[f"{name}_decode_digest"] = np.array([flat.astype(np.float64).sum(), np.abs(flat).astype(np.float64).sum()])
+            d[f"{name}_decode_sample"] = flat[::997].copy()
+    np.savez_compressed(os.path.join(OUT, "g3_yolo_forw.npz"), **d)
+
+
+# ----------------------------------------------------------------------------- G11 test_one_epoch post-proc
+def g11_postproc(helper, custom, yolo_forw):
+    """decode -> get_abs_coord -> score -> threshold -> nms_majority (test_one_epoch.py:21-37)."""
+    C, img, grids = 80, 128, (4, 8, 16)
+    heads = synth_heads(7000, 2, 3, C, grids)
+    # make conf logits high for a few cells so that some boxes pass 0.1
+    F = make_yoloforw(yolo_forw, custom, COCO_ANCHORS, C, img)
+    with torch.no_grad():
+        pred = F([torch.from_numpy(h) for h in heads])
+        pred[:, :, :4] = helper.get_abs_coord(pred[:, :, :4])
+        score = pred[:, :, 4] * (pred[:, :, 5:].max(axis=2)[0])
+        conf = 0.02   # lower than 0.1 so the synthetic case keeps a few hundred boxes
+        mask = score > conf
+        pc = [pred[e][m] for e, m in enumerate(mask)]
+        maj = [torch.cat([p[:, :4], p[:, 4:5] * (p[:, 5:].max(axis=1)[0]).unsqueeze(1),
+                          (p[:, 5:].max(axis=1)[1]).unsqueeze(1)], axis=1) for p in pc]
+        fin = [helper.nms_majority(f.clone()) for f in maj]
+    d = {"meta": np.array([7000, C, img, 2], np.int64), "conf": np.array([conf], np.float32)}
+    for e in range(2):
+        d[f"cand{e}"] = maj[e].numpy()
+        d[f"final{e}"] = fin[e].numpy()
+    np.savez_compressed(os.path.join(OUT, "g11_postproc.npz"), **d)
+
+
+# ----------------------------------------------------------------------------- G9 FocalLoss
+def g9_focal(custom):
+    x = detrand.uniform(900, (257,), -6, 6)
+    t = (detrand.uniform(901, (257,), 0, 1) > 0.7).astype(np.float32)
+    d = {"x": x, "t": t}
+    for gamma, alpha in ((1.0, 0.5), (1.5, 0.25), (2.0, 0.25)):
+        for red in ("sum", "None"):
+            fl = custom.FocalLoss(nn.BCEWithLogitsLoss(reduction=red), gamma=gamma, alpha=alpha)
+            xt = torch.from_numpy(x).clone().requires_grad_(True)
+            out = fl(xt, torch.from_numpy(t))
+            out.sum().backward()
+            d[f"g{gamma}_a{alpha}_{red}"] = out.detach().numpy()
+            d[f"g{gamma}_a{alpha}_{red}_grad"] = xt.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g9_focal.npz"), **d)
+
+
+# ----------------------------------------------------------------------------- G8 darknet / yolohead
+def det_weights(model, seed):
+    """Fill every parameter/buffer deterministically (scale like the reference init)."""
+    sd = model.state_dict()
+    for i, (k, v) in enumerate(sd.items()):
+        if k.endswith("num_batches_tracked"):
+            continue
+        shp = tuple(v.shape)
+        if k.endswith("running_mean"):
+            a = np.zeros(shp, np.float32)
+        elif k.endswith("running_var"):
+            a = np.ones(shp, np.float32)
+        elif "bn" in k and k.endswith("weight"):
+            a = detrand.uniform(seed + i, shp, 0.5, 1.5)
+        elif "bn" in k and k.endswith("bias"):
+            a = detrand.uniform(seed + i, shp, -0.2, 0.2)
+        elif k.endswith("bias"):
+            a = detrand.uniform(seed + i, shp, -0.1, 0.1)
+        else:
+            fan = shp[1] * shp[2] * shp[3]
+            s = math.sqrt(3.0) * math.sqrt(2.0 / fan)   # uniform with the std of N(0, sqrt(2/fan_in))
+            a = detrand.uniform(seed + i, shp, -s, s)
+        v.copy_(torch.from_numpy(a))
+    return [k for k in sd.keys()]
+
+
+def g8_network(yolohead, darknet):
+    d = {}
+    for bname, fn, px in (("darknet_21", darknet.darknet21, 64), ("darknet_53", darknet.darknet53, 64)):
+        yolohead.backbone_fn[bname] = (lambda f: (lambda path: f(None)))(fn)
+        cfg = {"backbone": {"backbone_name": bname, "backbone_pretrained": ""},
+               "dataset": {"anchors": COCO_ANCHORS}, "yolo": {"classes": 80},
+               "neck": {"fpn": False, "spp": False, "spp_bottleneck": True, "pyramids": []}}
+        torch.manual_seed(0)
+        m = yolohead.YoloHead(cfg)
+        keys = det_weights(m, 5000)
+        m.train()
+        x = detrand.uniform(4242, (2, 3, px, px), -2.0, 2.0)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        outs = m(xt)
+        # simple scalar objective with fixed cotangents so backward is reproducible
+        cots = [detrand.uniform(4300 + k, tuple(o.shape), -1.0, 1.0) for k, o in enumerate(outs)]
+        loss = sum((o * torch.from_numpy(c)).sum() for o, c in zip(outs, cots))
+        loss.backward()
+        d[f"{bname}_meta"] = np.array([5000, 4242, 4300, px, 2], np.int64)
+        d[f"{bname}_keys"] = np.array(keys)
+        for k, o in enumerate(outs):
+            d[f"{bname}_out{k}"] = o.detach().numpy()
+        d[f"{bname}_xgrad"] = xt.grad.numpy()
+        names, gn, gs = [], [], []
+        for n, p in m.named_parameters():
+            names.append(n)
+            gn.append(float(p.grad.double().norm()))
+            gs.append(p.grad.reshape(-1)[:: max(1, p.numel() // 16)][:16].numpy().copy())
+        d[f"{bname}_pnames"] = np.array(names)
+        d[f"{bname}_gradnorm"] = np.array(gn)
+        d[f"{bname}_gradsample"] = np.stack([np.pad(s, (0, 16 - len(s))) for s in gs])
+        # BN running stats after one train-mode forward (momentum 0.1)
+        d[f"{bname}_rm_stem"] = m.backbone.bn1.running_mean.numpy().copy()
+        d[f"{bname}_rv_stem"] = m.backbone.bn1.running_var.numpy().copy()
+        # eval-mode forward (running stats) as used by test_one_epoch
+        m.eval()
+        with torch.no_grad():
+            eo = m(torch.from_numpy(x))
+        for k, o in enumerate(eo):
+            d[f"{bname}_evalout{k}"] = o.numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_network.npz"), **d)
+
+
+# ----------------------------------------------------------------------------- torchvision_models side
+def import_tvision():
+    for k in [k for k in sys.modules if k == "utilities" or k.startswith("utilities.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, "torchvision_models"))
+    tv = _stub("torchvision")
+    ops = _stub("torchvision.ops")
+    misc = _stub("torchvision.ops.misc", FrozenBatchNorm2d=nn.BatchNorm2d)
+    tv.ops = ops
+    ops.misc = misc
+    from tvision import _utils
+    from tvision.anchor_utils import AnchorGenerator
+    from tvision.image_list import ImageList
+    return _utils, AnchorGenerator, ImageList
+
+
+def box_iou_np(a, b):
+    """torchvision.ops.box_iou semantics in float32 numpy; used only to feed Matcher."""
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    return (inter / (area_a[:, None] + area_b[None, :] - inter)).astype(np.float32)
+
+
+def synth_gt_xyxy(seed, m, extent=800.0):
+    side = detrand.uniform(seed, (m, 2), 16, 400)
+    tl = detrand.uniform(seed + 1, (m, 2), 0, 1) * (extent - side)
+    return np.concatenate([tl, tl + side], 1).astype(np.float32)
+
+
+def g5_7_tvision():
+    _utils, AnchorGenerator, ImageList = import_tvision()
+    d = {}
+    # G5 anchors: RetinaNet (retinanet.py:357-362) and Faster R-CNN (frcnn.py:186-191) configurations
+    retina_sizes = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in [32, 64, 128, 256, 512])
+    retina_ar = ((0.5, 1.0, 2.0),) * 5
+    frcnn_sizes = ((32,), (64,), (128,), (256,), (512,))
+    frcnn_ar = ((0.5, 1.0, 2.0),) * 5
+    for tag, sizes, ars, img, grids in (
+        ("retina800", retina_sizes, retina_ar, (800, 800), [(100, 100), (50, 50), (25, 25), (13, 13), (7, 7)]),
+        ("frcnn800", frcnn_sizes, frcnn_ar, (800, 800), [(200, 200), (100, 100), (50, 50), (25, 25), (13, 13)]),
+        ("retina800x1216", retina_sizes, retina_ar, (800, 1216), [(100, 152), (50, 76), (25, 38), (13, 19), (7, 10)]),
+        ("retina_small", retina_sizes, retina_ar, (128, 160), [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]),
+    ):
+        ag = AnchorGenerator(sizes, ars)
+        il = ImageList(torch.zeros(2, 3, *img), [img, img])
+        fm = [torch.zeros(2, 1, h, w) for h, w in grids]
+        anc = ag(il, fm)
+        a = anc[0].numpy()
+        assert (anc[1].numpy() == a).all()
+        d[f"anc_{tag}_img"] = np.array(img, np.int64)
+        d[f"anc_{tag}_grids"] = np.array(grids, np.int64)
+        d[f"anc_{tag}_sizes"] = np.array(sizes, np.float64)
+        d[f"anc_{tag}_ars"] = np.array(ars, np.float64)
+        d[f"anc_{tag}_n"] = np.array([a.shape[0]], np.int64)
+        if a.shape[0] < 20000:
+            d[f"anc_{tag}_all"] = a
+        d[f"anc_{tag}_head"] = a[:64].copy()
+        d[f"anc_{tag}_tail"] = a[-64:].copy()
+        d[f"anc_{tag}_sample"] = a[::1009].copy()
+        d[f"anc_{tag}_sum"] = a.astype(np.float64).sum(0)
+        d[f"anc_{tag}_cell"] = np.concatenate([c.numpy() for c in ag.cell_anchors], 0)
+        if tag == "retina800":
+            anchors_retina = a
+        if tag == "frcnn800":
+            anchors_frcnn = a
+    # G6 matcher on restated IoU
+    for tag, hi, lo, lowq, anchors, m in (
+        ("retina", 0.5, 0.4, True, anchors_retina, 7),
+        ("rpn", 0.7, 0.3, True, anchors_frcnn, 7),
+        ("roi", 0.5, 0.5, False, anchors_retina[::53], 5),
+        ("retina_m1", 0.5, 0.4, True, anchors_retina, 1),
+        ("retina_m20", 0.5, 0.4, True, anchors_retina, 20),
+    ):
+        gt = synth_gt_xyxy(600 + m, m)
+        if tag == "retina":
+            gt[1] = gt[0]          # identical GTs -> argmax-over-GT ties (first index wins)
+            gt[2] = anchors[70000]  # GT equal to an anchor -> IoU 1 and symmetric-neighbour ties
+        q = box_iou_np(gt, anchors)
+        mt = _utils.Matcher(hi, lo, allow_low_quality_matches=lowq)(torch.from_numpy(q)).numpy()
+        d[f"match_{tag}_gt"] = gt
+        d[f"match_{tag}_cfg"] = np.array([hi, lo, float(lowq)])
+        d[f"match_{tag}_out"] = mt.astype(np.int32) if anchors.shape[0] < 20000 else np.zeros(0, np.int32)
+        d[f"match_{tag}_nz_idx"] = np.nonzero(mt != -1)[0].astype(np.int64)
+        d[f"match_{tag}_nz_val"] = mt[mt != -1].astype(np.int64)
+        d[f"match_{tag}_n"] = np.array([anchors.shape[0]], np.int64)
+        if tag == "roi":
+            d["match_roi_anchors"] = anchors.copy()
+    # tiny hand-made matcher with explicit ties
+    q = np.array([[0.1, 0.6, 0.6, 0.2, 0.45, 0.0],
+                  [0.1, 0.6, 0.3, 0.2, 0.45, 0.0],
+                  [0.3, 0.1, 0.3, 0.2, 0.10, 0.0]], np.float32)
+    for lowq in (True, False):
+        mt = _utils.Matcher(0.5, 0.4, allow_low_quality_matches=lowq)(torch.from_numpy(q.copy())).numpy()
+        d[f"match_tiny_q"] = q
+        d[f"match_tiny_out_lowq{int(lowq)}"] = mt
+    # G7 box coder
+    for tag, w in (("w1", (1.0, 1.0, 1.0, 1.0)), ("w10", (10.0, 10.0, 5.0, 5.0))):
+        bc = _utils.BoxCoder(w)
+        prop = synth_gt_xyxy(700, 64)
+        ref = prop + detrand.uniform(702, (64, 4), -12, 12)
+        ref[:, 2:] = np.maximum(ref[:, 2:], ref[:, :2] + 1)
+        enc = bc.encode_single(torch.from_numpy(ref), torch.from_numpy(prop)).numpy()
+        codes = detrand.uniform(703, (64, 4), -2.5, 2.5) * np.array(w, np.float32)
+        codes[0, 2] = 50.0 * w[2]   # exceeds bbox_xform_clip -> clamp path
+        codes[1, 3] = 50.0 * w[3]
+        dec = bc.decode_single(torch.from_numpy(codes), torch.from_numpy(prop)).numpy()
+        codes3 = detrand.uniform(704, (64, 12), -2.0, 2.0)   # [n, 4*K] form (roi_heads)
+        dec3 = bc.decode_single(torch.from_numpy(codes3), torch.from_numpy(prop)).numpy()
+        d[f"coder_{tag}_w"] = np.array(w)
+        d[f"coder_{tag}_prop"], d[f"coder_{tag}_ref"], d[f"coder_{tag}_enc"] = prop, ref.astype(np.float32), enc
+        d[f"coder_{tag}_codes"], d[f"coder_{tag}_dec"] = codes.astype(np.float32), dec
+        d[f"coder_{tag}_codes3"], d[f"coder_{tag}_dec3"] = codes3, dec3
+    np.savez_compressed(os.path.join(OUT, "g5_7_tvision.npz"), **d)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    helper, custom, yolo_forw, yolohead, darknet = import_yolo()
+    g1_bbox_iou(helper)
+    g2_nms_majority(helper)
+    g9_focal(custom)
+    g3_yolo(helper, custom, yolo_forw)
+    g11_postproc(helper, custom, yolo_forw)
+    g8_network(yolohead, darknet)
+    g5_7_tvision()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
