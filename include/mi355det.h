@@ -1,0 +1,238 @@
+/* mi355det — C ABI of the MI355X-native detection hot path (libmi355det.so).
+ *
+ * Drop-in boundary for the one hot path of kostas1515/object_detectors.  The
+ * reference has no FFI of its own: its boundary is a set of Python callables.  Each entry point
+ * below names the reference callable (file:line under /root/reference) it replaces; the Python
+ * mirror in object_detectors_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless it is
+ *     marked "host".  The caller owns all buffers (inputs, outputs, workspace).
+ *   - every call enqueues on `stream` (hipStream_t passed as void*) and returns immediately;
+ *     no call synchronises, allocates or copies to the host.
+ *   - return value: 0 = MI355DET_OK, negative = error (mi355det_last_error() gives the text);
+ *     the library never throws and never aborts.
+ *   - data-dependent output sizes (NMS keeps, compaction) are written to a caller-provided
+ *     max-size buffer plus a device-side counter.
+ *   - fp32 for boxes / losses / scores; bf16 (NHWC) for convolution activations and weights.
+ */
+#ifndef MI355DET_H
+#define MI355DET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355DET_OK 0
+#define MI355DET_EINVAL (-1)   /* bad argument / unsupported shape */
+#define MI355DET_ELAUNCH (-2)  /* HIP launch failure */
+#define MI355DET_EWORKSPACE (-3) /* workspace too small */
+
+#define MI355DET_MAX_SCALES 4
+#define MI355DET_MAX_ANCHORS 8
+
+const char* mi355det_last_error(void);
+int mi355det_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * YOLO criterion geometry (yolo/nets/yolo_forw.py:93-119).  Anchor index within an image is
+ * off[k] + (y*W+x)*na + a, scales in the order the head returns them (stride 32, 16, 8).
+ * anchor_w/h are the NORMALISED anchor sizes exactly as the reference computes them in float32:
+ * float32(a_w / (img_size/grid)) / float32(grid).
+ */
+typedef struct {
+  int32_t num_scales, na, num_classes, pad0;
+  float img_size, ignore_thr;
+  int32_t iou_type, pad1;                 /* 0 IoU, 1 GIoU, 2 DIoU, 3 CIoU (helper.py:224-231) */
+  int32_t grid[MI355DET_MAX_SCALES];      /* H == W per scale */
+  int32_t off[MI355DET_MAX_SCALES + 1];   /* prefix sums of grid^2*na; off[num_scales] == N */
+  float anchor_w[MI355DET_MAX_SCALES][MI355DET_MAX_ANCHORS];
+  float anchor_h[MI355DET_MAX_SCALES][MI355DET_MAX_ANCHORS];
+} mi355det_yolo_geom;
+
+/* A head tensor in place: element (b, a, attr, pix) at base + b*sb + (a*attrs+attr)*sc + pix*sp
+ * (elements).  NCHW [bs,A*attrs,H,W]: sc=H*W, sp=1.  NHWC (engine native): sc=1, sp=row pitch. */
+typedef struct {
+  void* ptr;
+  int64_t sb, sc, sp;
+} mi355det_head_view;
+
+typedef struct {
+  float lambda_iou, lambda_xy, lambda_wh, lambda_conf, lambda_no_conf, lambda_cls;
+  float alpha, gamma;          /* custom.FocalLoss (yolo/utilities/custom.py:40-67) */
+  float grad_scale;            /* multiplies every gradient (1/sum(M) is applied internally) */
+  int32_t grad_is_bf16;        /* grad views hold bf16 (engine) instead of fp32 */
+} mi355det_yolo_loss_cfg;
+
+/* helper.bbox_iou (yolo/utilities/helper.py:221-277), broadcast form [M,1,4] x [1,N,4] -> [M,N]
+ * (elementwise form: M==1 rows paired, see `paired`).  xcycwh!=0 converts with get_abs_coord. */
+int mi355det_bbox_iou(const float* bb1, const float* bb2, float* out, int64_t m, int64_t n,
+                      int iou_type, int xcycwh, int paired, void* stream);
+
+/* YOLOForw.get_target (yolo_forw.py:178-208), all images in one launch.
+ *   gt_box [G,4] relative xcycwh, gt_off [bs+1] int32 prefix of per-image GT counts (device).
+ * out: best_key [G] u64 scratch (zeroed by the call), obj_idx [G] int64, tgt [G,4],
+ *      noobj [bs,N] uint8 (1 = contributes to the no-object loss). */
+int mi355det_yolo_assign(const mi355det_yolo_geom* geom, const float* gt_box, const int32_t* gt_off,
+                         int32_t bs, int32_t num_gt, int32_t max_gt_per_img, uint64_t* best_key,
+                         int64_t* obj_idx, float* tgt, uint8_t* noobj, void* stream);
+
+/* YOLOForw.forward, train branch (yolo_forw.py:121-162) fused forward+backward.
+ *   heads/grads: num_scales views (grads may be NULL for forward only; grad buffers must be
+ *   zero-filled by the caller — only conf planes and positive rows are written).
+ *   gt_label [G] int64, idf [C] or NULL (idf_logits, yolo_forw.py:63-67,136).
+ *   partials: float workspace of mi355det_yolo_loss_workspace(bs, N) bytes.
+ *   out12: loss, sub_losses[6] (xy, wh, iou, pos_conf, neg_conf, cls; already / sum(M)), stats[5]. */
+size_t mi355det_yolo_loss_workspace(int32_t bs, int64_t n_anchors);
+int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_cfg* cfg,
+                       const mi355det_head_view* heads, const mi355det_head_view* grads,
+                       const int32_t* gt_off, const int64_t* gt_label, const int64_t* obj_idx,
+                       const float* tgt, const uint8_t* noobj, const float* idf, int32_t bs,
+                       int32_t num_gt, void* workspace, size_t workspace_bytes, float* out12,
+                       void* stream);
+
+/* YOLOForw.forward, inference branch (yolo_forw.py:163-176): out [bs,N,attrs] fp32 contiguous.
+ * softmax_cls!=0: class_loss is CrossEntropy (softmax), else sigmoid. */
+int mi355det_yolo_decode(const mi355det_yolo_geom* geom, const mi355det_head_view* heads,
+                         const float* idf, int32_t bs, int softmax_cls, float* out, void* stream);
+
+/* test_one_epoch.py:24-35: get_abs_coord + score=conf*max(cls) + threshold + row build.
+ * pred [bs,N,attrs] (decoded). cand [bs,max_cand,6] = (x1,y1,x2,y2,score,label), count [bs] int32
+ * (true number of passing boxes, may exceed max_cand: caller must check).  Candidates keep the
+ * anchor order of the reference's boolean mask. */
+size_t mi355det_yolo_candidates_workspace(int32_t bs, int64_t n);
+int mi355det_yolo_candidates(const float* pred, int32_t bs, int64_t n, int32_t attrs, float conf_thr,
+                             float* cand, int32_t* count, int32_t max_cand, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* helper.nms_majority (helper.py:280-382), batched over images.
+ *   boxes [bs,max_n,6], count [bs] int32 (device).  Equal scores are ordered "stable ascending
+ *   argsort" (highest original index first among ties).
+ * out: out_rows [bs,max_n,6] kept rows in keep order with the majority relabel applied,
+ *      out_idx [bs,max_n] int32 original row index, out_count [bs] int32.
+ * max_n <= 16384.  workspace: mi355det_nms_workspace(bs, max_n). */
+size_t mi355det_nms_workspace(int32_t bs, int32_t max_n);
+int mi355det_nms_majority(const float* boxes, const int32_t* count, int32_t bs, int32_t max_n,
+                          float thresh_iou, int32_t num_classes /* labels in [0,num_classes) */, float* out_rows, int32_t* out_idx, int32_t* out_count,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* torchvision.ops.boxes.box_iou (call sites: tvision/retinanet.py:409, rpn.py:192, roi_heads.py:633) */
+int mi355det_box_iou(const float* boxes1, const float* boxes2, float* out, int64_t m, int64_t n,
+                     void* stream);
+
+/* torchvision.ops.boxes.nms / batched_nms (retinanet.py:463, rpn.py:272, roi_heads.py:771).
+ *   boxes [n,4] xyxy, scores [n], idxs [n] int64 or NULL (plain nms); n <= 16384.
+ *   keep [n] int64 in descending-score order (ties: lower index first), keep_count [1] int32. */
+int mi355det_nms(const float* boxes, const float* scores, const int64_t* idxs, int32_t n,
+                 float iou_thr, int64_t* keep, int32_t* keep_count, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* box_iou + Matcher.__call__ (+ set_low_quality_matches_) fused, never materialising [M,N]
+ * (tvision/_utils.py:271-344 after retinanet.py:409).  gt [M,4], anchors [N,4] xyxy.
+ * out matches [N] int64 in {-2,-1,0..M-1}; gt_best [M] uint32 scratch. */
+int mi355det_match_anchors(const float* gt, const float* anchors, int32_t m, int64_t n, float high_thr,
+                           float low_thr, int allow_low_quality, uint32_t* gt_best, int64_t* matches,
+                           void* stream);
+
+/* BoxCoder.encode_single / decode_single (tvision/_utils.py:79-125,190-223).  decode: codes [n,4*k] */
+int mi355det_box_encode(const float* reference_boxes, const float* proposals, float* out, int64_t n,
+                        float wx, float wy, float ww, float wh, void* stream);
+int mi355det_box_decode(const float* codes, const float* boxes, float* out, int64_t n, int32_t k,
+                        float wx, float wy, float ww, float wh, float clip, void* stream);
+
+/* AnchorGenerator.grid_anchors for one level (tvision/anchor_utils.py:98-134):
+ * out [gh*gw*a,4] = shifts(y outer, x inner) + cell[a] ; cell [a,4] from the host (rounded). */
+int mi355det_anchor_grid(const float* cell, int32_t a, int32_t gh, int32_t gw, int32_t stride_h,
+                         int32_t stride_w, float* out, void* stream);
+
+/* torchvision.ops.sigmoid_focal_loss (retinanet.py:137-141) fused forward (+sum) and backward.
+ *   x,t [n] ; scale [k] or NULL multiplies logits per class column (tfidf, retinanet.py:138) with
+ *   n = rows*k; valid [rows] uint8 or NULL row mask; loss_sum [1] (atomically accumulated, caller
+ *   zeroes), grad [n] or NULL = d(sum)/dx * grad_scale. */
+int mi355det_sigmoid_focal_loss(const float* x, const float* t, const float* scale, const uint8_t* valid,
+                                int64_t rows, int32_t k, float alpha, float gamma, float grad_scale,
+                                float* loss_sum, float* grad, void* stream);
+
+/* RetinaNet classification loss without the dense one-hot target (retinanet.py:107-143):
+ *   logits [rows,k], matched [rows] int64 (Matcher output), gt_labels [M] int64. Same outputs. */
+int mi355det_retina_cls_loss(const float* logits, const int64_t* matched, const int64_t* gt_labels,
+                             const float* scale, int64_t rows, int32_t k, float alpha, float gamma,
+                             float grad_scale, float* loss_sum, float* grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution path (yolo/nets/backbone/darknet.py:13-20,41-43,64-66; yolo/nets/yolohead.py:41-61):
+ * NHWC bf16 activations, fp32 accumulation on MFMA.  See conv section in DESIGN.md.
+ */
+typedef struct {
+  int32_t n, h, w, cin;        /* input  [n,h,w,cin], pixel pitch in_ld elements */
+  int32_t ho, wo, cout;        /* output [n,ho,wo,cout], pixel pitch out_ld */
+  int32_t ksize, stride, pad;  /* 1 or 3; 1 or 2; (k-1)/2 */
+  int32_t in_ld, out_ld;
+} mi355det_conv_shape;
+
+/* Forward implicit GEMM: y = conv(x, w) [+ bias]; w packed [cout_pad][k*k*cin] bf16 (K contiguous).
+ *   out_f32 != 0: y is fp32 (head conv_out), else bf16.
+ *   stats != NULL: per-channel sum and sum of squares of y accumulated into stats[0..cout) and
+ *   stats[cout_pad..) (fp32, caller zeroes) for training BatchNorm. */
+int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias,
+                      void* y, int out_f32, float* stats, int32_t cout_pad, void* stream);
+
+/* Data gradient: dx = conv_transpose(dy, w); wt packed for dgrad by mi355det_pack_weights.
+ * residual != NULL adds a bf16 tensor (same shape as dx) in the epilogue (residual-block skip). */
+int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx,
+                        const void* residual, int32_t residual_ld, void* stream);
+
+/* Weight gradient: dw[cout][k*k*cin] fp32 += x^T dy (split over pixels, fp32 atomics; caller zeroes).
+ * dbias != NULL: dbias[cout] += sum_pixels dy. */
+int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw,
+                        float* dbias, void* stream);
+
+/* fp32 master weights [cout][cin][k][k] (torch layout) -> bf16 fwd pack [cout_pad][k][k][cin] and
+ * dgrad pack (stride 1: [cin_pad][k][k][cout] taps flipped; stride 2: 4 parity classes). */
+size_t mi355det_dgrad_pack_elems(const mi355det_conv_shape* s);
+int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, void* w_fwd, int32_t cout_pad,
+                          void* w_dgrad, void* stream);
+/* dw fp32 [cout][k][k][cin] -> torch layout [cout][cin][k][k] (param.grad) */
+int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* grad, void* stream);
+
+/* BatchNorm2d (training) + LeakyReLU(0.1) around the conv (darknet.py:15-16,19-20):
+ *   bn_finalize: stats -> scale/shift (+ running stats update, momentum 0.1, unbiased var).
+ *   bn_act_fwd: a = lrelu(z*scale+shift) [+ residual]   (bf16 in/out, vectorised)
+ *   bn_act_bwd_reduce: per-channel sums of dy and dy*xhat where dy = (g1[+g2]) * lrelu'(.)
+ *   bn_act_bwd_apply: dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat))  (bf16)            */
+int mi355det_bn_finalize(const float* stats, int32_t c, int32_t c_pad, int64_t count, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* scale_shift /* [4*c]: scale, shift, mean, invstd */,
+                         void* stream);
+int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,
+                        float slope, const void* residual, int32_t res_ld, void* out, int32_t out_ld,
+                        void* stream);
+int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
+                               int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,
+                               float slope, float* sums /* [2*c] zeroed by caller */, void* stream);
+int mi355det_bn_act_bwd_apply(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
+                              int32_t z_ld, const float* scale_shift, const float* sums, const float* gamma,
+                              int32_t c, int64_t pixels, float slope, void* dz, int32_t dz_ld,
+                              float* dgamma, float* dbeta, void* stream);
+
+/* nn.Upsample(scale_factor=2, nearest) into a channel slice (yolohead.py:32,80-81) and its adjoint */
+int mi355det_upsample2x_fwd(const void* x, int32_t x_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out,
+                            int32_t out_ld, void* stream);
+int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out,
+                            int32_t out_ld, void* stream);
+
+/* layout / dtype converters at the module boundary */
+int mi355det_nchw_f32_to_nhwc_bf16(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, void* out,
+                                   int32_t out_ld, void* stream);
+int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h,
+                              int32_t w, float* out, void* stream);
+int mi355det_nchw_f32_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, void* out,
+                              int out_is_bf16, int32_t out_ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355DET_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of libmi355det.so — the only way the Python mirror reaches the GPU.
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+Signatures mirror include/mi355det.h one to one.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355det.so")
+
+MAX_SCALES, MAX_ANCHORS = 4, 8
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class YoloGeom(C.Structure):
+    _fields_ = [("num_scales", i32), ("na", i32), ("num_classes", i32), ("pad0", i32),
+                ("img_size", f32), ("ignore_thr", f32), ("iou_type", i32), ("pad1", i32),
+                ("grid", i32 * MAX_SCALES), ("off", i32 * (MAX_SCALES + 1)),
+                ("anchor_w", (f32 * MAX_ANCHORS) * MAX_SCALES), ("anchor_h", (f32 * MAX_ANCHORS) * MAX_SCALES)]
+
+
+class HeadView(C.Structure):
+    _fields_ = [("ptr", vp), ("sb", i64), ("sc", i64), ("sp", i64)]
+
+
+class YoloLossCfg(C.Structure):
+    _fields_ = [("lambda_iou", f32), ("lambda_xy", f32), ("lambda_wh", f32), ("lambda_conf", f32),
+                ("lambda_no_conf", f32), ("lambda_cls", f32), ("alpha", f32), ("gamma", f32),
+                ("grad_scale", f32), ("grad_is_bf16", i32)]
+
+
+class ConvShape(C.Structure):
+    _fields_ = [("n", i32), ("h", i32), ("w", i32), ("cin", i32), ("ho", i32), ("wo", i32), ("cout", i32),
+                ("ksize", i32), ("stride", i32), ("pad", i32), ("in_ld", i32), ("out_ld", i32)]
+
+
+P = C.POINTER
+PROTOTYPES = {
+    # name: (restype, argtypes)
+    "mi355det_last_error": (C.c_char_p, []),
+    "mi355det_version": (C.c_int, []),
+    "mi355det_bbox_iou": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
+    "mi355det_yolo_assign": (C.c_int, [P(YoloGeom), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "mi355det_yolo_loss_workspace": (sz, [i32, i64]),
+    "mi355det_yolo_loss": (C.c_int, [P(YoloGeom), P(YoloLossCfg), P(HeadView), P(HeadView), vp, vp, vp, vp, vp, vp,
+                                      i32, i32, vp, sz, vp, vp]),
+    "mi355det_yolo_decode": (C.c_int, [P(YoloGeom), P(HeadView), vp, i32, C.c_int, vp, vp]),
+    "mi355det_yolo_candidates_workspace": (sz, [i32, i64]),
+    "mi355det_yolo_candidates": (C.c_int, [vp, i32, i64, i32, f32, vp, vp, i32, vp, sz, vp]),
+    "mi355det_nms_workspace": (sz, [i32, i32]),
+    "mi355det_nms_majority": (C.c_int, [vp, vp, i32, i32, f32, i32, vp, vp, vp, vp, sz, vp]),
+    "mi355det_box_iou": (C.c_int, [vp, vp, vp, i64, i64, vp]),
+    "mi355det_nms": (C.c_int, [vp, vp, vp, i32, f32, vp, vp, vp, sz, vp]),
+    "mi355det_match_anchors": (C.c_int, [vp, vp, i32, i64, f32, f32, C.c_int, vp, vp, vp]),
+    "mi355det_box_encode": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
+    "mi355det_box_decode": (C.c_int, [vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, vp]),
+    "mi355det_anchor_grid": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "mi355det_sigmoid_focal_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
+    "mi355det_retina_cls_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
+    "mi355det_conv_fwd": (C.c_int, [P(ConvShape), vp, vp, vp, vp, C.c_int, vp, i32, vp]),
+    "mi355det_conv_dgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp]),
+    "mi355det_conv_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, vp]),
+    "mi355det_dgrad_pack_elems": (sz, [P(ConvShape)]),
+    "mi355det_pack_weights": (C.c_int, [P(ConvShape), vp, vp, i32, vp, vp]),
+    "mi355det_unpack_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp]),
+    "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
+    "mi355det_bn_act_fwd": (C.c_int, [vp, i32, vp, i32, i64, f32, vp, i32, vp, i32, vp]),
+    "mi355det_bn_act_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, f32, vp, vp]),
+    "mi355det_bn_act_bwd_apply": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i64, f32, vp, i32, vp, vp, vp]),
+    "mi355det_upsample2x_fwd": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "mi355det_upsample2x_bwd": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "mi355det_nchw_f32_to_nhwc": (C.c_int, [vp, i32, i32, i32, i32, vp, C.c_int, i32, vp]),
+    "mi355det_nhwc_to_nchw_f32": (C.c_int, [vp, C.c_int, i32, i32, i32, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class Mi355detError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mi355detError(
+                f"{LIB_PATH} not found: build it with `python -m object_detectors_amd.build` "
+                "(there is no CPU/PyTorch fallback for the hot path)")
+        L = C.CDLL(LIB_PATH)
+        missing = []
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype, fn.argtypes = res, args
+        if missing and os.environ.get("MI355DET_PARTIAL") != "1":
+            raise Mi355detError(f"{LIB_PATH} lacks symbols {missing}: rebuild with `python -m object_detectors_amd.build --force`")
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().mi355det_last_error().decode()
+        if status == -1:
+            raise ValueError(f"mi355det {what}: {msg}")
+        raise Mi355detError(f"mi355det {what} failed ({status}): {msg}")
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,609 @@
+// Box kernels: NMS family (majority-vote NMS of the YOLO path, torchvision nms / batched_nms),
+// pairwise box_iou, fused IoU+Matcher, BoxCoder, anchor grid, sigmoid focal loss.
+// Wavefront-reduction / bit-mask kernels, HBM/latency-bound; -ffp-contract=off for bit-exact
+// threshold decisions against the reference's unfused float32 arithmetic.
+#include "common.h"
+
+using namespace mi355;
+
+namespace {
+
+#define NMS_MAX_N 16384
+#define SORT_THREADS 1024
+
+struct NmsWs {   // per-image workspace carve (all offsets in bytes, 16-B aligned)
+  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, stride;
+  int words;
+};
+
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+__host__ __device__ inline NmsWs nms_layout(int max_n) {
+  NmsWs w;
+  w.words = (max_n + 63) / 64;
+  size_t o = 0;
+  w.sorted_idx = o; o = align16(o + sizeof(int) * (size_t)max_n);
+  w.sbox = o;       o = align16(o + sizeof(float4) * (size_t)max_n);
+  w.scls = o;       o = align16(o + sizeof(int) * (size_t)max_n);
+  w.kept = o;       o = align16(o + sizeof(int) * (size_t)max_n);
+  w.remover = o;    o = align16(o + sizeof(int) * (size_t)max_n);
+  w.misc = o;       o = align16(o + 64);
+  w.mask = o;       o = align16(o + sizeof(unsigned long long) * (size_t)max_n * w.words);
+  w.stride = o;
+  return w;
+}
+
+// ---- 1. sort by score (single block bitonic in LDS), gather sorted boxes -------------------
+// MODE 0: nms_majority rows [n,6]; order = reverse of a stable ascending argsort (helper.py:308,320)
+// MODE 1: torchvision nms; descending score, ties -> lower index first; optional category offsets
+template <int MODE>
+__global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                                 const long long* __restrict__ idxs, const int* __restrict__ count,
+                                                                 int n_fixed, int max_n, char* __restrict__ ws_base, NmsWs L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ float smax[SORT_THREADS / WAVE];
+  const int b = blockIdx.x;
+  const int n = count ? min(count[b], max_n) : n_fixed;
+  char* ws = ws_base + (size_t)b * L.stride;
+  int npad = 64;
+  while (npad < n) npad <<= 1;
+  const float* P = boxes + (size_t)b * max_n * (MODE == 0 ? 6 : 4);
+  for (int i = threadIdx.x; i < npad; i += SORT_THREADS) {
+    unsigned long long k = 0;
+    if (i < n) {
+      const float sc = MODE == 0 ? P[(size_t)i * 6 + 4] : scores[i];
+      const unsigned tie = MODE == 0 ? (unsigned)i : 0xFFFFFFFFu - (unsigned)i;
+      k = ((unsigned long long)f2ord(sc) << 32) | tie;
+    }
+    keys[i] = k;
+  }
+  // batched_nms offset: idxs * (max coordinate + 1)   (torchvision batched_nms)
+  float off_scale = 0.f;
+  if (MODE == 1 && idxs) {
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n * 4; i += SORT_THREADS) m = fmaxf(m, P[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x / WAVE] = m;
+    __syncthreads();
+    m = smax[0];
+    for (int w = 1; w < SORT_THREADS / WAVE; ++w) m = fmaxf(m, smax[w]);
+    off_scale = m + 1.0f;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += SORT_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          const bool desc = (i & k) == 0;   // descending overall
+          if (desc ? a < c : a > c) {
+            keys[i] = c;
+            keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int* sorted_idx = (int*)(ws + L.sorted_idx);
+  float4* sbox = (float4*)(ws + L.sbox);
+  int* scls = (int*)(ws + L.scls);
+  for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+    const unsigned tie = (unsigned)(keys[i] & 0xFFFFFFFFull);
+    const int src = MODE == 0 ? (int)tie : (int)(0xFFFFFFFFu - tie);
+    sorted_idx[i] = src;
+    if (MODE == 0) {
+      const float* r = P + (size_t)src * 6;
+      sbox[i] = make_float4(r[0], r[1], r[2], r[3]);
+      scls[i] = (int)r[5];   // (P[:,5]).int()
+    } else {
+      float4 v = *(const float4*)(P + (size_t)src * 4);
+      if (idxs) {
+        const float o = (float)idxs[src] * off_scale;
+        v.x += o; v.y += o; v.z += o; v.w += o;
+      }
+      sbox[i] = v;
+    }
+  }
+  if (threadIdx.x == 0) ((int*)(ws + L.misc))[0] = n;
+}
+
+// IoU variants with the reference's exact operation order
+template <int MODE>
+__device__ __forceinline__ float nms_iou(const float4 s, const float4 r) {   // s = kept box (S), r = remaining
+  const float xx1 = fmaxf(r.x, s.x), yy1 = fmaxf(r.y, s.y), xx2 = fminf(r.z, s.z), yy2 = fminf(r.w, s.w);
+  const float w = fmaxf(xx2 - xx1, 0.0f), h = fmaxf(yy2 - yy1, 0.0f);
+  const float inter = w * h;
+  const float as = (s.z - s.x) * (s.w - s.y), ar = (r.z - r.x) * (r.w - r.y);
+  if (MODE == 0) return inter / ((ar - inter) + as);   // helper.py:362-365
+  return inter / (as + ar - inter);                    // torchvision nms
+}
+
+// ---- 2. bit mask: bit (i,j) j>i set when box j is dropped by box i ------------------------------
+// MODE 0: drop = !(IoU < thr) (helper.py:368 keeps IoU<thr);  MODE 1: drop = IoU > thr
+template <int MODE>
+__global__ __launch_bounds__(WAVE) void nms_mask_kernel(char* __restrict__ ws_base, NmsWs L, float thr) {
+  __shared__ float4 cb[WAVE];
+  const int b = blockIdx.z;
+  char* ws = ws_base + (size_t)b * L.stride;
+  const int n = ((const int*)(ws + L.misc))[0];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj < ti || ti * 64 >= n || tj * 64 >= n) return;
+  const float4* sbox = (const float4*)(ws + L.sbox);
+  const int lane = threadIdx.x;
+  const int j = tj * 64 + lane;
+  cb[lane] = j < n ? sbox[j] : make_float4(0, 0, 0, 0);
+  __syncthreads();
+  const int i = ti * 64 + lane;
+  if (i >= n) return;
+  const float4 s = sbox[i];
+  unsigned long long bits = 0;
+  const int cn = min(64, n - tj * 64);
+  for (int c = (ti == tj ? lane + 1 : 0); c < cn; ++c) {
+    const float v = nms_iou<MODE>(s, cb[c]);
+    const bool drop = MODE == 0 ? !(v < thr) : (v > thr);
+    if (drop) bits |= 1ull << c;
+  }
+  ((unsigned long long*)(ws + L.mask))[(size_t)i * L.words + tj] = bits;
+}
+
+// ---- 3. greedy scan: one wave per image, 64-box tiles resolved in registers ----------------------
+#define SCAN_SLOTS (NMS_MAX_N / 64 / 64)   // 4 words of the removed-bitmap per lane
+__global__ __launch_bounds__(WAVE) void nms_scan_kernel(char* __restrict__ ws_base, NmsWs L, int* __restrict__ out_count) {
+  const int b = blockIdx.x;
+  char* ws = ws_base + (size_t)b * L.stride;
+  const int n = ((const int*)(ws + L.misc))[0];
+  const unsigned long long* mask = (const unsigned long long*)(ws + L.mask);
+  int* kept = (int*)(ws + L.kept);
+  int* remover = (int*)(ws + L.remover);
+  const int lane = threadIdx.x;
+  const int words = (n + 63) / 64;
+  unsigned long long removed[SCAN_SLOTS];
+#pragma unroll
+  for (int s = 0; s < SCAN_SLOTS; ++s) removed[s] = 0;
+  int kc = 0;
+  for (int t = 0; t < words; ++t) {
+    // removed word t lives in lane t%64, slot t/64
+    unsigned long long rw = 0;
+#pragma unroll
+    for (int s = 0; s < SCAN_SLOTS; ++s)
+      if (s == t / 64) rw = removed[s];
+    const unsigned rlo = __shfl((unsigned)rw, t & 63, WAVE), rhi = __shfl((unsigned)(rw >> 32), t & 63, WAVE);
+    const int cn = min(64, n - t * 64);
+    const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+    unsigned long long alive = ~(((unsigned long long)rhi << 32) | rlo) & valid;
+    const int row = t * 64 + lane;
+    const unsigned long long diag = row < n ? mask[(size_t)row * L.words + t] : 0ull;
+    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+    unsigned long long kept_bits = 0;
+    int my_remover = -1;
+    for (int j = 0; j < cn; ++j) {
+      if ((alive >> j) & 1ull) {
+        kept_bits |= 1ull << j;
+        const unsigned long long d =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, j);
+        const unsigned long long newly = alive & d;
+        if ((newly >> lane) & 1ull) my_remover = t * 64 + j;
+        alive &= ~d;
+      }
+    }
+    if (row < n) {   // rows already removed by an earlier tile keep the remover written by the row-OR below
+      if ((kept_bits >> lane) & 1ull) remover[row] = -1;
+      else if (my_remover >= 0) remover[row] = my_remover;
+    }
+    // kept list in order
+    if ((kept_bits >> lane) & 1ull) kept[kc + __popcll(kept_bits & ((1ull << lane) - 1ull))] = row;
+    kc += __popcll(kept_bits);
+    // OR the kept rows into the removed bitmap for words > t, assigning first removers
+    unsigned long long kb = kept_bits;
+    while (kb) {
+      const int j = __ffsll((long long)kb) - 1;
+      kb &= kb - 1;
+      const int krow = t * 64 + j;
+      const unsigned long long* mrow = mask + (size_t)krow * L.words;
+#pragma unroll
+      for (int s = 0; s < SCAN_SLOTS; ++s) {
+        const int w = lane + 64 * s;
+        if (w > t && w < words) {
+          const unsigned long long m = mrow[w];
+          unsigned long long newly = m & ~removed[s];
+          removed[s] |= m;
+          while (newly) {
+            const int bit = __ffsll((long long)newly) - 1;
+            newly &= newly - 1;
+            const int col = w * 64 + bit;
+            if (col < n) remover[col] = krow;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    ((int*)(ws + L.misc))[1] = kc;
+    out_count[b] = kc;
+  }
+}
+
+// ---- 4. majority vote + output (helper.py:369-375) --------------------------------------------
+// One wave per kept box: votes = boxes removed BY this box with IoU > thr; if they span more than
+// one class, relabel to the modal class (count ties -> smallest class id).
+#define VOTE_WAVES 4
+__global__ __launch_bounds__(VOTE_WAVES* WAVE) void nms_vote_kernel(const float* __restrict__ boxes, char* __restrict__ ws_base, NmsWs L,
+                                                                     int max_n, float thr, int num_classes,
+                                                                     float* __restrict__ out_rows, int* __restrict__ out_idx) {
+  extern __shared__ int hist_all[];
+  const int b = blockIdx.y;
+  char* ws = ws_base + (size_t)b * L.stride;
+  const int n = ((const int*)(ws + L.misc))[0];
+  const int kc = ((const int*)(ws + L.misc))[1];
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  int* hist = hist_all + (size_t)wid * num_classes;
+  const float4* sbox = (const float4*)(ws + L.sbox);
+  const int* scls = (const int*)(ws + L.scls);
+  const int* kept = (const int*)(ws + L.kept);
+  const int* remover = (const int*)(ws + L.remover);
+  const int* sorted_idx = (const int*)(ws + L.sorted_idx);
+  for (int c = lane; c < num_classes; c += WAVE) hist[c] = 0;
+  for (int k = blockIdx.x * VOTE_WAVES + wid; k < kc; k += gridDim.x * VOTE_WAVES) {
+    const int pos = kept[k];
+    const float4 s = sbox[pos];
+    int nvote = 0;
+    for (int j = pos + 1 + lane; j < n; j += WAVE) {
+      if (remover[j] == pos) {
+        const float v = nms_iou<0>(s, sbox[j]);
+        if (v > thr) {
+          const int c = scls[j];
+          if (c >= 0 && c < num_classes) atomicAdd(&hist[c], 1);
+          ++nvote;
+        }
+      }
+    }
+    nvote = (int)wave_sum((float)nvote);
+    __threadfence_block();
+    const int src = sorted_idx[pos];
+    const float* r = boxes + ((size_t)b * max_n + src) * 6;
+    float label = r[5];
+    if (nvote > 0) {
+      int best_cnt = 0, best_cls = 0x7FFFFFFF, distinct = 0;
+      for (int c = lane; c < num_classes; c += WAVE) {
+        const int h = hist[c];
+        if (h > 0) {
+          ++distinct;
+          if (h > best_cnt) {   // ascending c within a lane: first maximum = smallest id
+            best_cnt = h;
+            best_cls = c;
+          }
+          hist[c] = 0;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int oc = __shfl_xor(best_cnt, o, WAVE), ok = __shfl_xor(best_cls, o, WAVE);
+        distinct += __shfl_xor(distinct, o, WAVE);
+        if (oc > best_cnt || (oc == best_cnt && ok < best_cls)) {
+          best_cnt = oc;
+          best_cls = ok;
+        }
+      }
+      if (distinct > 1) label = (float)best_cls;
+    }
+    __threadfence_block();
+    if (lane < 6) out_rows[((size_t)b * max_n + k) * 6 + lane] = lane == 5 ? label : r[lane];
+    if (lane == 0) out_idx[(size_t)b * max_n + k] = src;
+  }
+}
+
+__global__ void nms_keep_kernel(char* __restrict__ ws_base, NmsWs L, long long* __restrict__ keep, int* __restrict__ keep_count) {
+  char* ws = ws_base;
+  const int kc = ((const int*)(ws + L.misc))[1];
+  const int* kept = (const int*)(ws + L.kept);
+  const int* sorted_idx = (const int*)(ws + L.sorted_idx);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < kc; k += gridDim.x * blockDim.x) keep[k] = sorted_idx[kept[k]];
+  if (blockIdx.x == 0 && threadIdx.x == 0) keep_count[0] = kc;
+}
+
+// ---- torchvision box_iou ----------------------------------------------------------------------
+__device__ __forceinline__ float tv_iou(const float4 a, const float4 b) {
+  const float area_a = (a.z - a.x) * (a.w - a.y), area_b = (b.z - b.x) * (b.w - b.y);
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f), h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+  const float inter = w * h;
+  return inter / (area_a + area_b - inter);
+}
+
+__global__ void box_iou_kernel(const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, long long m, long long n) {
+  const long long total = m * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / n, c = i - r * n;
+    out[i] = tv_iou(*(const float4*)(b1 + 4 * r), *(const float4*)(b2 + 4 * c));
+  }
+}
+
+// ---- fused box_iou + Matcher (tvision/_utils.py:271-344) ----------------------------------------
+// pass 1: per anchor max over GT (first index on ties) + thresholds; per-GT row max via atomicMax
+// pass 2: low-quality rescue — anchors attaining any GT's row maximum get their argmax back.
+// Algorithmic bytes: N*16 (anchors) + M*16 read, N*8 written (x2 anchors read when rescue is on).
+#define MATCH_THREADS 256
+#define MATCH_MAX_GT 1024
+__global__ __launch_bounds__(MATCH_THREADS) void match_pass1_kernel(const float* __restrict__ gt, const float* __restrict__ anchors, int m,
+                                                                     long long n, float hi, float lo, unsigned* __restrict__ gt_best,
+                                                                     long long* __restrict__ matches) {
+  extern __shared__ float4 sg[];
+  for (int g = threadIdx.x; g < m; g += MATCH_THREADS) sg[g] = *(const float4*)(gt + 4 * (size_t)g);
+  __syncthreads();
+  const long long i = blockIdx.x * (long long)MATCH_THREADS + threadIdx.x;
+  const bool live = i < n;
+  const float4 a = live ? *(const float4*)(anchors + 4 * i) : make_float4(0, 0, 0, 0);
+  float best = -INFINITY;
+  int arg = 0;
+  for (int g = 0; g < m; ++g) {
+    const float v = tv_iou(sg[g], a);
+    if (g == 0 || v > best) {   // first maximum, as torch.max(dim=0)
+      best = v;
+      arg = g;
+    }
+    // per-GT row maximum over anchors
+    unsigned o = live ? f2ord(v) : 0u;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) o = max(o, (unsigned)__shfl_xor((int)o, s, WAVE));
+    if ((threadIdx.x & 63) == 0) atomicMax(gt_best + g, o);
+  }
+  if (live) {
+    long long r = arg;
+    if (best < lo) r = -1;
+    else if (best < hi) r = -2;
+    matches[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(MATCH_THREADS) void match_pass2_kernel(const float* __restrict__ gt, const float* __restrict__ anchors, int m,
+                                                                     long long n, const unsigned* __restrict__ gt_best,
+                                                                     long long* __restrict__ matches) {
+  extern __shared__ float4 sg[];
+  unsigned* sb = (unsigned*)(sg + m);
+  for (int g = threadIdx.x; g < m; g += MATCH_THREADS) {
+    sg[g] = *(const float4*)(gt + 4 * (size_t)g);
+    sb[g] = gt_best[g];
+  }
+  __syncthreads();
+  const long long i = blockIdx.x * (long long)MATCH_THREADS + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = *(const float4*)(anchors + 4 * i);
+  float best = -INFINITY;
+  int arg = 0;
+  bool rescue = false;
+  for (int g = 0; g < m; ++g) {
+    const float v = tv_iou(sg[g], a);
+    if (g == 0 || v > best) {
+      best = v;
+      arg = g;
+    }
+    rescue = rescue || (v == ord2f(sb[g]));
+  }
+  if (rescue) matches[i] = arg;
+}
+
+// ---- BoxCoder (tvision/_utils.py:79-125, 190-223) -------------------------------------------------
+__global__ void box_encode_kernel(const float* __restrict__ ref, const float* __restrict__ prop, float* __restrict__ out, long long n, float wx,
+                                  float wy, float ww, float wh) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float4 p = *(const float4*)(prop + 4 * i), r = *(const float4*)(ref + 4 * i);
+    const float ew = p.z - p.x, eh = p.w - p.y, ecx = p.x + 0.5f * ew, ecy = p.y + 0.5f * eh;
+    const float gw = r.z - r.x, gh = r.w - r.y, gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+    *(float4*)(out + 4 * i) = make_float4(wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * logf(gw / ew), wh * logf(gh / eh));
+  }
+}
+
+__global__ void box_decode_kernel(const float* __restrict__ codes, const float* __restrict__ boxes, float* __restrict__ out, long long n, int k,
+                                  float wx, float wy, float ww, float wh, float clip) {
+  const long long total = n * k;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / k;
+    const float4 b = *(const float4*)(boxes + 4 * r), c = *(const float4*)(codes + 4 * i);
+    const float w = b.z - b.x, h = b.w - b.y, cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+    const float dx = c.x / wx, dy = c.y / wy, dw = fminf(c.z / ww, clip), dh = fminf(c.w / wh, clip);
+    const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+    *(float4*)(out + 4 * i) = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+  }
+}
+
+// ---- AnchorGenerator.grid_anchors, one level (anchor_utils.py:98-134) ----------------------------
+__global__ void anchor_grid_kernel(const float* __restrict__ cell, int a, int gh, int gw, int sh, int sw, float* __restrict__ out) {
+  const long long total = (long long)gh * gw * a;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ai = (int)(i % a);
+    const long long p = i / a;
+    const int x = (int)(p % gw), y = (int)(p / gw);
+    const float fx = (float)x * (float)sw, fy = (float)y * (float)sh;
+    const float4 c = *(const float4*)(cell + 4 * ai);
+    *(float4*)(out + 4 * i) = make_float4(fx + c.x, fy + c.y, fx + c.z, fy + c.w);
+  }
+}
+
+// ---- sigmoid focal loss fused fwd+bwd (torchvision.ops.sigmoid_focal_loss; retinanet.py:137-141) ---
+__device__ __forceinline__ void sfl(float x, float t, float alpha, float gamma, float& loss, float& grad) {
+  const float e = __expf(-fabsf(x));
+  const float ce = fmaxf(x, 0.0f) - x * t + log1pf(e);
+  const float p = x >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+  const float p_t = p * t + (1.0f - p) * (1.0f - t);
+  const float q = 1.0f - p_t;
+  const float mf = gamma == 2.0f ? q * q : powf(q, gamma);
+  const float dmf = gamma == 2.0f ? 2.0f * q : (q > 0.0f ? gamma * powf(q, gamma - 1.0f) : 0.0f);
+  const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
+  loss = ce * mf;
+  grad = (p - t) * mf - ce * dmf * dpt;
+  if (alpha >= 0.0f) {
+    const float a_t = alpha * t + (1.0f - alpha) * (1.0f - t);
+    loss *= a_t;
+    grad *= a_t;
+  }
+}
+
+// TGT_MODE 0: dense target tensor t; 1: target from Matcher output (matched>=0 -> class gt_labels[matched])
+template <int TGT_MODE>
+__global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x, const float* __restrict__ t, const long long* __restrict__ matched,
+                                                    const long long* __restrict__ gt_labels, const float* __restrict__ scale,
+                                                    const unsigned char* __restrict__ valid, long long rows, int k, float alpha, float gamma,
+                                                    float gscale, float* __restrict__ loss_sum, float* __restrict__ grad) {
+  __shared__ float red[4];
+  const long long total = rows * k;
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / k;
+    const int c = (int)(i - r * k);
+    bool ok;
+    float tv;
+    if (TGT_MODE == 0) {
+      ok = !valid || valid[r];
+      tv = t[i];
+    } else {
+      const long long mi = matched[r];
+      ok = mi != -2;   // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135)
+      tv = (mi >= 0 && gt_labels[mi] == c) ? 1.0f : 0.0f;
+    }
+    float g = 0.f;
+    if (ok) {
+      const float s = scale ? scale[c] : 1.0f;
+      float l;
+      sfl(s * x[i], tv, alpha, gamma, l, g);
+      acc += l;
+      g *= s * gscale;
+    }
+    if (grad) grad[i] = g;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+int launch_nms_common(int mode, const float* boxes, const float* scores, const long long* idxs, const int* count, int n_fixed, int bs,
+                      int max_n, float thr, void* workspace, size_t workspace_bytes, int* out_count, hipStream_t st, NmsWs& L) {
+  if (max_n <= 0 || max_n > NMS_MAX_N) return fail(MI355DET_EINVAL, "%s: n must be in [1,%lld]", "nms", NMS_MAX_N);
+  L = nms_layout(max_n);
+  if (workspace_bytes < L.stride * (size_t)bs) return fail(MI355DET_EWORKSPACE, "%s: workspace too small (%lld needed)", "nms", (long long)(L.stride * bs));
+  int npad = 64;
+  while (npad < max_n) npad <<= 1;
+  const size_t lds = (size_t)npad * 8;
+  if (mode == 0) {
+    (void)hipFuncSetAttribute((const void*)nms_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nms_sort_kernel<0>, dim3(bs), dim3(SORT_THREADS), lds, st, boxes, scores, idxs, count, n_fixed, max_n, (char*)workspace, L);
+  } else {
+    (void)hipFuncSetAttribute((const void*)nms_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nms_sort_kernel<1>, dim3(bs), dim3(SORT_THREADS), lds, st, boxes, scores, idxs, count, n_fixed, max_n, (char*)workspace, L);
+  }
+  const int tiles = (max_n + 63) / 64;
+  if (mode == 0) hipLaunchKernelGGL(nms_mask_kernel<0>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);
+  else hipLaunchKernelGGL(nms_mask_kernel<1>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(bs), dim3(WAVE), 0, st, (char*)workspace, L, out_count);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi355det_nms_workspace(int32_t bs, int32_t max_n) {
+  if (max_n <= 0 || bs <= 0) return 0;
+  return nms_layout(max_n).stride * (size_t)bs;
+}
+
+int mi355det_nms_majority(const float* boxes, const int32_t* count, int32_t bs, int32_t max_n, float thresh_iou, int32_t num_classes,
+                          float* out_rows, int32_t* out_idx, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream) {
+  if (bs <= 0 || num_classes <= 0 || num_classes > 8192) return fail(MI355DET_EINVAL, "%s: bad bs / num_classes (1..8192)", "nms_majority");
+  NmsWs L;
+  if (int e = launch_nms_common(0, boxes, nullptr, nullptr, count, 0, bs, max_n, thresh_iou, workspace, workspace_bytes, out_count, S(stream), L))
+    return e;
+  const size_t lds = (size_t)VOTE_WAVES * num_classes * sizeof(int);
+  (void)hipFuncSetAttribute((const void*)nms_vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int vb = max(1, min(64, (max_n + VOTE_WAVES - 1) / VOTE_WAVES));
+  hipLaunchKernelGGL(nms_vote_kernel, dim3(vb, bs), dim3(VOTE_WAVES * WAVE), lds, S(stream), boxes, (char*)workspace, L, max_n, thresh_iou,
+                     num_classes, out_rows, out_idx);
+  return check_launch("nms_majority");
+}
+
+int mi355det_nms(const float* boxes, const float* scores, const int64_t* idxs, int32_t n, float iou_thr, int64_t* keep, int32_t* keep_count,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (n == 0) {
+    if (hipMemsetAsync(keep_count, 0, sizeof(int32_t), S(stream)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: memset failed", "nms");
+    return 0;
+  }
+  NmsWs L;
+  if (int e = launch_nms_common(1, boxes, scores, (const long long*)idxs, nullptr, n, 1, n, iou_thr, workspace, workspace_bytes, keep_count,
+                                S(stream), L))
+    return e;
+  hipLaunchKernelGGL(nms_keep_kernel, dim3(min(64, (n + 255) / 256)), dim3(256), 0, S(stream), (char*)workspace, L, (long long*)keep, keep_count);
+  return check_launch("nms");
+}
+
+int mi355det_box_iou(const float* boxes1, const float* boxes2, float* out, int64_t m, int64_t n, void* stream) {
+  if (m < 0 || n < 0) return fail(MI355DET_EINVAL, "%s: bad shape", "box_iou");
+  if (m * n == 0) return 0;
+  const int blocks = (int)min((long long)4096, (long long)((m * n + 255) / 256));
+  hipLaunchKernelGGL(box_iou_kernel, dim3(blocks), dim3(256), 0, S(stream), boxes1, boxes2, out, (long long)m, (long long)n);
+  return check_launch("box_iou");
+}
+
+int mi355det_match_anchors(const float* gt, const float* anchors, int32_t m, int64_t n, float high_thr, float low_thr, int allow_low_quality,
+                           uint32_t* gt_best, int64_t* matches, void* stream) {
+  // reference raises ValueError on empty inputs (tvision/_utils.py:282-291): the Python mirror does that
+  if (m <= 0 || n <= 0) return fail(MI355DET_EINVAL, "%s: empty ground truth or proposals", "match_anchors");
+  if (m > MATCH_MAX_GT) return fail(MI355DET_EINVAL, "%s: more than %lld GT boxes per image", "match_anchors", MATCH_MAX_GT);
+  if (hipMemsetAsync(gt_best, 0, sizeof(uint32_t) * (size_t)m, S(stream)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: memset failed", "match");
+  const int blocks = (int)((n + MATCH_THREADS - 1) / MATCH_THREADS);
+  hipLaunchKernelGGL(match_pass1_kernel, dim3(blocks), dim3(MATCH_THREADS), sizeof(float4) * m, S(stream), gt, anchors, m, (long long)n, high_thr,
+                     low_thr, gt_best, (long long*)matches);
+  if (allow_low_quality)
+    hipLaunchKernelGGL(match_pass2_kernel, dim3(blocks), dim3(MATCH_THREADS), (sizeof(float4) + sizeof(unsigned)) * m, S(stream), gt, anchors, m,
+                       (long long)n, gt_best, (long long*)matches);
+  return check_launch("match_anchors");
+}
+
+int mi355det_box_encode(const float* reference_boxes, const float* proposals, float* out, int64_t n, float wx, float wy, float ww, float wh,
+                        void* stream) {
+  if (n < 0) return fail(MI355DET_EINVAL, "%s: bad shape", "box_encode");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(box_encode_kernel, dim3((int)min((long long)2048, (long long)((n + 255) / 256))), dim3(256), 0, S(stream), reference_boxes,
+                     proposals, out, (long long)n, wx, wy, ww, wh);
+  return check_launch("box_encode");
+}
+
+int mi355det_box_decode(const float* codes, const float* boxes, float* out, int64_t n, int32_t k, float wx, float wy, float ww, float wh, float clip,
+                        void* stream) {
+  if (n < 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "box_decode");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(box_decode_kernel, dim3((int)min((long long)2048, (long long)((n * k + 255) / 256))), dim3(256), 0, S(stream), codes, boxes,
+                     out, (long long)n, k, wx, wy, ww, wh, clip);
+  return check_launch("box_decode");
+}
+
+int mi355det_anchor_grid(const float* cell, int32_t a, int32_t gh, int32_t gw, int32_t stride_h, int32_t stride_w, float* out, void* stream) {
+  if (a <= 0 || gh <= 0 || gw <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "anchor_grid");
+  const long long total = (long long)a * gh * gw;
+  hipLaunchKernelGGL(anchor_grid_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), cell, a, gh, gw, stride_h,
+                     stride_w, out);
+  return check_launch("anchor_grid");
+}
+
+int mi355det_sigmoid_focal_loss(const float* x, const float* t, const float* scale, const uint8_t* valid, int64_t rows, int32_t k, float alpha,
+                                float gamma, float grad_scale, float* loss_sum, float* grad, void* stream) {
+  if (rows < 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "sigmoid_focal_loss");
+  if (rows == 0) return 0;
+  const int blocks = (int)min((long long)256 * 8, (long long)((rows * k + 255) / 256));
+  hipLaunchKernelGGL(focal_kernel<0>, dim3(blocks), dim3(256), 0, S(stream), x, t, (const long long*)nullptr, (const long long*)nullptr, scale,
+                     valid, (long long)rows, k, alpha, gamma, grad_scale, loss_sum, grad);
+  return check_launch("sigmoid_focal_loss");
+}
+
+int mi355det_retina_cls_loss(const float* logits, const int64_t* matched, const int64_t* gt_labels, const float* scale, int64_t rows, int32_t k,
+                             float alpha, float gamma, float grad_scale, float* loss_sum, float* grad, void* stream) {
+  if (rows < 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "retina_cls_loss");
+  if (rows == 0) return 0;
+  const int blocks = (int)min((long long)256 * 8, (long long)((rows * k + 255) / 256));
+  hipLaunchKernelGGL(focal_kernel<1>, dim3(blocks), dim3(256), 0, S(stream), logits, (const float*)nullptr, (const long long*)matched,
+                     (const long long*)gt_labels, scale, (const unsigned char*)nullptr, (long long)rows, k, alpha, gamma, grad_scale, loss_sum,
+                     grad);
+  return check_launch("retina_cls_loss");
+}
+
+}  // extern "C"

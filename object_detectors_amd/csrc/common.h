@@ -1,0 +1,72 @@
+// Shared helpers for libmi355det (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mi355det.h"
+
+#define WAVE 64
+
+namespace mi355 {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return MI355DET_ELAUNCH;
+  }
+  return MI355DET_OK;
+}
+
+typedef unsigned short bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned lo = __shfl_xor((unsigned)v, o, WAVE);
+    unsigned hi = __shfl_xor((unsigned)(v >> 32), o, WAVE);
+    unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    v = w > v ? w : v;
+  }
+  return v;
+}
+
+// order-preserving float -> uint32 (larger float => larger uint); -0 canonicalised to +0
+__device__ __forceinline__ unsigned f2ord(float f) {
+  f = f + 0.0f;
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(u);
+}
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+}  // namespace mi355

@@ -1,0 +1,707 @@
+// YOLO criterion kernels (wavefront-reduction family, HBM-bound; no MFMA — not contractions).
+// Replaces the per-image Python loops of yolo/nets/yolo_forw.py and yolo/utilities/helper.py.
+// Compiled with -ffp-contract=off: index decisions (argmax, thresholds) must see the same IEEE
+// float32 values as the reference's unfused torch ops.
+#include "common.h"
+
+using namespace mi355;
+
+namespace {
+
+struct Box {
+  float x1, y1, x2, y2;
+};
+
+// helper.get_abs_coord (helper.py:203-217)
+__device__ __forceinline__ Box abs_coord(float xc, float yc, float w, float h) {
+  Box b;
+  b.x1 = xc - w / 2.0f;
+  b.y1 = yc - h / 2.0f;
+  b.x2 = xc + w / 2.0f;
+  b.y2 = yc + h / 2.0f;
+  return b;
+}
+
+// helper.bbox_iou (helper.py:245-277), same operation order, float32
+__device__ __forceinline__ float iou_metric(const Box a, const Box b, int iou_type) {
+  float inter = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.0f) * fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.0f);
+  float w1 = a.x2 - a.x1, h1 = a.y2 - a.y1;
+  float w2 = b.x2 - b.x1, h2 = b.y2 - b.y1;
+  float uni = (w1 * h1 + 1e-16f) + w2 * h2 - inter;
+  float iou = inter / uni;
+  if (iou_type == 0) return iou;
+  float cw = fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1);
+  float ch = fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1);
+  if (iou_type == 1) {
+    float c_area = cw * ch + 1e-16f;
+    return iou - (c_area - uni) / c_area;
+  }
+  float c2 = cw * cw + ch * ch + 1e-16f;
+  float dx = (b.x1 + b.x2) - (a.x1 + a.x2), dy = (b.y1 + b.y2) - (a.y1 + a.y2);
+  float rho2 = dx * dx / 4.0f + dy * dy / 4.0f;
+  if (iou_type == 2) return iou - rho2 / c2;
+  float d = atanf(w2 / h2) - atanf(w1 / h1);
+  float v = 0.40528473456935109f * (d * d);
+  float alpha = v / (1.0f - iou + v);
+  return iou - (rho2 / c2 + v * alpha);
+}
+
+struct Geom {  // LDS copy with dynamic indexing
+  int num_scales, na, num_classes, attrs;
+  float img_size, ignore_thr;
+  int iou_type;
+  int grid[MI355DET_MAX_SCALES];
+  int off[MI355DET_MAX_SCALES + 1];
+  float aw[MI355DET_MAX_SCALES][MI355DET_MAX_ANCHORS];
+  float ah[MI355DET_MAX_SCALES][MI355DET_MAX_ANCHORS];
+};
+
+__device__ __forceinline__ void load_geom(Geom& s, const mi355det_yolo_geom& g) {
+  if (threadIdx.x == 0) {
+    s.num_scales = g.num_scales;
+    s.na = g.na;
+    s.num_classes = g.num_classes;
+    s.attrs = g.num_classes + 5;
+    s.img_size = g.img_size;
+    s.ignore_thr = g.ignore_thr;
+    s.iou_type = g.iou_type;
+#pragma unroll
+    for (int k = 0; k < MI355DET_MAX_SCALES; ++k) {
+      s.grid[k] = g.grid[k];
+      s.off[k] = g.off[k];
+#pragma unroll
+      for (int a = 0; a < MI355DET_MAX_ANCHORS; ++a) {
+        s.aw[k][a] = g.anchor_w[k][a];
+        s.ah[k][a] = g.anchor_h[k][a];
+      }
+    }
+    s.off[MI355DET_MAX_SCALES] = g.off[MI355DET_MAX_SCALES];
+  }
+  __syncthreads();
+}
+
+struct Anchor {
+  float cx, cy, aw, ah, gridf;
+  int scale, pix, a;
+};
+
+// yolo_forw.py:104-114 — anchor n of one image: index off[k] + (y*W+x)*na + a
+__device__ __forceinline__ Anchor anchor_at(const Geom& g, int n) {
+  Anchor r;
+  int k = 0;
+  while (k + 1 < g.num_scales && n >= g.off[k + 1]) ++k;
+  int local = n - g.off[k];
+  r.scale = k;
+  r.a = local % g.na;
+  r.pix = local / g.na;
+  int W = g.grid[k];
+  int y = r.pix / W, x = r.pix - y * W;
+  r.gridf = (float)W;
+  r.cx = ((float)x + 0.5f) / r.gridf;
+  r.cy = ((float)y + 0.5f) / r.gridf;
+  r.aw = g.aw[k][r.a];
+  r.ah = g.ah[k][r.a];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// helper.bbox_iou standalone
+__global__ void bbox_iou_kernel(const float* __restrict__ bb1, const float* __restrict__ bb2, float* __restrict__ out,
+                                long long m, long long n, int iou_type, int xcycwh, int paired) {
+  long long total = paired ? n : m * n;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = paired ? i : i / n, c = paired ? i : i % n;
+    const float4 p = *(const float4*)(bb1 + 4 * r);
+    const float4 q = *(const float4*)(bb2 + 4 * c);
+    Box a, b;
+    if (xcycwh) {
+      a = abs_coord(p.x, p.y, p.z, p.w);
+      b = abs_coord(q.x, q.y, q.z, q.w);
+    } else {
+      a = {p.x, p.y, p.z, p.w};
+      b = {q.x, q.y, q.z, q.w};
+    }
+    out[i] = iou_metric(a, b, iou_type);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// get_target, pass 1 (yolo_forw.py:186-187,200): one thread per (image, anchor); every GT of the
+// image is scored against the anchor generated on the fly (no [M,N] matrix, no anchor table in HBM).
+// Algorithmic bytes per image: M*16 (GT) + N (noobj byte) written.
+#define ASSIGN_THREADS 256
+#define GT_CHUNK 64
+__global__ __launch_bounds__(ASSIGN_THREADS) void yolo_assign_kernel(mi355det_yolo_geom geom, const float* __restrict__ gt_box,
+                                                                      const int* __restrict__ gt_off,
+                                                                      unsigned long long* __restrict__ best_key,
+                                                                      unsigned char* __restrict__ noobj, int n_total) {
+  __shared__ Geom g;
+  __shared__ float4 sgt[GT_CHUNK];
+  __shared__ unsigned long long swave[ASSIGN_THREADS / WAVE][GT_CHUNK];
+  load_geom(g, geom);
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * ASSIGN_THREADS + threadIdx.x;
+  const int g0 = gt_off[b], g1 = gt_off[b + 1];
+  const bool live = n < n_total;
+  Anchor an = anchor_at(g, live ? n : 0);
+  const Box ab = abs_coord(an.cx, an.cy, an.aw, an.ah);
+  const float thr = g.ignore_thr;
+  const int iou_type = g.iou_type;
+  bool below = true;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  for (int c0 = g0; c0 < g1; c0 += GT_CHUNK) {
+    const int cn = min(GT_CHUNK, g1 - c0);
+    __syncthreads();
+    if (threadIdx.x < cn) sgt[threadIdx.x] = *(const float4*)(gt_box + 4 * (size_t)(c0 + threadIdx.x));
+    __syncthreads();
+    for (int j = 0; j < cn; ++j) {
+      const float4 t = sgt[j];
+      const Box gb = abs_coord(t.x, t.y, t.z, t.w);
+      const float v = iou_metric(gb, ab, iou_type);
+      below = below && (v < thr);
+      unsigned long long key = live ? (((unsigned long long)f2ord(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)n)) : 0ull;
+      key = wave_max_u64(key);
+      if (lane == 0) swave[wid][j] = key;
+    }
+    __syncthreads();
+    if (threadIdx.x < cn) {
+      unsigned long long k = swave[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < ASSIGN_THREADS / WAVE; ++w) k = max(k, swave[w][threadIdx.x]);
+      atomicMax(best_key + c0 + threadIdx.x, k);
+    }
+  }
+  if (live) noobj[(size_t)b * n_total + n] = below ? 1 : 0;
+}
+
+// get_target, pass 2 (yolo_forw.py:187-201): decode argmax, targets, clear noobj at the matched anchors
+__global__ void yolo_targets_kernel(mi355det_yolo_geom geom, const float* __restrict__ gt_box, const int* __restrict__ gt_off,
+                                    const unsigned long long* __restrict__ best_key, long long* __restrict__ obj_idx,
+                                    float* __restrict__ tgt, unsigned char* __restrict__ noobj, int bs, int n_total) {
+  __shared__ Geom g;
+  load_geom(g, geom);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = gt_off[bs];
+  if (i >= G) return;
+  int b = 0;
+  while (b + 1 < bs && i >= gt_off[b + 1]) ++b;
+  const unsigned n = 0xFFFFFFFFu - (unsigned)(best_key[i] & 0xFFFFFFFFull);
+  obj_idx[i] = (long long)n;
+  const Anchor an = anchor_at(g, (int)n);
+  const float4 t = *(const float4*)(gt_box + 4 * (size_t)i);
+  float px = t.x * an.gridf, py = t.y * an.gridf;
+  float gx = px - truncf(px), gy = py - truncf(py);
+  gx = fminf(fmaxf(gx, 0.0001f), 0.9999f);
+  gy = fminf(fmaxf(gy, 0.0001f), 0.9999f);
+  float gw = logf(t.z / an.aw + 1e-16f);
+  float gh = logf(t.w / an.ah + 1e-16f);
+  *(float4*)(tgt + 4 * (size_t)i) = make_float4(gx, gy, gw, gh);
+  noobj[(size_t)b * n_total + n] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// custom.FocalLoss on BCE-with-logits (custom.py:50-60): value and d/dx
+__device__ __forceinline__ void focal_bce(float x, float t, float alpha, float gamma, float& loss, float& grad, float& prob) {
+  const float e = __expf(-fabsf(x));
+  const float bce = fmaxf(x, 0.0f) - x * t + log1pf(e);
+  const float p = x >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+  const float p_t = t * p + (1.0f - t) * (1.0f - p);
+  const float af = t * alpha + (1.0f - t) * (1.0f - alpha);
+  const float q = 1.0f - p_t;
+  const float mf = (gamma == 1.0f) ? q : (gamma == 2.0f ? q * q : powf(q, gamma));
+  loss = bce * (af * mf);
+  const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
+  float dmf;
+  if (gamma == 1.0f) dmf = -dpt;
+  else if (gamma == 2.0f) dmf = -2.0f * q * dpt;
+  else dmf = q > 0.0f ? -gamma * powf(q, gamma - 1.0f) * dpt : 0.0f;
+  grad = af * ((p - t) * mf + bce * dmf);
+  prob = p;
+}
+
+template <bool BF16>
+__device__ __forceinline__ void grad_store(void* base, long long off, float v) {
+  if (BF16) ((bf16_t*)base)[off] = f2bf(v);
+  else ((float*)base)[off] = v;
+}
+template <bool BF16>
+__device__ __forceinline__ void grad_add(void* base, long long off, float v) {
+  if (BF16) ((bf16_t*)base)[off] = f2bf(bf2f(((bf16_t*)base)[off]) + v);
+  else ((float*)base)[off] += v;
+}
+
+struct Views {
+  mi355det_head_view h[MI355DET_MAX_SCALES];
+};
+
+// No-object confidence term (yolo_forw.py:131-133,144): one thread per (image, anchor), lanes run
+// over pixels within an anchor plane.  Per-block partials {loss, sum sigmoid, count}.
+#define DENSE_THREADS 256
+template <bool BF16>
+__global__ __launch_bounds__(DENSE_THREADS) void yolo_noobj_kernel(mi355det_yolo_geom geom, Views heads, Views grads, int has_grad,
+                                                                    const unsigned char* __restrict__ noobj, float alpha,
+                                                                    float gamma, float gscale, float* __restrict__ partials,
+                                                                    int n_total) {
+  __shared__ Geom g;
+  __shared__ float red[DENSE_THREADS / WAVE][3];
+  load_geom(g, geom);
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * DENSE_THREADS + threadIdx.x;   // plane-major index: scale, anchor a, pixel
+  float l = 0.f, s = 0.f, c = 0.f;
+  if (t < n_total) {
+    int k = 0;
+    while (k + 1 < g.num_scales && t >= g.off[k + 1]) ++k;
+    const int local = t - g.off[k];
+    const int hw = g.grid[k] * g.grid[k];
+    const int a = local / hw, pix = local - a * hw;
+    const int n = g.off[k] + pix * g.na + a;
+    const long long ch = (long long)a * g.attrs + 4;
+    const mi355det_head_view hv = heads.h[k];
+    const float x = ((const float*)hv.ptr)[b * hv.sb + ch * hv.sc + pix * hv.sp];
+    if (noobj[(size_t)b * n_total + n]) {
+      float loss, grad, p;
+      focal_bce(x, 0.0f, alpha, gamma, loss, grad, p);
+      l = loss;
+      s = p;
+      c = 1.0f;
+      if (has_grad) {
+        const mi355det_head_view gv = grads.h[k];
+        grad_store<BF16>(gv.ptr, b * gv.sb + ch * gv.sc + pix * gv.sp, grad * gscale);
+      }
+    }
+  }
+  l = wave_sum(l);
+  s = wave_sum(s);
+  c = wave_sum(c);
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  if (lane == 0) {
+    red[wid][0] = l;
+    red[wid][1] = s;
+    red[wid][2] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < DENSE_THREADS / WAVE; ++w) v += red[w][threadIdx.x];
+    partials[((size_t)b * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
+  }
+}
+
+// forward-mode duals over the 4 raw box logits, for d(IoU metric)/d(raw)
+struct D4 {
+  float v, d[4];
+};
+__device__ __forceinline__ D4 dconst(float v) { return {v, {0, 0, 0, 0}}; }
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) { return {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}}; }
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) { return {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}}; }
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) {
+  return {a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2], a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+  const float q = a.v / b.v, ib = 1.0f / b.v;
+  return {q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib, (a.d[3] - q * b.d[3]) * ib}};
+}
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return a.v <= b.v ? a : b; }
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return a.v >= b.v ? a : b; }
+__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v > 0.0f ? a : dconst(fmaxf(a.v, 0.0f)); }
+__device__ __forceinline__ D4 datan(D4 a) {
+  const float s = 1.0f / (1.0f + a.v * a.v);
+  return {atanf(a.v), {a.d[0] * s, a.d[1] * s, a.d[2] * s, a.d[3] * s}};
+}
+
+struct DBox {
+  D4 x1, y1, x2, y2;
+};
+__device__ __forceinline__ D4 iou_metric_dual(const DBox a, const DBox b, int iou_type) {
+  const D4 eps = dconst(1e-16f);
+  D4 inter = dclamp0(dmin(a.x2, b.x2) - dmax(a.x1, b.x1)) * dclamp0(dmin(a.y2, b.y2) - dmax(a.y1, b.y1));
+  D4 w1 = a.x2 - a.x1, h1 = a.y2 - a.y1, w2 = b.x2 - b.x1, h2 = b.y2 - b.y1;
+  D4 uni = (w1 * h1 + eps) + w2 * h2 - inter;
+  D4 iou = inter / uni;
+  if (iou_type == 0) return iou;
+  D4 cw = dmax(a.x2, b.x2) - dmin(a.x1, b.x1), ch = dmax(a.y2, b.y2) - dmin(a.y1, b.y1);
+  if (iou_type == 1) {
+    D4 ca = cw * ch + eps;
+    return iou - (ca - uni) / ca;
+  }
+  D4 c2 = cw * cw + ch * ch + eps;
+  D4 dx = (b.x1 + b.x2) - (a.x1 + a.x2), dy = (b.y1 + b.y2) - (a.y1 + a.y2);
+  D4 rho2 = dx * dx / dconst(4.0f) + dy * dy / dconst(4.0f);
+  if (iou_type == 2) return iou - rho2 / c2;
+  D4 d = datan(w2 / h2) - datan(w1 / h1);
+  D4 v = dconst(0.40528473456935109f) * (d * d);
+  const float alpha = v.v / (1.0f - iou.v + v.v);   // no_grad in the reference (helper.py:273-274)
+  return iou - (rho2 / c2 + v * dconst(alpha));
+}
+
+// Positive terms (yolo_forw.py:123-150 + transform_pred + get_stats): one wave per image walks its
+// GTs in order (duplicate anchor assignments accumulate, like the reference's gather/scatter).
+// partial layout per image: xy, wh, iou_loss, pos_conf, cls, iou_sum, pconf_sum, pcls_sum
+#define POS_NP 8
+template <bool BF16>
+__global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom, mi355det_yolo_loss_cfg cfg, Views heads, Views grads,
+                                                         int has_grad, const int* __restrict__ gt_off,
+                                                         const long long* __restrict__ gt_label,
+                                                         const long long* __restrict__ obj_idx, const float* __restrict__ tgt,
+                                                         const float* __restrict__ idf, float inv_ng,
+                                                         float* __restrict__ pos_partials) {
+  __shared__ Geom g;
+  load_geom(g, geom);
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int C = g.num_classes;
+  float acc[POS_NP];
+#pragma unroll
+  for (int i = 0; i < POS_NP; ++i) acc[i] = 0.f;
+  const float gs = cfg.grad_scale * inv_ng;
+  for (int i = gt_off[b]; i < gt_off[b + 1]; ++i) {
+    const int n = (int)obj_idx[i];
+    const Anchor an = anchor_at(g, n);
+    const mi355det_head_view hv = heads.h[an.scale];
+    const float* hp = (const float*)hv.ptr + b * hv.sb + (long long)an.pix * hv.sp;
+    const long long ch0 = (long long)an.a * g.attrs;
+    float r[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = hp[(ch0 + k) * hv.sc];
+    const float4 t = *(const float4*)(tgt + 4 * (size_t)i);
+    // --- box terms (every lane computes them redundantly; lane k<5 writes gradient k)
+    const float sx = 1.0f / (1.0f + __expf(-r[0])), sy = 1.0f / (1.0f + __expf(-r[1]));
+    const float stride = g.img_size / an.gridf;
+    // transform_pred (yolo_forw.py:217-218,227-228): pixels
+    D4 px = {(sx + an.cx * an.gridf - 0.5f) * stride, {sx * (1 - sx) * stride, 0, 0, 0}};
+    D4 py = {(sy + an.cy * an.gridf - 0.5f) * stride, {0, sy * (1 - sy) * stride, 0, 0}};
+    const float pwv = __expf(r[2]) * an.aw * an.gridf * stride, phv = __expf(r[3]) * an.ah * an.gridf * stride;
+    D4 pw = {pwv, {0, 0, pwv, 0}}, ph = {phv, {0, 0, 0, phv}};
+    const float gxv = (t.x + an.cx * an.gridf - 0.5f) * stride, gyv = (t.y + an.cy * an.gridf - 0.5f) * stride;
+    const float gwv = __expf(t.z) * an.aw * an.gridf * stride, ghv = __expf(t.w) * an.ah * an.gridf * stride;
+    const D4 two = dconst(2.0f);
+    DBox pb = {px - pw / two, py - ph / two, px + pw / two, py + ph / two};
+    DBox gb = {dconst(gxv - gwv / 2.0f), dconst(gyv - ghv / 2.0f), dconst(gxv + gwv / 2.0f), dconst(gyv + ghv / 2.0f)};
+    const D4 iou = iou_metric_dual(pb, gb, g.iou_type);
+    float pl, pg, pp;
+    focal_bce(r[4], 1.0f, cfg.alpha, cfg.gamma, pl, pg, pp);
+    const float dxy0 = sx - t.x, dxy1 = sy - t.y, dwh0 = r[2] - t.z, dwh1 = r[3] - t.w;
+    acc[0] += cfg.lambda_xy * (dxy0 * dxy0 + dxy1 * dxy1);
+    acc[1] += cfg.lambda_wh * (dwh0 * dwh0 + dwh1 * dwh1);
+    acc[2] += cfg.lambda_iou * (1.0f - iou.v);
+    acc[3] += cfg.lambda_conf * pl;
+    acc[5] += iou.v;
+    acc[6] += pp;
+    // --- class term: CE(idf*logits, label) (yolo_forw.py:136); lanes over classes
+    const int label = (int)gt_label[i];
+    float m = -INFINITY, mr = -INFINITY;
+    for (int c = lane; c < C; c += WAVE) {
+      const float raw = hp[(ch0 + 5 + c) * hv.sc];
+      const float z = idf ? idf[c] * raw : raw;
+      m = fmaxf(m, z);
+      mr = fmaxf(mr, raw);
+    }
+    m = wave_max(m);
+    mr = wave_max(mr);
+    float se = 0.f, ser = 0.f, zl = 0.f, rl = 0.f;
+    for (int c = lane; c < C; c += WAVE) {
+      const float raw = hp[(ch0 + 5 + c) * hv.sc];
+      const float z = idf ? idf[c] * raw : raw;
+      se += __expf(z - m);
+      ser += __expf(raw - mr);
+      if (c == label) {
+        zl = z;
+        rl = raw;
+      }
+    }
+    se = wave_sum(se);
+    ser = wave_sum(ser);
+    zl = wave_sum(zl);
+    rl = wave_sum(rl);
+    acc[4] += cfg.lambda_cls * ((m + __logf(se)) - zl);
+    acc[7] += __expf(rl - mr) / ser;   // softmax(raw)[label] (transform_pred :222, get_stats :243)
+    if (has_grad) {
+      const mi355det_head_view gv = grads.h[an.scale];
+      const long long gb0 = b * gv.sb + (long long)an.pix * gv.sp;
+      if (lane < 5) {
+        float gr;
+        if (lane == 0) gr = cfg.lambda_xy * 2.0f * dxy0 * sx * (1 - sx) - cfg.lambda_iou * iou.d[0];
+        else if (lane == 1) gr = cfg.lambda_xy * 2.0f * dxy1 * sy * (1 - sy) - cfg.lambda_iou * iou.d[1];
+        else if (lane == 2) gr = cfg.lambda_wh * 2.0f * dwh0 - cfg.lambda_iou * iou.d[2];
+        else if (lane == 3) gr = cfg.lambda_wh * 2.0f * dwh1 - cfg.lambda_iou * iou.d[3];
+        else gr = cfg.lambda_conf * pg;
+        grad_add<BF16>(gv.ptr, gb0 + (ch0 + lane) * gv.sc, gr * gs);
+      }
+      for (int c = lane; c < C; c += WAVE) {
+        const float raw = hp[(ch0 + 5 + c) * hv.sc];
+        const float w = idf ? idf[c] : 1.0f;
+        const float z = w * raw;
+        float gr = __expf(z - m) / se - (c == label ? 1.0f : 0.0f);
+        grad_add<BF16>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * w * gr * gs);
+      }
+    }
+  }
+  if (lane < POS_NP) pos_partials[(size_t)b * POS_NP + lane] = acc[lane];
+}
+
+// Final reduction in a fixed order (deterministic): out12 = loss, sub_losses[6], stats[5]
+__global__ void yolo_reduce_kernel(const float* __restrict__ dense_partials, int n_dense, const float* __restrict__ pos_partials,
+                                   int bs, float lambda_no_conf, float ng, int num_classes, float* __restrict__ out12) {
+  __shared__ double sh[256][3];
+  double a[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < n_dense; i += blockDim.x)
+    for (int k = 0; k < 3; ++k) a[k] += (double)dense_partials[(size_t)i * 3 + k];
+  for (int k = 0; k < 3; ++k) sh[threadIdx.x][k] = a[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double d[3] = {0, 0, 0};
+    for (int t = 0; t < (int)blockDim.x; ++t)
+      for (int k = 0; k < 3; ++k) d[k] += sh[t][k];
+    double p[POS_NP];
+    for (int k = 0; k < POS_NP; ++k) p[k] = 0;
+    for (int b = 0; b < bs; ++b)
+      for (int k = 0; k < POS_NP; ++k) p[k] += (double)pos_partials[(size_t)b * POS_NP + k];
+    const double neg = lambda_no_conf * d[0];
+    const double sub[6] = {p[0], p[1], p[2], p[3], neg, p[4]};
+    double loss = 0;
+    for (int k = 0; k < 6; ++k) loss += sub[k];
+    out12[0] = (float)(loss / ng);
+    for (int k = 0; k < 6; ++k) out12[1 + k] = (float)(sub[k] / ng);
+    out12[7] = (float)(p[5] / ng);                         // avg_iou
+    out12[8] = (float)(p[6] / ng);                         // pos_conf
+    out12[9] = (float)(d[2] > 0 ? d[1] / d[2] : NAN);      // no_obj_conf (mean of empty = nan, like torch)
+    out12[10] = (float)(p[7] / ng);                        // pos_class
+    out12[11] = (float)((ng - p[7]) / (ng * (double)(num_classes - 1)));   // neg_class
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Inference decode (yolo_forw.py:163-176): one wave per (image, anchor) row, lanes over attributes.
+// Algorithmic bytes: 2 * bs*N*attrs*4.
+#define DEC_WAVES 4
+__global__ __launch_bounds__(DEC_WAVES* WAVE) void yolo_decode_kernel(mi355det_yolo_geom geom, Views heads, const float* __restrict__ idf,
+                                                                       int softmax_cls, float* __restrict__ out, int n_total,
+                                                                       long long rows) {
+  __shared__ Geom g;
+  load_geom(g, geom);
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int C = g.num_classes, attrs = g.attrs;
+  for (long long row = (long long)blockIdx.x * DEC_WAVES + wid; row < rows; row += (long long)gridDim.x * DEC_WAVES) {
+    const int b = (int)(row / n_total), n = (int)(row - (long long)b * n_total);
+    const Anchor an = anchor_at(g, n);
+    const mi355det_head_view hv = heads.h[an.scale];
+    const float* hp = (const float*)hv.ptr + b * hv.sb + (long long)an.pix * hv.sp + (long long)an.a * attrs * hv.sc;
+    float* op = out + row * attrs;
+    const float stride = g.img_size / an.gridf;
+    if (lane < 5) {
+      const float x = hp[lane * hv.sc];
+      float v;
+      if (lane == 0) v = (1.0f / (1.0f + __expf(-x)) + an.cx * an.gridf - 0.5f) * stride;
+      else if (lane == 1) v = (1.0f / (1.0f + __expf(-x)) + an.cy * an.gridf - 0.5f) * stride;
+      else if (lane == 2) v = __expf(x) * an.aw * an.gridf * stride;
+      else if (lane == 3) v = __expf(x) * an.ah * an.gridf * stride;
+      else v = 1.0f / (1.0f + __expf(-x));
+      op[lane] = v;
+    }
+    if (softmax_cls) {
+      float m = -INFINITY;
+      for (int c = lane; c < C; c += WAVE) {
+        const float z = (idf ? idf[c] : 1.0f) * hp[(5 + c) * hv.sc];
+        m = fmaxf(m, z);
+      }
+      m = wave_max(m);
+      float se = 0.f;
+      for (int c = lane; c < C; c += WAVE) se += __expf((idf ? idf[c] : 1.0f) * hp[(5 + c) * hv.sc] - m);
+      se = wave_sum(se);
+      const float inv = 1.0f / se;
+      for (int c = lane; c < C; c += WAVE) op[5 + c] = __expf((idf ? idf[c] : 1.0f) * hp[(5 + c) * hv.sc] - m) * inv;
+    } else {
+      for (int c = lane; c < C; c += WAVE) op[5 + c] = 1.0f / (1.0f + __expf(-(idf ? idf[c] : 1.0f) * hp[(5 + c) * hv.sc]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// test_one_epoch.py:24-35 — score = conf*max(cls) (first maximum, as torch.max), one wave per row;
+// then per image an ORDERED compaction (the reference's boolean-mask order) of rows with score>thr.
+__global__ __launch_bounds__(DEC_WAVES* WAVE) void yolo_score_kernel(const float* __restrict__ pred, long long rows, int attrs,
+                                                                      float* __restrict__ score, int* __restrict__ label) {
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int C = attrs - 5;
+  for (long long row = (long long)blockIdx.x * DEC_WAVES + wid; row < rows; row += (long long)gridDim.x * DEC_WAVES) {
+    const float* p = pred + row * attrs;
+    float best = -INFINITY;
+    int arg = 0x7FFFFFFF;
+    for (int c = lane; c < C; c += WAVE) {
+      const float v = p[5 + c];
+      if (v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, WAVE);
+      const int oa = __shfl_xor(arg, o, WAVE);
+      if (ob > best || (ob == best && oa < arg)) {
+        best = ob;
+        arg = oa;
+      }
+    }
+    if (lane == 0) {
+      score[row] = p[4] * best;
+      label[row] = arg;
+    }
+  }
+}
+
+#define CAND_THREADS 1024
+__global__ __launch_bounds__(CAND_THREADS) void yolo_candidates_kernel(const float* __restrict__ pred, const float* __restrict__ score,
+                                                                        const int* __restrict__ label, long long n, int attrs,
+                                                                        float conf_thr, float* __restrict__ cand,
+                                                                        int* __restrict__ count, int max_cand) {
+  __shared__ int wsum[CAND_THREADS / WAVE];
+  __shared__ int base;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (long long n0 = 0; n0 < n; n0 += CAND_THREADS) {
+    const long long i = n0 + threadIdx.x;
+    const float sc = i < n ? score[(size_t)b * n + i] : 0.0f;
+    const bool pass = i < n && sc > conf_thr;
+    const unsigned long long bal = __ballot(pass);
+    const int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wid] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    if (pass) {
+      const int dst = off + wpre;
+      if (dst < max_cand) {
+        const float* p = pred + ((size_t)b * n + i) * attrs;
+        float* o = cand + ((size_t)b * max_cand + dst) * 6;
+        o[0] = p[0] - p[2] / 2.0f;   // helper.get_abs_coord
+        o[1] = p[1] - p[3] / 2.0f;
+        o[2] = p[0] + p[2] / 2.0f;
+        o[3] = p[1] + p[3] / 2.0f;
+        o[4] = sc;
+        o[5] = (float)label[(size_t)b * n + i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < CAND_THREADS / WAVE; ++w) t += wsum[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[b] = base;
+}
+
+int check_geom(const mi355det_yolo_geom* g) {
+  if (!g) return fail(MI355DET_EINVAL, "%s: null geometry", "yolo");
+  if (g->num_scales < 1 || g->num_scales > MI355DET_MAX_SCALES || g->na < 1 || g->na > MI355DET_MAX_ANCHORS || g->num_classes < 1)
+    return fail(MI355DET_EINVAL, "%s: unsupported geometry (scales=%lld, anchors=%lld)", "yolo", g->num_scales, g->na);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355det_bbox_iou(const float* bb1, const float* bb2, float* out, int64_t m, int64_t n, int iou_type, int xcycwh, int paired,
+                      void* stream) {
+  if (m < 0 || n < 0 || iou_type < 0 || iou_type > 3) return fail(MI355DET_EINVAL, "%s: bad shape/iou_type", "bbox_iou");
+  const long long total = paired ? n : m * n;
+  if (total == 0) return 0;
+  const int blocks = (int)min((long long)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(bbox_iou_kernel, dim3(blocks), dim3(256), 0, S(stream), bb1, bb2, out, (long long)m, (long long)n, iou_type, xcycwh,
+                     paired);
+  return check_launch("bbox_iou");
+}
+
+int mi355det_yolo_assign(const mi355det_yolo_geom* geom, const float* gt_box, const int32_t* gt_off, int32_t bs, int32_t num_gt,
+                         int32_t max_gt_per_img, uint64_t* best_key, int64_t* obj_idx, float* tgt, uint8_t* noobj, void* stream) {
+  if (int e = check_geom(geom)) return e;
+  (void)max_gt_per_img;
+  const int N = geom->off[geom->num_scales];
+  if (bs <= 0 || num_gt < 0) return fail(MI355DET_EINVAL, "%s: bad batch", "yolo_assign");
+  if (num_gt > 0) {
+    if (hipMemsetAsync(best_key, 0, sizeof(uint64_t) * (size_t)num_gt, S(stream)) != hipSuccess)
+      return fail(MI355DET_ELAUNCH, "%s: memset failed", "yolo_assign");
+  }
+  hipLaunchKernelGGL(yolo_assign_kernel, dim3((N + ASSIGN_THREADS - 1) / ASSIGN_THREADS, bs), dim3(ASSIGN_THREADS), 0, S(stream), *geom,
+                     gt_box, gt_off, (unsigned long long*)best_key, noobj, N);
+  if (num_gt > 0)
+    hipLaunchKernelGGL(yolo_targets_kernel, dim3((num_gt + 255) / 256), dim3(256), 0, S(stream), *geom, gt_box, gt_off,
+                       (const unsigned long long*)best_key, (long long*)obj_idx, tgt, noobj, bs, N);
+  return check_launch("yolo_assign");
+}
+
+size_t mi355det_yolo_loss_workspace(int32_t bs, int64_t n_anchors) {
+  const size_t dense_blocks = (size_t)bs * ((n_anchors + DENSE_THREADS - 1) / DENSE_THREADS);
+  return (dense_blocks * 3 + (size_t)bs * POS_NP) * sizeof(float);
+}
+
+int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_cfg* cfg, const mi355det_head_view* heads,
+                       const mi355det_head_view* grads, const int32_t* gt_off, const int64_t* gt_label, const int64_t* obj_idx,
+                       const float* tgt, const uint8_t* noobj, const float* idf, int32_t bs, int32_t num_gt, void* workspace,
+                       size_t workspace_bytes, float* out12, void* stream) {
+  if (int e = check_geom(geom)) return e;
+  if (!cfg || !heads || bs <= 0 || num_gt <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments (num_gt must be > 0)", "yolo_loss");
+  const int N = geom->off[geom->num_scales];
+  if (workspace_bytes < mi355det_yolo_loss_workspace(bs, N)) return fail(MI355DET_EWORKSPACE, "%s: workspace too small", "yolo_loss");
+  Views hv, gv;
+  for (int k = 0; k < MI355DET_MAX_SCALES; ++k) {
+    hv.h[k] = k < geom->num_scales ? heads[k] : mi355det_head_view{nullptr, 0, 0, 0};
+    gv.h[k] = (grads && k < geom->num_scales) ? grads[k] : mi355det_head_view{nullptr, 0, 0, 0};
+  }
+  const int has_grad = grads != nullptr;
+  const int dblocks = (N + DENSE_THREADS - 1) / DENSE_THREADS;
+  float* dense_p = (float*)workspace;
+  float* pos_p = dense_p + (size_t)bs * dblocks * 3;
+  const float inv_ng = 1.0f / (float)num_gt;
+  const float gscale = cfg->lambda_no_conf * cfg->grad_scale * inv_ng;
+  if (cfg->grad_is_bf16) {
+    hipLaunchKernelGGL(yolo_noobj_kernel<true>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,
+                       cfg->alpha, cfg->gamma, gscale, dense_p, N);
+    hipLaunchKernelGGL(yolo_pos_kernel<true>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,
+                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, pos_p);
+  } else {
+    hipLaunchKernelGGL(yolo_noobj_kernel<false>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,
+                       cfg->alpha, cfg->gamma, gscale, dense_p, N);
+    hipLaunchKernelGGL(yolo_pos_kernel<false>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,
+                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, pos_p);
+  }
+  hipLaunchKernelGGL(yolo_reduce_kernel, dim3(1), dim3(256), 0, S(stream), dense_p, bs * dblocks, pos_p, bs, cfg->lambda_no_conf,
+                     (float)num_gt, geom->num_classes, out12);
+  return check_launch("yolo_loss");
+}
+
+int mi355det_yolo_decode(const mi355det_yolo_geom* geom, const mi355det_head_view* heads, const float* idf, int32_t bs, int softmax_cls,
+                         float* out, void* stream) {
+  if (int e = check_geom(geom)) return e;
+  if (!heads || bs <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "yolo_decode");
+  const int N = geom->off[geom->num_scales];
+  Views hv;
+  for (int k = 0; k < MI355DET_MAX_SCALES; ++k) hv.h[k] = k < geom->num_scales ? heads[k] : mi355det_head_view{nullptr, 0, 0, 0};
+  const long long rows = (long long)bs * N;
+  const int blocks = (int)min((long long)256 * 16, (rows + DEC_WAVES - 1) / DEC_WAVES);
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3(blocks), dim3(DEC_WAVES * WAVE), 0, S(stream), *geom, hv, idf, softmax_cls, out, N, rows);
+  return check_launch("yolo_decode");
+}
+
+size_t mi355det_yolo_candidates_workspace(int32_t bs, int64_t n) { return (size_t)bs * (size_t)n * 8; }
+
+int mi355det_yolo_candidates(const float* pred, int32_t bs, int64_t n, int32_t attrs, float conf_thr, float* cand, int32_t* count,
+                             int32_t max_cand, void* workspace, size_t workspace_bytes, void* stream) {
+  if (bs <= 0 || n <= 0 || attrs < 6 || max_cand <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "yolo_candidates");
+  if (workspace_bytes < mi355det_yolo_candidates_workspace(bs, n)) return fail(MI355DET_EWORKSPACE, "%s: workspace too small", "yolo_candidates");
+  float* score = (float*)workspace;
+  int* label = (int*)(score + (size_t)bs * n);
+  const long long rows = (long long)bs * n;
+  const int blocks = (int)min((long long)256 * 16, (rows + DEC_WAVES - 1) / DEC_WAVES);
+  hipLaunchKernelGGL(yolo_score_kernel, dim3(blocks), dim3(DEC_WAVES * WAVE), 0, S(stream), pred, rows, attrs, score, label);
+  hipLaunchKernelGGL(yolo_candidates_kernel, dim3(bs), dim3(CAND_THREADS), 0, S(stream), pred, score, label, (long long)n, attrs, conf_thr,
+                     cand, count, max_cand);
+  return check_launch("yolo_candidates");
+}
+
+}  // extern "C"

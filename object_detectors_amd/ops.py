@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C ABI (include/mi355det.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation below runs
+in libmi355det.so.  All tensors must live on the GPU; nothing falls back to torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import HeadView, YoloGeom, YoloLossCfg, check, lib, ptr, stream_ptr
+
+
+def _f32c(t):
+    if not t.is_cuda:
+        raise ValueError("mi355det ops need CUDA/HIP tensors (no CPU fallback)")
+    return t.contiguous().float()
+
+
+# ----------------------------------------------------------------------------------------- YOLO
+def make_geom(anchors, num_classes, img_size, grids, iou_type=1, ignore_thr=0.5):
+    """anchors: per scale list of (w,h) pixels, scale order = head order (stride 32,16,8).
+    Normalised anchor sizes are computed exactly like yolo_forw.py:99,108-113 (float64 divide,
+    float32 store, float32 divide by grid)."""
+    import numpy as np
+    g = YoloGeom()
+    ns, na = len(grids), len(anchors[0])
+    if ns > _lib.MAX_SCALES or na > _lib.MAX_ANCHORS:
+        raise ValueError("unsupported number of scales / anchors per scale")
+    g.num_scales, g.na, g.num_classes = ns, na, num_classes
+    g.img_size, g.ignore_thr, g.iou_type = float(img_size), float(ignore_thr), int(iou_type)
+    off = 0
+    for k, gr in enumerate(grids):
+        g.grid[k] = int(gr)
+        g.off[k] = off
+        off += gr * gr * na
+        stride = img_size / gr
+        for a, (aw, ah) in enumerate(anchors[k]):
+            g.anchor_w[k][a] = float(np.float32(np.float32(aw / stride) / np.float32(gr)))
+            g.anchor_h[k][a] = float(np.float32(np.float32(ah / stride) / np.float32(gr)))
+    for k in range(ns, _lib.MAX_SCALES + 1):
+        g.off[k] = off
+    return g
+
+
+def head_views(heads, attrs_total):
+    """NCHW-shaped tensors [bs, A*attrs, H, W] with any (dense-pixel) strides -> HeadView array."""
+    arr = (HeadView * _lib.MAX_SCALES)()
+    keep = []
+    for k, t in enumerate(heads):
+        if t.dim() != 4 or t.shape[1] != attrs_total:
+            raise ValueError(f"head {k}: expected [bs,{attrs_total},H,W], got {tuple(t.shape)}")
+        if t.dtype != torch.float32 or t.stride(2) != t.shape[3] * t.stride(3):
+            t = t.float().contiguous()
+        keep.append(t)
+        arr[k].ptr = t.data_ptr()
+        arr[k].sb, arr[k].sc, arr[k].sp = t.stride(0), t.stride(1), t.stride(3)
+    return arr, keep
+
+
+def flatten_targets(targets, device):
+    """list of {'bbox': [M,4], 'category_id': [M]} -> (boxes [G,4] f32, labels [G] i64, off [bs+1] i32, counts)."""
+    counts = [int(t["bbox"].shape[0]) for t in targets]
+    boxes = torch.cat([t["bbox"].reshape(-1, 4) for t in targets]).to(device=device, dtype=torch.float32).contiguous()
+    labels = torch.cat([t["category_id"].reshape(-1) for t in targets]).to(device=device, dtype=torch.int64).contiguous()
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    off = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+    return boxes, labels, off, counts
+
+
+def bbox_iou(bb1, bb2, iou_type, xcycwh=True):
+    """helper.bbox_iou: broadcast [M,1,4]x[1,N,4] -> [M,N], or same-shape [n,4] -> [n]."""
+    bb1, bb2 = _f32c(bb1), _f32c(bb2)
+    if bb1.dim() == 3 and bb2.dim() == 3 and bb1.shape[1] == 1 and bb2.shape[0] == 1:
+        m, n = bb1.shape[0], bb2.shape[1]
+        out = torch.empty((m, n), device=bb1.device, dtype=torch.float32)
+        check(lib().mi355det_bbox_iou(ptr(bb1), ptr(bb2), ptr(out), m, n, int(iou_type), int(xcycwh), 0, stream_ptr()), "bbox_iou")
+        return out
+    if bb1.shape != bb2.shape or bb1.shape[-1] != 4:
+        raise ValueError("bbox_iou: shapes must be [M,1,4]x[1,N,4] or equal [...,4]")
+    n = bb1.numel() // 4
+    out = torch.empty(bb1.shape[:-1], device=bb1.device, dtype=torch.float32)
+    check(lib().mi355det_bbox_iou(ptr(bb1), ptr(bb2), ptr(out), 1, n, int(iou_type), int(xcycwh), 1, stream_ptr()), "bbox_iou")
+    return out
+
+
+def yolo_assign(geom, boxes, off, bs, counts):
+    """YOLOForw.get_target for the whole batch -> (obj_idx [G] i64, tgt [G,4], noobj [bs,N] u8)."""
+    dev = boxes.device
+    G, N = boxes.shape[0], geom.off[geom.num_scales]
+    key = torch.empty(max(G, 1), device=dev, dtype=torch.int64)
+    obj_idx = torch.empty(G, device=dev, dtype=torch.int64)
+    tgt = torch.empty((G, 4), device=dev, dtype=torch.float32)
+    noobj = torch.empty((bs, N), device=dev, dtype=torch.uint8)
+    check(lib().mi355det_yolo_assign(C.byref(geom), ptr(boxes), ptr(off), bs, G, max(counts) if counts else 0, ptr(key),
+                                     ptr(obj_idx), ptr(tgt), ptr(noobj), stream_ptr()), "yolo_assign")
+    return obj_idx, tgt, noobj
+
+
+def yolo_loss(geom, cfg, hviews, gviews, off, labels, obj_idx, tgt, noobj, idf, bs, G):
+    dev = labels.device
+    N = geom.off[geom.num_scales]
+    wsb = lib().mi355det_yolo_loss_workspace(bs, N)
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    out12 = torch.empty(12, device=dev, dtype=torch.float32)
+    check(lib().mi355det_yolo_loss(C.byref(geom), C.byref(cfg), hviews, gviews, ptr(off), ptr(labels), ptr(obj_idx), ptr(tgt),
+                                   ptr(noobj), ptr(idf), bs, G, ptr(ws), wsb, ptr(out12), stream_ptr()), "yolo_loss")
+    return out12
+
+
+def yolo_decode(geom, hviews, idf, bs, softmax_cls=True):
+    N, attrs = geom.off[geom.num_scales], geom.num_classes + 5
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((bs, N, attrs), device=dev, dtype=torch.float32)
+    check(lib().mi355det_yolo_decode(C.byref(geom), hviews, ptr(idf), bs, int(softmax_cls), ptr(out), stream_ptr()), "yolo_decode")
+    return out
+
+
+def yolo_candidates(pred, conf_thr, max_cand=None):
+    """test_one_epoch.py:24-35 -> (cand [bs,max_cand,6], count [bs] i32)."""
+    pred = _f32c(pred)
+    bs, n, attrs = pred.shape
+    max_cand = int(max_cand or min(n, 16384))
+    cand = torch.empty((bs, max_cand, 6), device=pred.device, dtype=torch.float32)
+    count = torch.empty(bs, device=pred.device, dtype=torch.int32)
+    wsb = lib().mi355det_yolo_candidates_workspace(bs, n)
+    ws = torch.empty(wsb, device=pred.device, dtype=torch.uint8)
+    check(lib().mi355det_yolo_candidates(ptr(pred), bs, n, attrs, float(conf_thr), ptr(cand), ptr(count), max_cand, ptr(ws), wsb,
+                                         stream_ptr()), "yolo_candidates")
+    return cand, count
+
+
+def nms_majority_batched(boxes, count, thresh_iou, num_classes):
+    """boxes [bs,max_n,6], count [bs] i32 -> (rows [bs,max_n,6], idx [bs,max_n] i32, kept [bs] i32)."""
+    boxes = _f32c(boxes)
+    bs, max_n, _ = boxes.shape
+    rows = torch.empty_like(boxes)
+    idx = torch.empty((bs, max_n), device=boxes.device, dtype=torch.int32)
+    kept = torch.empty(bs, device=boxes.device, dtype=torch.int32)
+    wsb = lib().mi355det_nms_workspace(bs, max_n)
+    ws = torch.empty(wsb, device=boxes.device, dtype=torch.uint8)
+    check(lib().mi355det_nms_majority(ptr(boxes), ptr(count), bs, max_n, float(thresh_iou), int(num_classes), ptr(rows), ptr(idx),
+                                      ptr(kept), ptr(ws), wsb, stream_ptr()), "nms_majority")
+    return rows, idx, kept
+
+
+# ------------------------------------------------------------------------------- torchvision side
+def box_iou(boxes1, boxes2):
+    b1, b2 = _f32c(boxes1), _f32c(boxes2)
+    out = torch.empty((b1.shape[0], b2.shape[0]), device=b1.device, dtype=torch.float32)
+    check(lib().mi355det_box_iou(ptr(b1), ptr(b2), ptr(out), b1.shape[0], b2.shape[0], stream_ptr()), "box_iou")
+    return out
+
+
+def nms(boxes, scores, iou_threshold, idxs=None):
+    boxes, scores = _f32c(boxes), _f32c(scores)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty(0, device=boxes.device, dtype=torch.int64)
+    if idxs is not None:
+        idxs = idxs.to(torch.int64).contiguous()
+    keep = torch.empty(n, device=boxes.device, dtype=torch.int64)
+    cnt = torch.empty(1, device=boxes.device, dtype=torch.int32)
+    wsb = lib().mi355det_nms_workspace(1, n)
+    ws = torch.empty(wsb, device=boxes.device, dtype=torch.uint8)
+    check(lib().mi355det_nms(ptr(boxes), ptr(scores), ptr(idxs), n, float(iou_threshold), ptr(keep), ptr(cnt), ptr(ws), wsb,
+                             stream_ptr()), "nms")
+    return keep[: int(cnt.item())]
+
+
+def match_anchors(gt, anchors, high, low, allow_low_quality):
+    gt, anchors = _f32c(gt), _f32c(anchors)
+    m, n = gt.shape[0], anchors.shape[0]
+    if m == 0:
+        raise ValueError("No ground-truth boxes available for one of the images during training")
+    if n == 0:
+        raise ValueError("No proposal boxes available for one of the images during training")
+    best = torch.empty(m, device=gt.device, dtype=torch.int32)
+    out = torch.empty(n, device=gt.device, dtype=torch.int64)
+    check(lib().mi355det_match_anchors(ptr(gt), ptr(anchors), m, n, float(high), float(low), int(allow_low_quality), ptr(best),
+                                       ptr(out), stream_ptr()), "match_anchors")
+    return out
+
+
+def box_encode(reference_boxes, proposals, weights):
+    r, p = _f32c(reference_boxes), _f32c(proposals)
+    out = torch.empty_like(p)
+    check(lib().mi355det_box_encode(ptr(r), ptr(p), ptr(out), p.shape[0], *[float(w) for w in weights], stream_ptr()), "box_encode")
+    return out
+
+
+def box_decode(rel_codes, boxes, weights, clip):
+    c, b = _f32c(rel_codes), _f32c(boxes)
+    n, k = b.shape[0], c.shape[1] // 4
+    out = torch.empty_like(c)
+    check(lib().mi355det_box_decode(ptr(c), ptr(b), ptr(out), n, k, *[float(w) for w in weights], float(clip), stream_ptr()),
+          "box_decode")
+    return out
+
+
+def anchor_grid(cell, gh, gw, sh, sw):
+    cell = _f32c(cell)
+    out = torch.empty((gh * gw * cell.shape[0], 4), device=cell.device, dtype=torch.float32)
+    check(lib().mi355det_anchor_grid(ptr(cell), cell.shape[0], gh, gw, int(sh), int(sw), ptr(out), stream_ptr()), "anchor_grid")
+    return out
+
+
+def sigmoid_focal_loss_sum(x, t, alpha, gamma, scale=None, valid=None, want_grad=True, grad_scale=1.0):
+    """sum-reduced loss and its gradient wrt x in one pass: x,t [rows,k]."""
+    x, t = _f32c(x), _f32c(t)
+    rows, k = (x.shape[0], x.shape[1]) if x.dim() == 2 else (x.numel(), 1)
+    loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+    grad = torch.empty_like(x) if want_grad else None
+    if valid is not None:
+        valid = valid.to(torch.uint8).contiguous()
+    check(lib().mi355det_sigmoid_focal_loss(ptr(x), ptr(t), ptr(scale), ptr(valid), rows, k, float(alpha), float(gamma),
+                                            float(grad_scale), ptr(loss), ptr(grad), stream_ptr()), "sigmoid_focal_loss")
+    return loss[0], grad
+
+
+def retina_cls_loss_sum(logits, matched, gt_labels, alpha, gamma, scale=None, want_grad=True, grad_scale=1.0):
+    logits = _f32c(logits)
+    rows, k = logits.shape
+    loss = torch.zeros(1, device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    check(lib().mi355det_retina_cls_loss(ptr(logits), ptr(matched.contiguous()), ptr(gt_labels.to(torch.int64).contiguous()),
+                                         ptr(scale), rows, k, float(alpha), float(gamma), float(grad_scale), ptr(loss), ptr(grad),
+                                         stream_ptr()), "retina_cls_loss")
+    return loss[0], grad

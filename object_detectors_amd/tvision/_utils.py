@@ -1,0 +1,73 @@
+"""Mirror of torchvision_models/tvision/_utils.py: Matcher and BoxCoder over HIP kernels."""
+import math
+
+import torch
+
+from .. import ops
+
+
+class BoxCoder(object):
+    """tvision/_utils.py:128-223."""
+
+    def __init__(self, weights, bbox_xform_clip=math.log(1000. / 16)):
+        self.weights = weights
+        self.bbox_xform_clip = bbox_xform_clip
+
+    def encode(self, reference_boxes, proposals):
+        boxes_per_image = [len(b) for b in reference_boxes]
+        targets = self.encode_single(torch.cat(reference_boxes, dim=0), torch.cat(proposals, dim=0))
+        return targets.split(boxes_per_image, 0)
+
+    def encode_single(self, reference_boxes, proposals):
+        if proposals.shape[0] == 0:
+            return proposals.new_zeros((0, 4))
+        return ops.box_encode(reference_boxes, proposals, self.weights)
+
+    def decode(self, rel_codes, boxes):
+        assert isinstance(boxes, (list, tuple))
+        concat = torch.cat(boxes, dim=0)
+        box_sum = concat.shape[0]
+        if box_sum > 0:
+            rel_codes = rel_codes.reshape(box_sum, -1)
+        pred = self.decode_single(rel_codes, concat)
+        if box_sum > 0:
+            pred = pred.reshape(box_sum, -1, 4)
+        return pred
+
+    def decode_single(self, rel_codes, boxes):
+        if boxes.shape[0] == 0:
+            return rel_codes.new_zeros(rel_codes.shape)
+        return ops.box_decode(rel_codes, boxes, self.weights, self.bbox_xform_clip)
+
+
+class Matcher(object):
+    """tvision/_utils.py:226-344.  `__call__` keeps the reference's [M,N] quality-matrix signature;
+    `match_boxes` is the fused form (box_iou + matching, no [M,N] matrix) used by the model mirrors."""
+    BELOW_LOW_THRESHOLD = -1
+    BETWEEN_THRESHOLDS = -2
+
+    def __init__(self, high_threshold, low_threshold, allow_low_quality_matches=False):
+        assert low_threshold <= high_threshold
+        self.high_threshold = high_threshold
+        self.low_threshold = low_threshold
+        self.allow_low_quality_matches = allow_low_quality_matches
+
+    def match_boxes(self, gt_boxes, anchors):
+        return ops.match_anchors(gt_boxes, anchors, self.high_threshold, self.low_threshold, self.allow_low_quality_matches)
+
+    def __call__(self, match_quality_matrix):
+        q = match_quality_matrix
+        if q.numel() == 0:
+            if q.shape[0] == 0:
+                raise ValueError("No ground-truth boxes available for one of the images during training")
+            raise ValueError("No proposal boxes available for one of the images during training")
+        # a materialised matrix was handed over: thresholds on it (same semantics as the fused kernel)
+        vals, matches = q.max(dim=0)
+        allm = matches.clone()
+        matches[vals < self.low_threshold] = self.BELOW_LOW_THRESHOLD
+        matches[(vals >= self.low_threshold) & (vals < self.high_threshold)] = self.BETWEEN_THRESHOLDS
+        if self.allow_low_quality_matches:
+            best, _ = q.max(dim=1)
+            pred = torch.where(q == best[:, None])[1]
+            matches[pred] = allm[pred]
+        return matches

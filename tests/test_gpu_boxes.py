@@ -1,0 +1,148 @@
+"""GPU parity for the torchvision_models-side kernels vs oracle/tv_oracle.py and reference fixtures."""
+import numpy as np
+import pytest
+
+from oracle import detrand
+from oracle import tv_oracle as tv
+from tests.test_oracle_tv import ANCHOR_TAGS, build_anchors
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+@pytest.mark.parametrize("tag", ANCHOR_TAGS)
+def test_anchor_generator_gpu(golden, tag):
+    from object_detectors_amd.tvision.anchor_utils import AnchorGenerator
+    g = golden("g5_7_tvision")
+    sizes = tuple(tuple(r) for r in g[f"anc_{tag}_sizes"].tolist())
+    ars = tuple(tuple(r) for r in g[f"anc_{tag}_ars"].tolist())
+    img = tuple(int(v) for v in g[f"anc_{tag}_img"])
+    grids = [tuple(int(v) for v in r) for r in g[f"anc_{tag}_grids"]]
+
+    class IL:
+        tensors = torch.zeros(2, 3, *img)
+        image_sizes = [img, img]
+    ag = AnchorGenerator(sizes, ars)
+    out = ag(IL, [torch.zeros(2, 1, h, w, device=dev()) for h, w in grids])
+    a = out[0].cpu().numpy()
+    assert np.array_equal(a, build_anchors(g, tag))           # oracle, bit-exact
+    assert np.array_equal(a[:64], g[f"anc_{tag}_head"]) and np.array_equal(a[::1009], g[f"anc_{tag}_sample"])
+
+
+def test_box_iou_gpu():
+    a = np.concatenate([detrand.uniform(1, (37, 2), 0, 500), detrand.uniform(2, (37, 2), 500, 900)], 1)
+    b = np.concatenate([detrand.uniform(3, (1000, 2), 0, 600), detrand.uniform(4, (1000, 2), 300, 900)], 1)
+    b[5] = b[4]
+    from object_detectors_amd.tvision import boxes
+    got = boxes.box_iou(T(a), T(b)).cpu().numpy()
+    assert np.array_equal(got, tv.box_iou(a, b), equal_nan=True)
+
+
+@pytest.mark.parametrize("tag,anc", [("retina", "retina800"), ("rpn", "frcnn800"), ("roi", None),
+                                     ("retina_m1", "retina800"), ("retina_m20", "retina800")])
+def test_match_anchors_gpu(golden, tag, anc):
+    from object_detectors_amd.tvision._utils import Matcher
+    g = golden("g5_7_tvision")
+    anchors = g["match_roi_anchors"] if anc is None else build_anchors(g, anc)
+    hi, lo, lowq = g[f"match_{tag}_cfg"]
+    m = Matcher(float(hi), float(lo), bool(lowq)).match_boxes(T(g[f"match_{tag}_gt"]), T(anchors)).cpu().numpy()
+    nz = np.nonzero(m != -1)[0]
+    assert np.array_equal(nz, g[f"match_{tag}_nz_idx"])          # reference fixture, bit-exact
+    assert np.array_equal(m[nz], g[f"match_{tag}_nz_val"])
+
+
+def test_matcher_errors_gpu():
+    from object_detectors_amd.tvision._utils import Matcher
+    with pytest.raises(ValueError):
+        Matcher(0.5, 0.4, True).match_boxes(torch.zeros(0, 4, device=dev()), torch.zeros(5, 4, device=dev()))
+    with pytest.raises(ValueError):
+        Matcher(0.5, 0.4, True)(torch.zeros(0, 5, device=dev()))
+
+
+@pytest.mark.parametrize("tag", ["w1", "w10"])
+def test_box_coder_gpu(golden, tag):
+    from object_detectors_amd.tvision._utils import BoxCoder
+    g = golden("g5_7_tvision")
+    bc = BoxCoder(tuple(g[f"coder_{tag}_w"].tolist()))
+    enc = bc.encode_single(T(g[f"coder_{tag}_ref"]), T(g[f"coder_{tag}_prop"])).cpu().numpy()
+    np.testing.assert_allclose(enc, g[f"coder_{tag}_enc"], rtol=1e-5, atol=1e-6)
+    dec = bc.decode_single(T(g[f"coder_{tag}_codes"]), T(g[f"coder_{tag}_prop"])).cpu().numpy()
+    np.testing.assert_allclose(dec, g[f"coder_{tag}_dec"], rtol=1e-5, atol=1e-3)
+    dec3 = bc.decode_single(T(g[f"coder_{tag}_codes3"]), T(g[f"coder_{tag}_prop"])).cpu().numpy()
+    np.testing.assert_allclose(dec3, g[f"coder_{tag}_dec3"], rtol=1e-5, atol=1e-3)
+
+
+def nms_inputs(seed, n, extent=800.0):
+    c = detrand.uniform(seed, (n, 2), 0, extent)
+    s = np.exp(detrand.uniform(seed + 1, (n, 2), np.log(8), np.log(400))).astype(np.float32)
+    boxes = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+    scores = detrand.uniform(seed + 2, (n,), 0, 1)
+    return boxes, scores
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 5000, 10000])
+def test_nms_gpu(n):
+    from object_detectors_amd.tvision import boxes as B
+    boxes, scores = nms_inputs(300 + n, n)
+    if n >= 64:
+        scores[10] = scores[20]     # equal scores: lower index first
+    keep = B.nms(T(boxes), T(scores), 0.5).cpu().numpy()
+    assert np.array_equal(keep, tv.nms(boxes, scores, 0.5))
+
+
+@pytest.mark.parametrize("k", [1, 5, 90, 1203])
+def test_batched_nms_gpu(k):
+    from object_detectors_amd.tvision import boxes as B
+    boxes, scores = nms_inputs(900 + k, 5000)
+    idxs = detrand.randint(77 + k, (5000,), 0, k)
+    keep = B.batched_nms(T(boxes), T(scores), T(idxs), 0.5).cpu().numpy()
+    assert np.array_equal(keep, tv.batched_nms(boxes, scores, idxs, 0.5))
+    assert B.batched_nms(torch.zeros(0, 4, device=dev()), torch.zeros(0, device=dev()), torch.zeros(0, dtype=torch.int64, device=dev()), 0.5).numel() == 0
+
+
+def test_sigmoid_focal_loss_gpu():
+    from object_detectors_amd.tvision.focal_loss import sigmoid_focal_loss
+    x = detrand.uniform(11, (4000, 91), -8, 8)
+    t = (detrand.uniform(12, (4000, 91), 0, 1) > 0.98).astype(np.float32)
+    xt = T(x).requires_grad_(True)
+    loss = sigmoid_focal_loss(xt, T(t), reduction="sum")
+    loss.backward()
+    l, g = tv.sigmoid_focal_loss(x, t)
+    np.testing.assert_allclose(loss.item(), l.astype(np.float64).sum(), rtol=1e-4)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-6)
+
+
+def test_retinanet_cls_loss_gpu(golden):
+    from object_detectors_amd.tvision._utils import Matcher
+    from object_detectors_amd.tvision.focal_loss import retinanet_classification_loss
+    g = golden("g5_7_tvision")
+    anchors = build_anchors(g, "retina_small")
+    N, K, b = anchors.shape[0], 91, 2
+    gts = []
+    for i in range(b):
+        side = detrand.uniform(50 + i, (4, 2), 16, 90)
+        tl = detrand.uniform(60 + i, (4, 2), 0, 1) * (np.array([160, 128], np.float32) - side)
+        gts.append((np.concatenate([tl, tl + side], 1).astype(np.float32), detrand.randint(70 + i, (4,), 1, K)))
+    logits = detrand.uniform(80, (b, N, K), -6, 2)
+    reg = detrand.uniform(81, (b, N, 4), -1, 1)
+    tfidf = detrand.uniform(82, (K,), 0.5, 2.0)
+    for tf in (None, tfidf):
+        cl, _rl, mis, (gc, _gr) = tv.retinanet_loss(logits, reg, anchors, gts, tfidf=tf)
+        m = Matcher(0.5, 0.4, True)
+        lt = T(logits).requires_grad_(True)
+        matched = [m.match_boxes(T(bx), T(anchors)) for bx, _ in gts]
+        for a, bm in zip(matched, mis):
+            assert np.array_equal(a.cpu().numpy(), bm)
+        targets = [{"labels": T(lb)} for _, lb in gts]
+        loss = retinanet_classification_loss(lt, targets, matched, tfidf=None if tf is None else T(tf))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), cl, rtol=1e-4)
+        np.testing.assert_allclose(lt.grad.cpu().numpy(), gc, rtol=2e-3, atol=1e-7)
