@@ -175,10 +175,15 @@ typedef struct {
 
 /* Forward implicit GEMM: y = conv(x, w) [+ bias]; w packed [cout_pad][k*k*cin] bf16 (K contiguous).
  *   out_f32 != 0: y is fp32 (head conv_out), else bf16.
- *   stats != NULL: per-channel sum and sum of squares of y accumulated into stats[0..cout) and
- *   stats[cout_pad..) (fp32, caller zeroes) for training BatchNorm. */
+ *   stats != NULL: per pixel-tile partial sums / sums of squares of y, stats[row][0][c], stats[row][1][c]
+ *   (fp32, row pitch 2*cout_pad, plain stores, deterministic) for training BatchNorm. */
 int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias,
                       void* y, int out_f32, float* stats, int32_t cout_pad, void* stream);
+/* number of rows of the `stats` partial buffer [rows][2][cout_pad] the forward writes (one per pixel tile) */
+int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad);
+/* Darknet stem (darknet.py:41, 3->32 3x3): NCHW fp32 image -> im2col rows [n*h*w][32] bf16
+ * (k=(kh*3+kw)*3+c, 27 valid) consumed by conv_fwd / conv_wgrad as a 1x1 convolution with cin=32. */
+int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int32_t w, void* stream);
 
 /* Data gradient: dx = conv_transpose(dy, w); wt packed for dgrad by mi355det_pack_weights.
  * residual != NULL adds a bf16 tensor (same shape as dx) in the epilogue (residual-block skip). */
@@ -203,10 +208,16 @@ int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* 
  *   bn_act_fwd: a = lrelu(z*scale+shift) [+ residual]   (bf16 in/out, vectorised)
  *   bn_act_bwd_reduce: per-channel sums of dy and dy*xhat where dy = (g1[+g2]) * lrelu'(.)
  *   bn_act_bwd_apply: dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat))  (bf16)            */
-int mi355det_bn_finalize(const float* stats, int32_t c, int32_t c_pad, int64_t count, const float* gamma,
-                         const float* beta, float eps, float momentum, float* running_mean,
-                         float* running_var, float* scale_shift /* [4*c]: scale, shift, mean, invstd */,
-                         void* stream);
+int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count,
+                         const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var,
+                         float* scale_shift /* [4*c]: scale, shift, mean, invstd */, void* stream);
+/* eval mode (model.eval(), test_one_epoch.py:10): scale/shift from the running statistics */
+int mi355det_bn_eval_scale_shift(int32_t c, const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, float* scale_shift, void* stream);
+/* out = a + b on bf16 NHWC channel slices (gradient join of the concat/upsample branches) */
+int mi355det_add_bf16(const void* a, int32_t a_ld, const void* b, int32_t b_ld, int32_t c, int64_t pixels,
+                      void* out, int32_t out_ld, void* stream);
 int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,
                         float slope, const void* residual, int32_t res_ld, void* out, int32_t out_ld,
                         void* stream);
@@ -225,8 +236,6 @@ int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, i
                             int32_t out_ld, void* stream);
 
 /* layout / dtype converters at the module boundary */
-int mi355det_nchw_f32_to_nhwc_bf16(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, void* out,
-                                   int32_t out_ld, void* stream);
 int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h,
                               int32_t w, float* out, void* stream);
 int mi355det_nchw_f32_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, void* out,

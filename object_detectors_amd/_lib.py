@@ -65,7 +65,11 @@ PROTOTYPES = {
     "mi355det_dgrad_pack_elems": (sz, [P(ConvShape)]),
     "mi355det_pack_weights": (C.c_int, [P(ConvShape), vp, vp, i32, vp, vp]),
     "mi355det_unpack_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp]),
-    "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
+    "mi355det_conv_stats_rows": (C.c_int, [P(ConvShape), i32]),
+    "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
+    "mi355det_bn_eval_scale_shift": (C.c_int, [i32, vp, vp, vp, vp, f32, vp, vp]),
+    "mi355det_add_bf16": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, i32, vp]),
     "mi355det_bn_act_fwd": (C.c_int, [vp, i32, vp, i32, i64, f32, vp, i32, vp, i32, vp]),
     "mi355det_bn_act_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, f32, vp, vp]),
     "mi355det_bn_act_bwd_apply": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i64, f32, vp, i32, vp, vp, vp]),

@@ -1,0 +1,536 @@
+// Implicit-GEMM convolution on MFMA (gfx950): forward and data-gradient.
+//
+//   D[co][pix] = sum_k W[co][k] * A[pix][k],   k = tap*Cin + c   (NHWC bf16, fp32 accumulate)
+//
+// * activations stay NHWC bf16 in HBM; the im2col tile A[pix][k-chunk] is gathered straight into
+//   LDS with global_load_lds (16 B per lane, per-lane source address = padding/stride handled by
+//   pointing out-of-image rows at a zero page), weights W[co][k] are K-contiguous.
+// * LDS rows are XOR-swizzled on the SOURCE side (LDS-DMA writes lane-linear) so the ds_read_b128
+//   fragment reads are bank-conflict free for 128-B (BK=64) and 64-B (BK=32) rows.
+// * v_mfma_f32_16x16x32_bf16 with weights as the MFMA A operand (rows = output channels): each lane
+//   ends up with 4 consecutive channels of one pixel -> 8-byte NHWC stores, and per-channel BatchNorm
+//   statistics reduce over 16 lanes.
+// * one generic "lattice + tap table" addressing covers 3x3/1x1, stride 1/2 forward and the
+//   transposed (dgrad) problems incl. the four parity classes of a stride-2 dgrad.
+// * 2-stage LDS pipeline: LDS-DMA of k-step t+1 is in flight while k-step t runs on the MFMAs;
+//   2 workgroups per CU overlap each other's waits.
+#include "common.h"
+
+using namespace mi355;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+
+#define MAX_TAPS 9
+
+struct IgemmParams {
+  const bf16_t* x;       // input activations (fwd: x, dgrad: dy)
+  const bf16_t* w;       // packed weights [CoutPad][T*Cin]
+  void* y;               // output (bf16 or fp32)
+  const float* bias;     // EPI_F32
+  float* stats;          // EPI_STATS: [gridM][2][CoutPad] partial sum / sumsq
+  const bf16_t* res;     // EPI_RES: residual to add
+  const bf16_t* zero;    // >= 256 B of zeros
+  int M, MH, MW;         // lattice: M = N*MH*MW
+  int Hin, Win, ldin, Cin, sin;
+  int Hout, Wout, ldout, so, oy0, ox0;
+  int Cout, CoutPad, ldres;
+  int T;
+  int dy[MAX_TAPS], dx[MAX_TAPS];
+};
+
+enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3 };
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  return BK == 64 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3);
+}
+
+// WM x WN waves; each wave computes 64 pixels x (TN*16) channels.
+template <int WM, int WN, int TN, int BK, int EPI>
+__global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * 64, BN = WN * TN * 16;
+  constexpr int ROWB = BK * 2;               // bytes per LDS row
+  constexpr int R = 1024 / ROWB;             // rows per LDS-DMA wave instruction
+  constexpr int CPR = BK / 8;                // 16-B chunks per row
+  constexpr int A_INSTR = BM / R, B_INSTR = BN / R;
+  constexpr int A_PER = (A_INSTR + NW - 1) / NW, B_PER = (B_INSTR + NW - 1) / NW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages; reused by the epilogue
+  __shared__ int s_toff[MAX_TAPS];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid % WM, wn = wid / WM;
+
+  // XCD-aware block remap (bijective form): blocks that share an A tile (same m-tile, all n-tiles) and
+  // neighbouring m-tiles run on one XCD so the re-reads hit that XCD's L2.
+  const int ntn = p.CoutPad / BN;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = bid / ntn, nt = bid - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  if (tid < p.T) s_toff[tid] = (p.dy[tid] * p.Win + p.dx[tid]) * p.ldin;
+
+  // ---- per-lane source descriptors for the rows this lane stages
+  const int lrow = lane / CPR, cpos = lane % CPR;
+  long long a_base[A_PER];
+  unsigned a_valid[A_PER];
+  int a_chunk[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int instr = wid * A_PER + i;
+    const int row = instr * R + lrow;
+    const int m = m0 + row;
+    a_chunk[i] = (cpos ^ swz<BK>(row)) * 8;
+    unsigned vm = 0;
+    long long base = 0;
+    if (instr < A_INSTR && m < p.M) {
+      const int xx = m % p.MW, t1 = m / p.MW, yy = t1 % p.MH, n = t1 / p.MH;
+      const int iy0 = yy * p.sin, ix0 = xx * p.sin;
+      base = ((long long)(n * p.Hin + iy0) * p.Win + ix0) * p.ldin;
+      for (int t = 0; t < p.T; ++t) {
+        const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
+        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) vm |= 1u << t;
+      }
+    }
+    a_base[i] = base;
+    a_valid[i] = vm;
+  }
+  const int Ktot = p.T * p.Cin;
+  const bf16_t* b_ptr[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int instr = wid * B_PER + i;
+    const int row = instr * R + lrow;
+    b_ptr[i] = p.w + (long long)(n0 + (instr < B_INSTR ? row : 0)) * Ktot + (cpos ^ swz<BK>(row)) * 8;
+  }
+  __syncthreads();
+
+  const int ksteps = Ktot / BK;
+  const int cin_steps = p.Cin / BK;
+
+  auto stage = [&](int s, int buf) {
+    const int t = s / cin_steps, c0 = (s - t * cin_steps) * BK;
+    const int toff = s_toff[t] + c0;
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int instr = wid * A_PER + i;
+      if (A_INSTR % NW == 0 || instr < A_INSTR) {
+        const bf16_t* src = ((a_valid[i] >> t) & 1u) ? p.x + a_base[i] + toff + a_chunk[i] : p.zero + cpos * 8;
+        glds16(src, sa + instr * 1024);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int instr = wid * B_PER + i;
+      if (B_INSTR % NW == 0 || instr < B_INSTR) glds16(b_ptr[i] + (long long)s * BK, sb + instr * 1024);
+    }
+  };
+
+  f32x4_t acc[TN][4];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int s = 0; s < ksteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < ksteps) stage(s + 1, buf ^ 1);
+    const char* sa = smem + buf * STAGE;
+    const char* sb = sa + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t wf[TN], af[4];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * (TN * 16) + i * 16 + fr;
+        wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wm * 64 + j * 16 + fr;
+        af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels co = n0 + wn*TN*16 + i*16 + fq*4 + r (r=0..3) of pixel
+  //      m = m0 + wm*64 + j*16 + fr
+  if (EPI == EPI_STATS) {
+    float* sred = (float*)smem;   // [WM][BN][2]
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[i][j][r];
+          s1 += v;
+          s2 += v * v;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s1 += __shfl_xor(s1, o, 64);
+          s2 += __shfl_xor(s2, o, 64);
+        }
+        if (fr == 0) {
+          const int c = wn * (TN * 16) + i * 16 + fq * 4 + r;
+          sred[(wm * BN + c) * 2 + 0] = s1;
+          sred[(wm * BN + c) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s1 += sred[(w * BN + c) * 2 + 0];
+        s2 += sred[(w * BN + c) * 2 + 1];
+      }
+      float* dst = p.stats + (long long)mt * 2 * p.CoutPad;
+      dst[n0 + c] = s1;
+      dst[p.CoutPad + n0 + c] = s2;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wm * 64 + j * 16 + fr;
+    if (m >= p.M) continue;
+    const int xx = m % p.MW, t1 = m / p.MW, yy = t1 % p.MH, n = t1 / p.MH;
+    const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+    if (oy >= p.Hout || ox >= p.Wout) continue;
+    const long long pix = (long long)(n * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int co = n0 + wn * (TN * 16) + i * 16 + fq * 4;
+      if (co >= p.Cout) continue;
+      f32x4_t v = acc[i][j];
+      if (EPI == EPI_F32) {
+        float* o = (float*)p.y + pix * p.ldout + co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.Cout) o[r] = v[r] + (p.bias ? p.bias[co + r] : 0.f);
+      } else {
+        if (EPI == EPI_RES) {
+          const uint2 rr = *(const uint2*)(p.res + pix * p.ldres + co);
+          v[0] += bf2f((bf16_t)(rr.x & 0xFFFF));
+          v[1] += bf2f((bf16_t)(rr.x >> 16));
+          v[2] += bf2f((bf16_t)(rr.y & 0xFFFF));
+          v[3] += bf2f((bf16_t)(rr.y >> 16));
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)((bf16_t*)p.y + pix * p.ldout + co) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: fp32 master [cout][cin][k][k] -> bf16 [cout_pad][tap][cin]  (K contiguous)
+__global__ void pack_fwd_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cout_pad, int cin, int cin_pad, int kk) {
+  const long long total = (long long)cout_pad * kk * cin_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cin_pad);
+    const int t = (int)((i / cin_pad) % kk);
+    const int co = (int)(i / ((long long)cin_pad * kk));
+    float v = 0.f;
+    if (co < cout && c < cin) v = w[((long long)co * cin + c) * kk + t];
+    out[i] = f2bf(v);
+  }
+}
+
+// dgrad pack: rows = input channel ci, K = (tap list) x cout.  taps[j] gives the forward tap index
+// (kh*k+kw) whose weights feed dgrad tap j.  out [cin_pad][ntaps][cout]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cin, int cin_pad, int kk, int ntaps,
+                                  const int* __restrict__ taps_dev, int t0, int t1, int t2, int t3, int t4, int t5, int t6, int t7, int t8) {
+  const int taps[9] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
+  (void)taps_dev;
+  const long long total = (long long)cin_pad * ntaps * cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cout);
+    const int j = (int)((i / cout) % ntaps);
+    const int ci = (int)(i / ((long long)cout * ntaps));
+    int tap = taps[0];
+#pragma unroll
+    for (int q = 1; q < 9; ++q)
+      if (j == q) tap = taps[q];
+    float v = 0.f;
+    if (ci < cin) v = w[((long long)co * cin + ci) * kk + tap];
+    out[i] = f2bf(v);
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dw, float* __restrict__ grad, int cout, int cin, int cin_pad, int kk) {
+  const long long total = (long long)cout * cin * kk;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % kk);
+    const int c = (int)((i / kk) % cin);
+    const int co = (int)(i / ((long long)kk * cin));
+    grad[i] = dw[((long long)co * kk + t) * cin_pad + c];
+  }
+}
+
+// stem im2col: NCHW fp32 image [n,3,h,w] -> [n*h*w][32] bf16 rows, k = (kh*3+kw)*3 + c for k<27, zeros after
+// (darknet.py:41 conv1 3->32 3x3 s1 p1; K=27 is below the MFMA K granularity, so the stem runs as a
+//  1x1 conv over this 32-wide matrix, which forward and wgrad share).
+__global__ void stem_im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int n, int h, int w) {
+  const long long total = (long long)n * h * w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((long long)w * h));
+    unsigned short v[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) v[k] = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iy = y + kh - 1, ix = x + kw - 1;
+        const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float f = ok ? img[((long long)(b * 3 + c) * h + iy) * w + ix] : 0.f;
+          v[(kh * 3 + kw) * 3 + c] = f2bf(f);
+        }
+      }
+    uint4* o = (uint4*)(out + i * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint4 u;
+      u.x = v[q * 8 + 0] | ((unsigned)v[q * 8 + 1] << 16);
+      u.y = v[q * 8 + 2] | ((unsigned)v[q * 8 + 3] << 16);
+      u.z = v[q * 8 + 4] | ((unsigned)v[q * 8 + 5] << 16);
+      u.w = v[q * 8 + 6] | ((unsigned)v[q * 8 + 7] << 16);
+      o[q] = u;
+    }
+  }
+}
+
+bf16_t* g_zero_page = nullptr;
+
+int ensure_zero_page() {
+  if (g_zero_page) return 0;
+  void* p = nullptr;
+  if (hipMalloc(&p, 4096) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMalloc(zero page) failed", "conv");
+  if (hipMemset(p, 0, 4096) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMemset(zero page) failed", "conv");
+  g_zero_page = (bf16_t*)p;
+  return 0;
+}
+
+template <int WM, int WN, int TN, int BK, int EPI>
+int launch_cfg(const IgemmParams& p, hipStream_t st) {
+  constexpr int BM = WM * 64, BN = WN * TN * 16;
+  constexpr int lds = 2 * (BM + BN) * BK * 2;
+  const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
+  auto k = igemm_kernel<WM, WN, TN, BK, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
+  return check_launch("igemm");
+}
+
+template <int EPI>
+int launch_igemm(const IgemmParams& p, hipStream_t st) {
+  if (p.Cin % 32 != 0) return fail(MI355DET_EINVAL, "%s: Cin must be a multiple of 32 (got %lld)", "conv", p.Cin);
+  const bool k64 = p.Cin % 64 == 0;
+  if (p.CoutPad % 128 == 0) return k64 ? launch_cfg<2, 2, 4, 64, EPI>(p, st) : launch_cfg<2, 2, 4, 32, EPI>(p, st);
+  if (p.CoutPad % 64 == 0) return k64 ? launch_cfg<4, 1, 4, 64, EPI>(p, st) : launch_cfg<4, 1, 4, 32, EPI>(p, st);
+  if (p.CoutPad % 32 == 0) return k64 ? launch_cfg<4, 1, 2, 64, EPI>(p, st) : launch_cfg<4, 1, 2, 32, EPI>(p, st);
+  return fail(MI355DET_EINVAL, "%s: padded Cout must be a multiple of 32 (got %lld)", "conv", p.CoutPad);
+}
+
+int check_shape(const mi355det_conv_shape* s, const char* what) {
+  if (!s) return fail(MI355DET_EINVAL, "%s: null shape", what);
+  if (!((s->ksize == 1 && s->pad == 0) || (s->ksize == 3 && s->pad == 1)) || (s->stride != 1 && s->stride != 2))
+    return fail(MI355DET_EINVAL, "%s: only 1x1/p0 and 3x3/p1 with stride 1 or 2 are supported", what);
+  if (s->ho != (s->h + 2 * s->pad - s->ksize) / s->stride + 1 || s->wo != (s->w + 2 * s->pad - s->ksize) / s->stride + 1)
+    return fail(MI355DET_EINVAL, "%s: output size does not match the convolution geometry", what);
+  if (s->in_ld < s->cin || s->out_ld < s->cout) return fail(MI355DET_EINVAL, "%s: pixel pitch smaller than channel count", what);
+  return 0;
+}
+
+int grid_m_rows(const mi355det_conv_shape* s, int cout_pad) {
+  const int bm = cout_pad % 128 == 0 ? 128 : 256;
+  const long long M = (long long)s->n * s->ho * s->wo;
+  return (int)((M + bm - 1) / bm);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad) {
+  if (!s) return 0;
+  return grid_m_rows(s, cout_pad);
+}
+
+int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias, void* y, int out_f32, float* stats,
+                      int32_t cout_pad, void* stream) {
+  if (int e = check_shape(s, "conv_fwd")) return e;
+  if (int e = ensure_zero_page()) return e;
+  if (cout_pad < s->cout) return fail(MI355DET_EINVAL, "%s: cout_pad < cout", "conv_fwd");
+  IgemmParams p{};
+  p.x = (const bf16_t*)x;
+  p.w = (const bf16_t*)w;
+  p.y = y;
+  p.bias = bias;
+  p.stats = stats;
+  p.zero = g_zero_page;
+  p.MH = s->ho;
+  p.MW = s->wo;
+  p.M = s->n * s->ho * s->wo;
+  p.Hin = s->h; p.Win = s->w; p.ldin = s->in_ld; p.Cin = s->cin; p.sin = s->stride;
+  p.Hout = s->ho; p.Wout = s->wo; p.ldout = s->out_ld; p.so = 1; p.oy0 = 0; p.ox0 = 0;
+  p.Cout = s->cout; p.CoutPad = cout_pad;
+  p.T = s->ksize * s->ksize;
+  for (int kh = 0; kh < s->ksize; ++kh)
+    for (int kw = 0; kw < s->ksize; ++kw) {
+      p.dy[kh * s->ksize + kw] = kh - s->pad;
+      p.dx[kh * s->ksize + kw] = kw - s->pad;
+    }
+  if (out_f32) return launch_igemm<EPI_F32>(p, S(stream));
+  if (stats) return launch_igemm<EPI_STATS>(p, S(stream));
+  return launch_igemm<EPI_PLAIN>(p, S(stream));
+}
+
+// dgrad tap lists.  stride 1: dx[y,x] = sum_{kh,kw} dy[y+p-kh, x+p-kw] * w[kh,kw]  -> tap j=(kh,kw): d = p-kh.
+// stride 2 (k=3,p=1): output pixel parity (py,px); valid kh have (y+1-kh) even: py=0 -> kh=1 (dy 0);
+// py=1 -> kh=0 (dy +1), kh=2 (dy 0)  [in units of the dy lattice: (y+1-kh)/2 with y=2*yy+py].
+static int dgrad_taps(const mi355det_conv_shape* s, int py, int px, int* fwd_tap, int* dy, int* dx) {
+  int n = 0;
+  const int k = s->ksize, pd = s->pad;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) {
+      if (s->stride == 1) {
+        fwd_tap[n] = kh * k + kw;
+        dy[n] = pd - kh;
+        dx[n] = pd - kw;
+        ++n;
+      } else {
+        const int ny = py + pd - kh, nx = px + pd - kw;
+        if ((ny & 1) || (nx & 1)) continue;
+        fwd_tap[n] = kh * k + kw;
+        dy[n] = ny / 2;   // exact (even), may be negative zero-side only for ny in {-0}: ny in {-1..2}
+        dx[n] = nx / 2;
+        ++n;
+      }
+    }
+  return n;
+}
+
+size_t mi355det_dgrad_pack_elems(const mi355det_conv_shape* s) {
+  if (!s) return 0;
+  const size_t cin_pad = (size_t)((s->cin + 31) / 32 * 32);
+  return cin_pad * (size_t)(s->ksize * s->ksize) * (size_t)s->cout + 64;
+}
+
+int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, void* w_fwd, int32_t cout_pad, void* w_dgrad, void* stream) {
+  if (int e = check_shape(s, "pack_weights")) return e;
+  const int kk = s->ksize * s->ksize;
+  if (w_fwd) {
+    const long long total = (long long)cout_pad * kk * s->cin;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), w, (bf16_t*)w_fwd, s->cout,
+                       cout_pad, s->cin, s->cin, kk);
+  }
+  if (w_dgrad) {
+    const int cin_pad = (s->cin + 31) / 32 * 32;
+    bf16_t* out = (bf16_t*)w_dgrad;
+    const int classes = s->stride == 1 ? 1 : 4;
+    for (int c = 0; c < classes; ++c) {
+      int ft[9] = {0}, dy[9], dx[9];
+      const int nt = dgrad_taps(s, c >> 1, c & 1, ft, dy, dx);
+      const long long total = (long long)cin_pad * nt * s->cout;
+      hipLaunchKernelGGL(pack_dgrad_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), w, out, s->cout, s->cin,
+                         cin_pad, kk, nt, (const int*)nullptr, ft[0], ft[1], ft[2], ft[3], ft[4], ft[5], ft[6], ft[7], ft[8]);
+      out += total;
+    }
+  }
+  return check_launch("pack_weights");
+}
+
+int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* grad, void* stream) {
+  if (int e = check_shape(s, "unpack_wgrad")) return e;
+  const int kk = s->ksize * s->ksize;
+  const long long total = (long long)s->cout * s->cin * kk;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), dw, grad, s->cout, s->cin,
+                     s->cin, kk);
+  return check_launch("unpack_wgrad");
+}
+
+int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                        void* stream) {
+  if (int e = check_shape(s, "conv_dgrad")) return e;
+  if (int e = ensure_zero_page()) return e;
+  if (s->cout % 32 != 0) return fail(MI355DET_EINVAL, "%s: Cout (the dgrad reduction dim) must be a multiple of 32 (got %lld)", "conv_dgrad", s->cout);
+  const int cin_pad = (s->cin + 31) / 32 * 32;
+  const bf16_t* wp = (const bf16_t*)wt;
+  const int classes = s->stride == 1 ? 1 : 4;
+  for (int c = 0; c < classes; ++c) {
+    IgemmParams p{};
+    int ft[9];
+    p.T = dgrad_taps(s, c >> 1, c & 1, ft, p.dy, p.dx);
+    p.x = (const bf16_t*)dy;
+    p.w = wp;
+    p.y = dx;
+    p.res = (const bf16_t*)residual;
+    p.ldres = residual_ld;
+    p.zero = g_zero_page;
+    if (s->stride == 1) {
+      p.MH = s->h; p.MW = s->w; p.so = 1; p.oy0 = 0; p.ox0 = 0;
+    } else {
+      p.MH = (s->h + 1) / 2; p.MW = (s->w + 1) / 2; p.so = 2; p.oy0 = c >> 1; p.ox0 = c & 1;
+    }
+    p.M = s->n * p.MH * p.MW;
+    p.Hin = s->ho; p.Win = s->wo; p.ldin = s->out_ld; p.Cin = s->cout; p.sin = 1;
+    p.Hout = s->h; p.Wout = s->w; p.ldout = s->in_ld;
+    p.Cout = s->cin; p.CoutPad = cin_pad;
+    int e = residual ? launch_igemm<EPI_RES>(p, S(stream)) : launch_igemm<EPI_PLAIN>(p, S(stream));
+    if (e) return e;
+    wp += (long long)cin_pad * p.T * s->cout;
+  }
+  return 0;
+}
+
+int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int32_t w, void* stream) {
+  if (n <= 0 || h <= 0 || w <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "stem_im2col");
+  const long long total = (long long)n * h * w;
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3((int)min((long long)8192, (total + 255) / 256)), dim3(256), 0, S(stream), img, (bf16_t*)out, n, h, w);
+  return check_launch("stem_im2col");
+}
+
+}  // extern "C"

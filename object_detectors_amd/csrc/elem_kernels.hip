@@ -1,0 +1,373 @@
+// HBM-bound elementwise / reduction kernels around the convolutions: training BatchNorm2d +
+// LeakyReLU(0.1) forward/backward (darknet.py:15-16,19-20,33), nearest x2 upsample into a
+// channel slice (yolohead.py:32,80-81), layout converters.  NHWC bf16, 16-byte vector accesses.
+#include "common.h"
+
+using namespace mi355;
+
+namespace {
+
+struct bf8 {
+  float v[8];
+};
+__device__ __forceinline__ bf8 ld8(const bf16_t* p) {
+  const uint4 u = *(const uint4*)p;
+  bf8 r;
+  r.v[0] = bf2f((bf16_t)(u.x & 0xFFFF)); r.v[1] = bf2f((bf16_t)(u.x >> 16));
+  r.v[2] = bf2f((bf16_t)(u.y & 0xFFFF)); r.v[3] = bf2f((bf16_t)(u.y >> 16));
+  r.v[4] = bf2f((bf16_t)(u.z & 0xFFFF)); r.v[5] = bf2f((bf16_t)(u.z >> 16));
+  r.v[6] = bf2f((bf16_t)(u.w & 0xFFFF)); r.v[7] = bf2f((bf16_t)(u.w >> 16));
+  return r;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const bf8& r) {
+  uint4 u;
+  u.x = (unsigned)f2bf(r.v[0]) | ((unsigned)f2bf(r.v[1]) << 16);
+  u.y = (unsigned)f2bf(r.v[2]) | ((unsigned)f2bf(r.v[3]) << 16);
+  u.z = (unsigned)f2bf(r.v[4]) | ((unsigned)f2bf(r.v[5]) << 16);
+  u.w = (unsigned)f2bf(r.v[6]) | ((unsigned)f2bf(r.v[7]) << 16);
+  *(uint4*)p = u;
+}
+
+// stats partials [rows][2][c_pad] -> scale/shift/mean/invstd (+ running stats, nn.BatchNorm2d momentum rule)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          float* __restrict__ ss) {
+  __shared__ double sh[8][32][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  double s1 = 0, s2 = 0;
+  if (ch < c)
+    for (int r = rl; r < rows; r += 8) {
+      s1 += (double)partial[(size_t)r * 2 * c_pad + ch];
+      s2 += (double)partial[(size_t)r * 2 * c_pad + c_pad + ch];
+    }
+  sh[rl][cl][0] = s1;
+  sh[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    for (int r = 1; r < 8; ++r) {
+      s1 += sh[r][cl][0];
+      s2 += sh[r][cl][1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * invstd;
+    ss[ch] = sc;
+    ss[c + ch] = beta[ch] - (float)mean * sc;
+    ss[2 * c + ch] = (float)mean;
+    ss[3 * c + ch] = invstd;
+    if (rmean) {
+      rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+    }
+  }
+}
+
+// eval-mode scale/shift from running stats
+__global__ void bn_eval_kernel(int c, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
+                               const float* __restrict__ rvar, float eps, float* __restrict__ ss) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float invstd = 1.0f / sqrtf(rvar[ch] + eps);
+  const float sc = gamma[ch] * invstd;
+  ss[ch] = sc;
+  ss[c + ch] = beta[ch] - rmean[ch] * sc;
+  ss[2 * c + ch] = rmean[ch];
+  ss[3 * c + ch] = invstd;
+}
+
+// a = lrelu(z*scale+shift) [+ residual]
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ z, int z_ld, const float* __restrict__ ss, int c,
+                                                         long long pixels, float slope, const bf16_t* __restrict__ res, int res_ld,
+                                                         bf16_t* __restrict__ out, int out_ld) {
+  const int groups = c >> 3;
+  const long long total = pixels * groups;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / groups;
+    const int c0 = (int)(i - m * groups) << 3;
+    bf8 v = ld8(z + m * z_ld + c0);
+    const float4 sa = *(const float4*)(ss + c0), sb = *(const float4*)(ss + c0 + 4);
+    const float4 ha = *(const float4*)(ss + c + c0), hb = *(const float4*)(ss + c + c0 + 4);
+    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float y = v.v[k] * sc[k] + sh[k];
+      v.v[k] = y > 0.f ? y : y * slope;
+    }
+    if (res) {
+      const bf8 r = ld8(res + m * res_ld + c0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] += r.v[k];
+    }
+    st8(out + m * out_ld + c0, v);
+  }
+}
+
+// per-channel sums of dy and dy*xhat, dy = (g1 [+ g2]) * lrelu'(y).  Block = (c/8) channel groups x
+// (256/(c/8)) pixel lanes; partial sums combined in LDS, then one atomic per channel per block.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ g1, int g1_ld, const bf16_t* __restrict__ g2, int g2_ld,
+                                                            const bf16_t* __restrict__ z, int z_ld, const float* __restrict__ ss, int c,
+                                                            long long pixels, float slope, float* __restrict__ sums, int pix_per_block) {
+  __shared__ float red[256][17];
+  const int groups = c >> 3;                 // power of two <= 256 (checked on the host)
+  const int gl = threadIdx.x % groups, pl = threadIdx.x / groups, npl = 256 / groups;
+  const int c0 = gl << 3;
+  float sc[8], sh[8], mu[8], is[8], a1[8], a2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = ss[c0 + k];
+    sh[k] = ss[c + c0 + k];
+    mu[k] = ss[2 * c + c0 + k];
+    is[k] = ss[3 * c + c0 + k];
+    a1[k] = 0.f;
+    a2[k] = 0.f;
+  }
+  const long long mA = (long long)blockIdx.x * pix_per_block, mB = min(pixels, mA + pix_per_block);
+  for (long long m = mA + pl; m < mB; m += npl) {
+    bf8 g = ld8(g1 + m * g1_ld + c0);
+    if (g2) {
+      const bf8 h = ld8(g2 + m * g2_ld + c0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g.v[k] += h.v[k];
+    }
+    const bf8 zz = ld8(z + m * z_ld + c0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float y = zz.v[k] * sc[k] + sh[k];
+      const float dy = y > 0.f ? g.v[k] : g.v[k] * slope;
+      a1[k] += dy;
+      a2[k] += dy * ((zz.v[k] - mu[k]) * is[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[threadIdx.x][k] = a1[k];
+    red[threadIdx.x][8 + k] = a2[k];
+  }
+  __syncthreads();
+  // thread t < 2*c handles (which = t / c, channel = t % c)
+  for (int t = threadIdx.x; t < 2 * c; t += 256) {
+    const int which = t / c, ch = t - which * c;
+    const int gi = ch >> 3, k = ch & 7;
+    float s = 0.f;
+    for (int p2 = 0; p2 < npl; ++p2) s += red[p2 * groups + gi][which * 8 + k];
+    atomicAdd(sums + which * c + ch, s);
+  }
+}
+
+// dz = scale * (dy - mean(dy) - xhat * mean(dy*xhat));  also dgamma/dbeta (block 0)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ g1, int g1_ld, const bf16_t* __restrict__ g2, int g2_ld,
+                                                           const bf16_t* __restrict__ z, int z_ld, const float* __restrict__ ss,
+                                                           const float* __restrict__ sums, int c, long long pixels, float slope,
+                                                           bf16_t* __restrict__ dz, int dz_ld, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  const int groups = c >> 3;
+  const long long total = pixels * groups;
+  const float inv = 1.0f / (float)pixels;
+  if (blockIdx.x == 0 && dgamma)
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      dbeta[ch] += sums[ch];
+      dgamma[ch] += sums[c + ch];
+    }
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / groups;
+    const int c0 = (int)(i - m * groups) << 3;
+    bf8 g = ld8(g1 + m * g1_ld + c0);
+    if (g2) {
+      const bf8 h = ld8(g2 + m * g2_ld + c0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g.v[k] += h.v[k];
+    }
+    const bf8 zz = ld8(z + m * z_ld + c0);
+    bf8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ch = c0 + k;
+      const float sc = ss[ch], sh = ss[c + ch], mu = ss[2 * c + ch], is = ss[3 * c + ch];
+      const float y = zz.v[k] * sc + sh;
+      const float dy = y > 0.f ? g.v[k] : g.v[k] * slope;
+      const float xh = (zz.v[k] - mu) * is;
+      o.v[k] = sc * (dy - sums[ch] * inv - xh * sums[c + ch] * inv);
+    }
+    st8(dz + m * dz_ld + c0, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const bf16_t* __restrict__ x, int x_ld, int n, int h, int w, int c,
+                                                             bf16_t* __restrict__ out, int out_ld) {
+  const int groups = c >> 3;
+  const long long total = (long long)n * (2 * h) * (2 * w) * groups;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i % groups);
+    const long long p = i / groups;
+    const int ox = (int)(p % (2 * w)), oy = (int)((p / (2 * w)) % (2 * h)), b = (int)(p / ((long long)4 * w * h));
+    const uint4 v = *(const uint4*)(x + ((long long)(b * h + (oy >> 1)) * w + (ox >> 1)) * x_ld + g * 8);
+    *(uint4*)(out + p * out_ld + g * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const bf16_t* __restrict__ gq, int g_ld, int n, int h, int w, int c,
+                                                             bf16_t* __restrict__ out, int out_ld) {
+  const int groups = c >> 3;
+  const long long total = (long long)n * h * w * groups;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int g = (int)(i % groups);
+    const long long p = i / groups;
+    const int x = (int)(p % w), y = (int)((p / w) % h), b = (int)(p / ((long long)w * h));
+    bf8 a;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const bf8 v = ld8(gq + ((long long)(b * 2 * h + 2 * y + dy) * (2 * w) + 2 * x + dx) * g_ld + g * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a.v[k] += v.v[k];
+      }
+    st8(out + p * out_ld + g * 8, a);
+  }
+}
+
+// out = a + b (bf16, channel slices) — gradient joins of the concat branches
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, int a_ld, const bf16_t* __restrict__ b, int b_ld, int c,
+                                                  long long pixels, bf16_t* __restrict__ out, int out_ld) {
+  const int groups = c >> 3;
+  const long long total = pixels * groups;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / groups;
+    const int c0 = (int)(i - m * groups) << 3;
+    bf8 v = ld8(a + m * a_ld + c0);
+    const bf8 w = ld8(b + m * b_ld + c0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v.v[k] += w.v[k];
+    st8(out + m * out_ld + c0, v);
+  }
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int n, int c, int hw, void* __restrict__ out, int out_ld) {
+  const long long total = (long long)n * hw;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long b = i / hw, p = i - b * hw;
+    for (int ch = 0; ch < c; ++ch) {
+      const float v = x[(b * c + ch) * hw + p];
+      if (OUT_BF16) ((bf16_t*)out)[i * out_ld + ch] = f2bf(v);
+      else ((float*)out)[i * out_ld + ch] = v;
+    }
+  }
+}
+
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ x, int x_ld, int n, int c, int hw, float* __restrict__ out) {
+  const long long total = (long long)n * c * hw;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long p = i % hw;
+    const int ch = (int)((i / hw) % c);
+    const long long b = i / ((long long)hw * c);
+    const long long src = (b * hw + p) * x_ld + ch;
+    out[i] = IN_BF16 ? bf2f(((const bf16_t*)x)[src]) : ((const float*)x)[src];
+  }
+}
+
+inline int grid_for(long long total) { return (int)min((long long)256 * 16, (total + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
+  if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale_shift);
+  return check_launch("bn_finalize");
+}
+
+int mi355det_bn_eval_scale_shift(int32_t c, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                 float* scale_shift, void* stream) {
+  if (c <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_eval");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((c + 255) / 256), dim3(256), 0, S(stream), c, gamma, beta, running_mean, running_var, eps, scale_shift);
+  return check_launch("bn_eval");
+}
+
+int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels, float slope, const void* residual,
+                        int32_t res_ld, void* out, int32_t out_ld, void* stream) {
+  if (c <= 0 || c % 8 != 0 || pixels <= 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "bn_act_fwd");
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)z, z_ld, scale_shift, c,
+                     (long long)pixels, slope, (const bf16_t*)residual, res_ld, (bf16_t*)out, out_ld);
+  return check_launch("bn_act_fwd");
+}
+
+int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift,
+                               int32_t c, int64_t pixels, float slope, float* sums, void* stream) {
+  const int groups = c / 8;
+  if (c <= 0 || c % 8 != 0 || groups > 256 || (groups & (groups - 1)) != 0)
+    return fail(MI355DET_EINVAL, "%s: channels/8 must be a power of two <= 256 (got c=%lld)", "bn_act_bwd_reduce", c);
+  const int npl = 256 / groups;
+  long long ppb = (long long)npl * 64;   // 64 pixels per pixel-lane
+  long long blocks = (pixels + ppb - 1) / ppb;
+  if (blocks > 8192) {
+    ppb = (pixels + 8191) / 8192;
+    blocks = (pixels + ppb - 1) / ppb;
+  }
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2, g2_ld,
+                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)ppb);
+  return check_launch("bn_act_bwd_reduce");
+}
+
+int mi355det_bn_act_bwd_apply(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift,
+                              const float* sums, const float* gamma, int32_t c, int64_t pixels, float slope, void* dz, int32_t dz_ld, float* dgamma,
+                              float* dbeta, void* stream) {
+  (void)gamma;
+  if (c <= 0 || c % 8 != 0 || pixels <= 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "bn_act_bwd_apply");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2,
+                     g2_ld, (const bf16_t*)z, z_ld, scale_shift, sums, c, (long long)pixels, slope, (bf16_t*)dz, dz_ld, dgamma, dbeta);
+  return check_launch("bn_act_bwd_apply");
+}
+
+int mi355det_upsample2x_fwd(const void* x, int32_t x_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out, int32_t out_ld, void* stream) {
+  if (c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "upsample2x_fwd");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)n * 4 * h * w * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)x, x_ld, n, h,
+                     w, c, (bf16_t*)out, out_ld);
+  return check_launch("upsample2x_fwd");
+}
+
+int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out, int32_t out_ld, void* stream) {
+  if (c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "upsample2x_bwd");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)g, g_ld, n, h, w,
+                     c, (bf16_t*)out, out_ld);
+  return check_launch("upsample2x_bwd");
+}
+
+int mi355det_add_bf16(const void* a, int32_t a_ld, const void* b, int32_t b_ld, int32_t c, int64_t pixels, void* out, int32_t out_ld, void* stream) {
+  if (c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "add_bf16");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(pixels * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)a, a_ld, (const bf16_t*)b, b_ld, c,
+                     (long long)pixels, (bf16_t*)out, out_ld);
+  return check_launch("add_bf16");
+}
+
+int mi355det_nchw_f32_to_nhwc(const float* x, int32_t n, int32_t c, int32_t h, int32_t w, void* out, int out_is_bf16, int32_t out_ld, void* stream) {
+  const long long total = (long long)n * h * w;
+  if (out_is_bf16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<true>, dim3(grid_for(total)), dim3(256), 0, S(stream), x, n, c, h * w, out, out_ld);
+  else
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<false>, dim3(grid_for(total)), dim3(256), 0, S(stream), x, n, c, h * w, out, out_ld);
+  return check_launch("nchw_f32_to_nhwc");
+}
+
+int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h, int32_t w, float* out, void* stream) {
+  const long long total = (long long)n * c * h * w;
+  if (x_is_bf16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<true>, dim3(grid_for(total)), dim3(256), 0, S(stream), x, x_ld, n, c, h * w, out);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<false>, dim3(grid_for(total)), dim3(256), 0, S(stream), x, x_ld, n, c, h * w, out);
+  return check_launch("nhwc_to_nchw_f32");
+}
+
+}  // extern "C"

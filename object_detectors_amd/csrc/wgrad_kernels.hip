@@ -1,0 +1,277 @@
+// Weight-gradient GEMM on MFMA (gfx950):
+//
+//   dW[co][n'] += sum_{m in pixel range} dY[m][co] * Xcol[m][n'],   n' = tap*Cin + ci
+//
+// Both operands are pixel-major in HBM (NHWC), i.e. the reduction index is the slow axis, so the MFMA
+// fragments are produced with the gfx950 transposed LDS read (ds_read_b64_tr_b16): tiles are staged
+// [pixel][channel] with LDS-DMA (coalesced 256-B rows) and read column-wise without any shuffle.
+// 32-byte blocks of every LDS row are XOR-swizzled (on the source side) so the 8 rows a half-wave
+// touches in one transposed read land on distinct banks.
+// Split over the pixel axis; partial tiles are accumulated with fp32 atomics (256 B per wave row
+// segment), sized so atomic bytes stay far below the MFMA time (wgrad).
+#include "common.h"
+
+using namespace mi355;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+struct FastDiv {
+  unsigned mul, shift, d;
+};
+
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
+  const unsigned t = __umulhi(f.mul, n);
+  return (t + n) >> f.shift;   // valid for n < 2^31
+}
+
+struct WgradParams {
+  const bf16_t* x;      // [n,h,w,cin] pitch ldx
+  const bf16_t* dy;     // [n,ho,wo,cout] pitch lddy
+  float* dw;            // [cout][T*cin] fp32, accumulated atomically
+  const bf16_t* zero;
+  int M, Ho, Wo, H, W, ldx, lddy, Cin, Cout, stride, pad, ks, T, NP;   // NP = T*Cin
+  int co_tiles, np_tiles, splits, chunk;                                // chunk = pixels per split (multiple of 64)
+  FastDiv dWo, dHo, dCin;
+};
+
+namespace {
+
+#define WG_BKP 64      // pixels per k-step
+#define WG_TILE 128    // co and n' tile
+#define WG_ROWB 256    // LDS row bytes (128 bf16)
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ int rowf(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+__device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+  return __builtin_bit_cast(bf16x4_t, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int STAGE = 2 * WG_BKP * WG_ROWB;   // dy tile + x tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid & 1, wc = wid >> 1;   // wave tile: co rows wr*64.., n' cols wc*64..
+
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tiles = p.co_tiles * p.np_tiles;
+  const int split = bid / tiles, tile = bid - split * tiles;
+  const int ct = tile % p.co_tiles, nt = tile / p.co_tiles;
+  const int co0 = ct * WG_TILE, np0 = nt * WG_TILE;
+  const int mA = split * p.chunk, mB = min(p.M, mA + p.chunk);
+  if (mA >= mB) return;
+
+  // staging roles: one LDS-DMA wave instruction = 4 rows x 256 B; 16 instr per tile per k-step, 4 per wave
+  const int lrow = lane >> 4, cpos = lane & 15;
+  // this lane's column block for the two possible swizzle phases (row bit 3 = 0 / 1)
+  int x_off[2], x_tapdy[2], x_tapdx[2], dy_off[2];
+  bool x_ok[2];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph) {
+    const int f = (lrow & 3) | (ph << 2);
+    const int gchunk = (((cpos >> 1) ^ f) << 1) | (cpos & 1);
+    dy_off[ph] = co0 + gchunk * 8;
+    const int np = np0 + gchunk * 8;
+    x_ok[ph] = np < p.NP;
+    const int t = x_ok[ph] ? (int)fdiv((unsigned)np, p.dCin) : 0;
+    const int ci = np - t * p.Cin;
+    const int kh = t / p.ks, kw = t - kh * p.ks;
+    x_tapdy[ph] = kh - p.pad;
+    x_tapdx[ph] = kw - p.pad;
+    x_off[ph] = ci;
+  }
+  const bool dy_ok0 = dy_off[0] < p.Cout, dy_ok1 = dy_off[1] < p.Cout;
+
+  auto stage = [&](int m_base, int buf) {
+    char* sd = smem + buf * STAGE;
+    char* sx = sd + WG_BKP * WG_ROWB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int instr = wid * 4 + i;
+      const int row = instr * 4 + lrow;
+      const int ph = (row >> 3) & 1;
+      const int m = m_base + row;
+      const bool mv = m < mB;
+      // dY tile: row m, channels co0 + swizzled chunk
+      const bf16_t* sdy = (mv && (ph ? dy_ok1 : dy_ok0)) ? p.dy + (long long)m * p.lddy + (ph ? dy_off[1] : dy_off[0]) : p.zero;
+      glds16(sdy, sd + instr * 1024);
+      // X tile: gather the input pixel of tap(t) for output pixel m
+      const unsigned um = (unsigned)(mv ? m : 0);
+      const unsigned q1 = fdiv(um, p.dWo);
+      const int wo = (int)(um - q1 * p.Wo);
+      const unsigned n = fdiv(q1, p.dHo);
+      const int ho = (int)(q1 - n * p.Ho);
+      const int iy = ho * p.stride + (ph ? x_tapdy[1] : x_tapdy[0]);
+      const int ix = wo * p.stride + (ph ? x_tapdx[1] : x_tapdx[0]);
+      const bool ok = mv && (ph ? x_ok[1] : x_ok[0]) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const bf16_t* sxp = ok ? p.x + ((long long)((int)n * p.H + iy) * p.W + ix) * p.ldx + (ph ? x_off[1] : x_off[0]) : p.zero;
+      glds16(sxp, sx + instr * 1024);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  const int ksteps = (mB - mA + WG_BKP - 1) / WG_BKP;
+  stage(mA, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // transposed-read lane roles: 16-lane group g covers pixels 8g..8g+7 of a 32-pixel sub-step;
+  // lane 4q+pp supplies row q, columns 4pp..4pp+3 of the 16-column block
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  for (int s = 0; s < ksteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < ksteps) stage(mA + (s + 1) * WG_BKP, buf ^ 1);
+    const char* sd = smem + buf * STAGE;
+    const char* sx = sd + WG_BKP * WG_ROWB;
+#pragma unroll
+    for (int ks = 0; ks < WG_BKP / 32; ++ks) {
+      bf16x8_t af[4], bfr[4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = ks * 32 + 8 * g + 4 * h + q;
+        const int f = rowf(row);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int blk = (wr * 64 + i * 16) >> 4;   // 32-byte block index of this 16-channel group
+          const bf16x4_t v = lds_tr(sd + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
+          af[i][4 * h + 0] = v[0];
+          af[i][4 * h + 1] = v[1];
+          af[i][4 * h + 2] = v[2];
+          af[i][4 * h + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int blk = (wc * 64 + j * 16) >> 4;
+          const bf16x4_t v = lds_tr(sx + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
+          bfr[j][4 * h + 0] = v[0];
+          bfr[j][4 * h + 1] = v[1];
+          bfr[j][4 * h + 2] = v[2];
+          bfr[j][4 * h + 3] = v[3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // D[row = co][col = n']: lane holds rows fq*4+r, column fr
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wr * 64 + i * 16 + fq * 4 + r;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int np = np0 + wc * 64 + j * 16 + fr;
+        if (np < p.NP) atomicAdd(p.dw + (long long)co * p.NP + np, acc[i][j][r]);
+      }
+    }
+  }
+}
+
+// per-channel sum over pixels of a bf16 NHWC tensor (bias gradient of the head convs)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ld, int c, long long pixels, float* __restrict__ out) {
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (ch < c)
+    for (long long m = blockIdx.y * 4 + pl; m < pixels; m += (long long)gridDim.y * 4) s += bf2f(x[m * ld + ch]);
+  red[pl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (pl == 0 && ch < c) atomicAdd(out + ch, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+bf16_t* g_zero_page_w = nullptr;
+int ensure_zero_page_w() {
+  if (g_zero_page_w) return 0;
+  void* p = nullptr;
+  if (hipMalloc(&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: zero page alloc failed", "wgrad");
+  g_zero_page_w = (bf16_t*)p;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw, float* dbias, void* stream) {
+  if (!s) return fail(MI355DET_EINVAL, "%s: null shape", "conv_wgrad");
+  if (int e = ensure_zero_page_w()) return e;
+  if (s->cin % 8 != 0) return fail(MI355DET_EINVAL, "%s: Cin must be a multiple of 8 (got %lld)", "conv_wgrad", s->cin);
+  if (s->out_ld % 8 != 0 || s->in_ld % 8 != 0) return fail(MI355DET_EINVAL, "%s: pixel pitches must be multiples of 8", "conv_wgrad");
+  WgradParams p{};
+  p.x = (const bf16_t*)x;
+  p.dy = (const bf16_t*)dy;
+  p.dw = dw;
+  p.zero = g_zero_page_w;
+  p.M = s->n * s->ho * s->wo;
+  p.Ho = s->ho; p.Wo = s->wo; p.H = s->h; p.W = s->w;
+  p.ldx = s->in_ld; p.lddy = s->out_ld;
+  p.Cin = s->cin; p.Cout = s->cout; p.stride = s->stride; p.pad = s->pad; p.ks = s->ksize;
+  p.T = s->ksize * s->ksize;
+  p.NP = p.T * p.Cin;
+  p.co_tiles = (p.Cout + WG_TILE - 1) / WG_TILE;
+  p.np_tiles = (p.NP + WG_TILE - 1) / WG_TILE;
+  const int tiles = p.co_tiles * p.np_tiles;
+  // split the pixel axis so that ~2 workgroups per CU are busy but every workgroup still reduces
+  // >= 4096 pixels (atomic bytes per MFMA flop stay small)
+  int splits = (512 + tiles - 1) / tiles;
+  const int max_splits = max(1, p.M / 4096);
+  splits = max(1, min(splits, max_splits));
+  int chunk = (p.M + splits - 1) / splits;
+  chunk = (chunk + WG_BKP - 1) / WG_BKP * WG_BKP;
+  splits = (p.M + chunk - 1) / chunk;
+  p.splits = splits;
+  p.chunk = chunk;
+  p.dWo = make_fastdiv((unsigned)p.Wo);
+  p.dHo = make_fastdiv((unsigned)p.Ho);
+  p.dCin = make_fastdiv((unsigned)p.Cin);
+  const int lds = 2 * 2 * WG_BKP * WG_ROWB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), lds, S(stream), p);
+  if (dbias) {
+    const int gy = (int)min((long long)256, ((long long)p.M + 255) / 256);
+    hipLaunchKernelGGL(colsum_kernel, dim3((p.Cout + 63) / 64, gy), dim3(256), 0, S(stream), (const bf16_t*)dy, s->out_ld, s->cout, (long long)p.M, dbias);
+  }
+  return check_launch("conv_wgrad");
+}
+
+}  // extern "C"

@@ -229,3 +229,50 @@ def retina_cls_loss_sum(logits, matched, gt_labels, alpha, gamma, scale=None, wa
                                          ptr(scale), rows, k, float(alpha), float(gamma), float(grad_scale), ptr(loss), ptr(grad),
                                          stream_ptr()), "retina_cls_loss")
     return loss[0], grad
+
+
+# ------------------------------------------------------------------------------------ conv path
+def conv_shape(n, h, w, cin, cout, ksize, stride, in_ld=None, out_ld=None):
+    pad = (ksize - 1) // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    return _lib.ConvShape(n, h, w, cin, ho, wo, cout, ksize, stride, pad, in_ld or cin, out_ld or cout)
+
+
+def pad_to(v, m):
+    return (v + m - 1) // m * m
+
+
+def cout_pad_of(cout):
+    return pad_to(cout, 128) if cout >= 128 or cout % 32 else cout
+
+
+def pack_weights(shape, w_master, want_dgrad=True):
+    """fp32 [cout,cin,k,k] -> (bf16 fwd pack [cout_pad, k*k*cin], bf16 dgrad pack)."""
+    dev = w_master.device
+    cp = cout_pad_of(shape.cout)
+    kk = shape.ksize * shape.ksize
+    wf = torch.empty(cp * kk * shape.cin, device=dev, dtype=torch.bfloat16)
+    wd = None
+    if want_dgrad:
+        wd = torch.empty(lib().mi355det_dgrad_pack_elems(C.byref(shape)), device=dev, dtype=torch.bfloat16)
+    check(lib().mi355det_pack_weights(C.byref(shape), ptr(w_master.contiguous()), ptr(wf), cp, ptr(wd), stream_ptr()), "pack_weights")
+    return wf, wd
+
+
+def conv_fwd(shape, x, w_fwd, y, bias=None, out_f32=False, stats=None):
+    cp = cout_pad_of(shape.cout)
+    check(lib().mi355det_conv_fwd(C.byref(shape), ptr(x), ptr(w_fwd), ptr(bias), ptr(y), int(out_f32), ptr(stats), cp, stream_ptr()),
+          "conv_fwd")
+
+
+def conv_stats_rows(shape):
+    return lib().mi355det_conv_stats_rows(C.byref(shape), cout_pad_of(shape.cout))
+
+
+def conv_dgrad(shape, dy, w_dgrad, dx, residual=None, residual_ld=0):
+    check(lib().mi355det_conv_dgrad(C.byref(shape), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(residual), int(residual_ld), stream_ptr()),
+          "conv_dgrad")
+
+
+def conv_wgrad(shape, x, dy, dw, dbias=None):
+    check(lib().mi355det_conv_wgrad(C.byref(shape), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream_ptr()), "conv_wgrad")

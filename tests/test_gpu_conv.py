@@ -1,0 +1,209 @@
+"""GPU parity of the MFMA convolution path (fwd / dgrad / wgrad, BN+LeakyReLU) against a plain
+PyTorch fp32 reference of the same op evaluated on the same bf16-rounded operands."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).bfloat16().float()
+
+
+def nhwc(x, ld=None):
+    """NCHW fp32 cpu -> NHWC bf16 gpu with pixel pitch ld."""
+    n, c, h, w = x.shape
+    ld = ld or c
+    out = torch.zeros(n, h, w, ld, dtype=torch.bfloat16, device=dev())
+    out[..., :c] = x.permute(0, 2, 3, 1).to(dev()).bfloat16()
+    return out
+
+
+CASES = [
+    # n, h, w, cin, cout, k, s
+    (2, 16, 16, 64, 128, 3, 1),
+    (2, 16, 16, 128, 256, 3, 1),
+    (1, 20, 20, 512, 1024, 3, 1),
+    (2, 16, 16, 32, 64, 3, 2),
+    (2, 16, 16, 32, 64, 3, 1),
+    (2, 16, 16, 64, 32, 1, 1),
+    (3, 13, 13, 128, 64, 1, 1),
+    (2, 26, 26, 64, 128, 3, 2),
+    (1, 13, 13, 256, 512, 3, 2),
+    (2, 9, 11, 128, 256, 3, 1),
+    (1, 8, 8, 768, 256, 1, 1),
+    (1, 8, 8, 384, 128, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from object_detectors_amd import ops
+    n, h, w, cin, cout, k, s = case
+    x = rnd((n, cin, h, w), 1)
+    wt = rnd((cout, cin, k, k), 2, (2.0 / (cin * k * k)) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=s, padding=(k - 1) // 2)
+    gy = rnd(tuple(y_ref.shape), 3)
+    y_ref.backward(gy)
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s)
+    wt_d = wt.to(dev())
+    wf, wd = ops.pack_weights(shape, wt_d)
+    xd = nhwc(x)
+    y = torch.empty(n, shape.ho, shape.wo, cout, dtype=torch.bfloat16, device=dev())
+    rows = ops.conv_stats_rows(shape)
+    cp = ops.cout_pad_of(cout)
+    stats = torch.zeros(rows, 2, cp, device=dev())
+    ops.conv_fwd(shape, xd, wf, y, stats=stats)
+    got = y.float().permute(0, 3, 1, 2).cpu()
+    tol = 2e-2 * y_ref.abs().max().item()
+    assert (got - y_ref.detach()).abs().max().item() < tol
+    # BN statistics from the fp32 accumulators
+    s1 = stats[:, 0, :cout].sum(0).cpu()
+    s2 = stats[:, 1, :cout].sum(0).cpu()
+    np.testing.assert_allclose(s1, y_ref.detach().sum((0, 2, 3)), rtol=1e-3, atol=1e-2 * y_ref.abs().max().item())
+    np.testing.assert_allclose(s2, (y_ref.detach() ** 2).sum((0, 2, 3)), rtol=1e-3)
+    # dgrad
+    gyd = nhwc(gy)
+    dx = torch.zeros(n, h, w, cin, dtype=torch.bfloat16, device=dev())
+    ops.conv_dgrad(shape, gyd, wd, dx)
+    gdx = dx.float().permute(0, 3, 1, 2).cpu()
+    assert (gdx - xr.grad).abs().max().item() < 2e-2 * xr.grad.abs().max().item()
+    # dgrad with residual add
+    res = rnd((n, cin, h, w), 4)
+    dx2 = torch.zeros_like(dx)
+    res_d = nhwc(res)
+    ops.conv_dgrad(shape, gyd, wd, dx2, residual=res_d, residual_ld=cin)
+    assert (dx2.float().permute(0, 3, 1, 2).cpu() - (xr.grad + res)).abs().max().item() < 2e-2 * (xr.grad + res).abs().max().item()
+    # wgrad: fp32 [cout][k*k][cin]
+    dw = torch.zeros(cout, k * k * cin, device=dev())
+    ops.conv_wgrad(shape, xd, gyd, dw)
+    gdw = dw.view(cout, k, k, cin).permute(0, 3, 1, 2).cpu()
+    assert (gdw - wr.grad).abs().max().item() < 1e-2 * wr.grad.abs().max().item()
+
+
+def test_head_conv_f32_bias_255():
+    from object_detectors_amd import ops
+    n, h, w, cin, cout = 2, 10, 10, 256, 255
+    x = rnd((n, cin, h, w), 5)
+    wt = rnd((cout, cin, 1, 1), 6, 0.05)
+    bias = rnd((cout,), 7, 0.1)
+    y_ref = F.conv2d(x, wt, bias)
+    shape = ops.conv_shape(n, h, w, cin, cout, 1, 1, out_ld=256)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()), want_dgrad=False)
+    y = torch.zeros(n, h, w, 256, dtype=torch.float32, device=dev())
+    bias_d, x_d = bias.to(dev()), nhwc(x)
+    ops.conv_fwd(shape, x_d, wf, y, bias=bias_d, out_f32=True)
+    got = y[..., :255].permute(0, 3, 1, 2).cpu()
+    assert (got - y_ref).abs().max().item() < 1e-2 * y_ref.abs().max().item()
+    assert (y[..., 255] == 0).all()
+    # backward of the head conv: dy bf16 with pitch 256 (pad column zero), dgrad K = 256 (padded)
+    gy = rnd((n, cout, h, w), 8)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    F.conv2d(xr, wr, br).backward(gy)
+    gyd = nhwc(gy, ld=256)
+    shape_b = ops.conv_shape(n, h, w, cin, 256, 1, 1, out_ld=256)   # treat the pad column as a zero channel
+    wt_pad = torch.zeros(256, cin, 1, 1)
+    wt_pad[:255] = wt
+    _, wd = ops.pack_weights(shape_b, wt_pad.to(dev()))
+    dx = torch.zeros(n, h, w, cin, dtype=torch.bfloat16, device=dev())
+    ops.conv_dgrad(shape_b, gyd, wd, dx)
+    assert (dx.float().permute(0, 3, 1, 2).cpu() - xr.grad).abs().max().item() < 2e-2 * xr.grad.abs().max().item()
+    dw = torch.zeros(255, cin, device=dev())
+    db = torch.zeros(255, device=dev())
+    ops.conv_wgrad(shape, x_d, gyd, dw, dbias=db)
+    assert (dw.cpu() - wr.grad.view(255, cin)).abs().max().item() < 1e-2 * wr.grad.abs().max().item()
+    assert (db.cpu() - br.grad).abs().max().item() < 1e-2 * br.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("c,pixels,res", [(32, 1000, False), (64, 4096, True), (256, 777, True), (1024, 300, False)])
+def test_bn_lrelu_fwd_bwd(c, pixels, res):
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    z = rnd((pixels, c), 11, 2.0) + 0.3
+    z = z.bfloat16().float()
+    gamma = rnd((c,), 12, 0.3) + 1.0
+    beta = rnd((c,), 13, 0.2)
+    r = rnd((pixels, c), 14) if res else None
+    g = rnd((pixels, c), 15)
+    # torch reference (fp32): BN(train) -> LeakyReLU(0.1) -> +res
+    zr = z.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    zz = zr.t().reshape(1, c, pixels, 1)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y = F.leaky_relu(F.batch_norm(zz, rm, rv, gr, br, True, 0.1, 1e-5), 0.1)
+    out_ref = y.reshape(c, pixels).t() + (r if res else 0)
+    out_ref.backward(g)
+    d = dev()
+    zd = z.to(d).bfloat16()
+    rows = 3
+    part = torch.zeros(rows, 2, c, device=d)
+    part[0, 0] = z.sum(0).to(d)
+    part[1, 1] = (z ** 2).sum(0).to(d)
+    ss = torch.empty(4 * c, device=d)
+    rmd, rvd = torch.zeros(c, device=d), torch.ones(c, device=d)
+    gam_d, bet_d = gamma.to(d), beta.to(d)   # keep alive: ptr() of a temporary would dangle
+    check(lib().mi355det_bn_finalize(ptr(part), rows, c, c, pixels, ptr(gam_d), ptr(bet_d), 1e-5, 0.1, ptr(rmd), ptr(rvd),
+                                     ptr(ss), stream_ptr()))
+    np.testing.assert_allclose(rmd.cpu(), rm, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(rvd.cpu(), rv, rtol=1e-3, atol=1e-4)
+    out = torch.empty(pixels, c, dtype=torch.bfloat16, device=d)
+    rd = r.to(d).bfloat16() if res else None
+    check(lib().mi355det_bn_act_fwd(ptr(zd), c, ptr(ss), c, pixels, 0.1, ptr(rd), c, ptr(out), c, stream_ptr()))
+    assert (out.float().cpu() - out_ref.detach()).abs().max().item() < 2e-2 * out_ref.abs().max().item()
+    gd = g.to(d).bfloat16()
+    sums = torch.zeros(2 * c, device=d)
+    check(lib().mi355det_bn_act_bwd_reduce(ptr(gd), c, None, 0, ptr(zd), c, ptr(ss), c, pixels, 0.1, ptr(sums), stream_ptr()))
+    dz = torch.empty(pixels, c, dtype=torch.bfloat16, device=d)
+    dg, db = torch.zeros(c, device=d), torch.zeros(c, device=d)
+    check(lib().mi355det_bn_act_bwd_apply(ptr(gd), c, None, 0, ptr(zd), c, ptr(ss), ptr(sums), None, c, pixels, 0.1, ptr(dz), c, ptr(dg),
+                                          ptr(db), stream_ptr()))
+    assert (dz.float().cpu() - zr.grad).abs().max().item() < 2e-2 * zr.grad.abs().max().item()
+    np.testing.assert_allclose(dg.cpu(), gr.grad, rtol=2e-2, atol=2e-2 * gr.grad.abs().max().item())
+    np.testing.assert_allclose(db.cpu(), br.grad, rtol=2e-2, atol=2e-2 * br.grad.abs().max().item())
+
+
+def test_upsample_and_layout():
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    d = dev()
+    x = rnd((2, 16, 5, 7), 21)
+    xd = nhwc(x)
+    out = torch.zeros(2, 10, 14, 24, dtype=torch.bfloat16, device=d)   # write into channels [0,16) of a 24-wide buffer
+    check(lib().mi355det_upsample2x_fwd(ptr(xd), 16, 2, 5, 7, 16, ptr(out), 24, stream_ptr()))
+    ref = F.interpolate(x, scale_factor=2, mode="nearest")
+    assert torch.equal(out[..., :16].float().permute(0, 3, 1, 2).cpu(), ref)
+    assert (out[..., 16:] == 0).all()
+    g = rnd((2, 16, 10, 14), 22)
+    gd = nhwc(g)
+    gx = torch.zeros(2, 5, 7, 16, dtype=torch.bfloat16, device=d)
+    check(lib().mi355det_upsample2x_bwd(ptr(gd), 16, 2, 5, 7, 16, ptr(gx), 16, stream_ptr()))
+    xr = x.clone().requires_grad_(True)
+    F.interpolate(xr, scale_factor=2, mode="nearest").backward(g)
+    assert (gx.float().permute(0, 3, 1, 2).cpu() - xr.grad).abs().max().item() < 3e-2 * xr.grad.abs().max().item()
+    # stem im2col == unfold
+    img = rnd((2, 3, 9, 8), 23)
+    col = torch.zeros(2 * 9 * 8, 32, dtype=torch.bfloat16, device=d)
+    img_d = img.to(d)
+    check(lib().mi355det_stem_im2col(ptr(img_d), ptr(col), 2, 9, 8, stream_ptr()))
+    unf = F.unfold(img, 3, padding=1).view(2, 3, 9, 72).permute(0, 3, 2, 1).reshape(2 * 72, 27)   # k = tap*3 + c
+    assert torch.equal(col[:, :27].float().cpu(), unf)
+    assert (col[:, 27:] == 0).all()
+    # layout converters
+    t = rnd((2, 5, 4, 6), 24)
+    o = torch.zeros(2, 4, 6, 8, dtype=torch.bfloat16, device=d)
+    t_d = t.to(d)
+    check(lib().mi355det_nchw_f32_to_nhwc(ptr(t_d), 2, 5, 4, 6, ptr(o), 1, 8, stream_ptr()))
+    assert torch.equal(o[..., :5].float().permute(0, 3, 1, 2).cpu(), t)
+    back = torch.empty(2, 5, 4, 6, device=d)
+    check(lib().mi355det_nhwc_to_nchw_f32(ptr(o), 1, 8, 2, 5, 4, 6, ptr(back), stream_ptr()))
+    assert torch.equal(back.cpu(), t)
