@@ -195,11 +195,11 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
 int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw,
                         float* dbias, void* stream);
 
-/* fp32 master weights [cout][cin][k][k] (torch layout) -> bf16 fwd pack [cout_pad][k][k][cin] and
+/* fp32 master weights, torch OIHW [cout][cin][k][k] or engine OHWI [cout][k][k][cin] (w_is_ohwi) -> bf16 fwd pack [cout_pad][k][k][cin] and
  * dgrad pack (stride 1: [cin_pad][k][k][cout] taps flipped; stride 2: 4 parity classes). */
 size_t mi355det_dgrad_pack_elems(const mi355det_conv_shape* s);
-int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, void* w_fwd, int32_t cout_pad,
-                          void* w_dgrad, void* stream);
+int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is_ohwi, void* w_fwd,
+                          int32_t cout_pad, void* w_dgrad, void* stream);
 /* dw fp32 [cout][k][k][cin] -> torch layout [cout][cin][k][k] (param.grad) */
 int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* grad, void* stream);
 

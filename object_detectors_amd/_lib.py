@@ -63,7 +63,7 @@ PROTOTYPES = {
     "mi355det_conv_dgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp]),
     "mi355det_conv_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, vp]),
     "mi355det_dgrad_pack_elems": (sz, [P(ConvShape)]),
-    "mi355det_pack_weights": (C.c_int, [P(ConvShape), vp, vp, i32, vp, vp]),
+    "mi355det_pack_weights": (C.c_int, [P(ConvShape), vp, C.c_int, vp, i32, vp, vp]),
     "mi355det_unpack_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp]),
     "mi355det_conv_stats_rows": (C.c_int, [P(ConvShape), i32]),
     "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),

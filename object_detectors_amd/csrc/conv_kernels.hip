@@ -194,7 +194,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float v = acc[i][j][r];
+          // statistics of the STORED (bf16-rounded) tensor: the BN backward formulas then hold exactly
+          const float v = bf2f(f2bf(acc[i][j][r]));
           s1 += v;
           s2 += v * v;
         }
@@ -260,14 +261,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
 
 // ------------------------------------------------------------------------------------------
 // weight packing: fp32 master [cout][cin][k][k] -> bf16 [cout_pad][tap][cin]  (K contiguous)
-__global__ void pack_fwd_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cout_pad, int cin, int cin_pad, int kk) {
+__global__ void pack_fwd_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cout_pad, int cin, int cin_pad, int kk,
+                                long long s_co, long long s_ci, long long s_t) {
   const long long total = (long long)cout_pad * kk * cin_pad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cin_pad);
     const int t = (int)((i / cin_pad) % kk);
     const int co = (int)(i / ((long long)cin_pad * kk));
     float v = 0.f;
-    if (co < cout && c < cin) v = w[((long long)co * cin + c) * kk + t];
+    if (co < cout && c < cin) v = w[co * s_co + c * s_ci + t * s_t];
     out[i] = f2bf(v);
   }
 }
@@ -275,9 +277,9 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, bf16_t* __restrict_
 // dgrad pack: rows = input channel ci, K = (tap list) x cout.  taps[j] gives the forward tap index
 // (kh*k+kw) whose weights feed dgrad tap j.  out [cin_pad][ntaps][cout]
 __global__ void pack_dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cin, int cin_pad, int kk, int ntaps,
-                                  const int* __restrict__ taps_dev, int t0, int t1, int t2, int t3, int t4, int t5, int t6, int t7, int t8) {
+                                  long long s_co, long long s_ci, long long s_t, int t0, int t1, int t2, int t3, int t4, int t5, int t6,
+                                  int t7, int t8) {
   const int taps[9] = {t0, t1, t2, t3, t4, t5, t6, t7, t8};
-  (void)taps_dev;
   const long long total = (long long)cin_pad * ntaps * cout;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int co = (int)(i % cout);
@@ -288,7 +290,7 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, bf16_t* __restric
     for (int q = 1; q < 9; ++q)
       if (j == q) tap = taps[q];
     float v = 0.f;
-    if (ci < cin) v = w[((long long)co * cin + ci) * kk + tap];
+    if (ci < cin) v = w[co * s_co + ci * s_ci + tap * s_t];
     out[i] = f2bf(v);
   }
 }
@@ -459,13 +461,16 @@ size_t mi355det_dgrad_pack_elems(const mi355det_conv_shape* s) {
   return cin_pad * (size_t)(s->ksize * s->ksize) * (size_t)s->cout + 64;
 }
 
-int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, void* w_fwd, int32_t cout_pad, void* w_dgrad, void* stream) {
+int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is_ohwi, void* w_fwd, int32_t cout_pad, void* w_dgrad,
+                          void* stream) {
   if (int e = check_shape(s, "pack_weights")) return e;
   const int kk = s->ksize * s->ksize;
+  // master layout: torch OIHW [cout][cin][k][k] or engine OHWI [cout][k][k][cin]
+  const long long s_co = (long long)s->cin * kk, s_ci = w_is_ohwi ? 1 : kk, s_t = w_is_ohwi ? s->cin : 1;
   if (w_fwd) {
     const long long total = (long long)cout_pad * kk * s->cin;
     hipLaunchKernelGGL(pack_fwd_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), w, (bf16_t*)w_fwd, s->cout,
-                       cout_pad, s->cin, s->cin, kk);
+                       cout_pad, s->cin, s->cin, kk, s_co, s_ci, s_t);
   }
   if (w_dgrad) {
     const int cin_pad = (s->cin + 31) / 32 * 32;
@@ -476,7 +481,7 @@ int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, void* w_
       const int nt = dgrad_taps(s, c >> 1, c & 1, ft, dy, dx);
       const long long total = (long long)cin_pad * nt * s->cout;
       hipLaunchKernelGGL(pack_dgrad_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), w, out, s->cout, s->cin,
-                         cin_pad, kk, nt, (const int*)nullptr, ft[0], ft[1], ft[2], ft[3], ft[4], ft[5], ft[6], ft[7], ft[8]);
+                         cin_pad, kk, nt, s_co, s_ci, s_t, ft[0], ft[1], ft[2], ft[3], ft[4], ft[5], ft[6], ft[7], ft[8]);
       out += total;
     }
   }

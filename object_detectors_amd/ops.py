@@ -43,14 +43,16 @@ def make_geom(anchors, num_classes, img_size, grids, iou_type=1, ignore_thr=0.5)
     return g
 
 
-def head_views(heads, attrs_total):
+def head_views(heads, attrs_total, dtype=torch.float32):
     """NCHW-shaped tensors [bs, A*attrs, H, W] with any (dense-pixel) strides -> HeadView array."""
     arr = (HeadView * _lib.MAX_SCALES)()
     keep = []
     for k, t in enumerate(heads):
         if t.dim() != 4 or t.shape[1] != attrs_total:
             raise ValueError(f"head {k}: expected [bs,{attrs_total},H,W], got {tuple(t.shape)}")
-        if t.dtype != torch.float32 or t.stride(2) != t.shape[3] * t.stride(3):
+        if t.dtype != dtype or t.stride(2) != t.shape[3] * t.stride(3):
+            if dtype != torch.float32:
+                raise ValueError("gradient views must already be bf16 with dense pixel strides")
             t = t.float().contiguous()
         keep.append(t)
         arr[k].ptr = t.data_ptr()
@@ -246,16 +248,17 @@ def cout_pad_of(cout):
     return pad_to(cout, 128) if cout >= 128 or cout % 32 else cout
 
 
-def pack_weights(shape, w_master, want_dgrad=True):
-    """fp32 [cout,cin,k,k] -> (bf16 fwd pack [cout_pad, k*k*cin], bf16 dgrad pack)."""
+def pack_weights(shape, w_master, want_dgrad=True, ohwi=False, wf=None, wd=None):
+    """fp32 [cout,cin,k,k] (or OHWI [cout,k,k,cin]) -> (bf16 fwd pack [cout_pad, k*k*cin], bf16 dgrad pack)."""
     dev = w_master.device
     cp = cout_pad_of(shape.cout)
     kk = shape.ksize * shape.ksize
-    wf = torch.empty(cp * kk * shape.cin, device=dev, dtype=torch.bfloat16)
-    wd = None
-    if want_dgrad:
+    if wf is None:
+        wf = torch.empty(cp * kk * shape.cin, device=dev, dtype=torch.bfloat16)
+    if want_dgrad and wd is None:
         wd = torch.empty(lib().mi355det_dgrad_pack_elems(C.byref(shape)), device=dev, dtype=torch.bfloat16)
-    check(lib().mi355det_pack_weights(C.byref(shape), ptr(w_master.contiguous()), ptr(wf), cp, ptr(wd), stream_ptr()), "pack_weights")
+    check(lib().mi355det_pack_weights(C.byref(shape), ptr(w_master.contiguous()), int(ohwi), ptr(wf), cp, ptr(wd), stream_ptr()),
+          "pack_weights")
     return wf, wd
 
 

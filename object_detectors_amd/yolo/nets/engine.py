@@ -1,0 +1,517 @@
+"""YOLOv3 (Darknet backbone + YoloHead) executor over libmi355det.so.
+
+Mirrors the forward graph of the reference's `DarkNet` (yolo/nets/backbone/darknet.py:37-84) and
+`YoloHead` (yolo/nets/yolohead.py:14-88) and owns the matching backward.  MI355X-first layout:
+
+  * activations NHWC bf16, resident in HBM for the whole step (z = pre-BN conv output and a = activated
+    output are both kept: ~12 GB at bs 32 / 640 px, trivial against 288 GB);
+  * channel concat is free: the producer writes straight into its channel slice of the concat buffer;
+  * every op is one prepared C-ABI call; a step is a static list of (function, ctypes args) tuples built
+    once per input shape ("plan"), so the host only walks a list and the GPU queue stays full;
+  * master weights / gradients live in two flat fp32 buffers (one memset, bucketed all-reduce, fused
+    optimizers); conv weights are OHWI so the weight-gradient GEMM output IS the parameter gradient.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from ... import _lib, ops
+from ..._lib import check, lib
+
+BLOCKS = {"darknet_21": [1, 1, 2, 2, 1], "darknet_53": [1, 2, 8, 8, 4]}
+SLOPE = 0.1
+BN_EPS, BN_MOM = 1e-5, 0.1
+
+
+def _vp(t, byte_off=0):
+    return C.c_void_p(t.data_ptr() + byte_off) if t is not None else None
+
+
+class Act:
+    """A [n,h,w,c] bf16 activation living in (a channel slice of) an NHWC buffer."""
+
+    def __init__(self, buf, n, h, w, c, ld, ch_off=0):
+        self.buf, self.n, self.h, self.w, self.c, self.ld, self.ch_off = buf, n, h, w, c, ld, ch_off
+        self.grad = None
+        self.grad_written = False
+        self.skips = []
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 2 * self.ch_off)
+
+    @property
+    def pixels(self):
+        return self.n * self.h * self.w
+
+    def slice(self, c0, c):
+        return Act(self.buf, self.n, self.h, self.w, c, self.ld, self.ch_off + c0)
+
+
+class ConvSpec:
+    def __init__(self, name, cin, cout, k, stride, bn=True, bias=False):
+        self.name, self.cin, self.cout, self.k, self.stride, self.bn, self.bias = name, cin, cout, k, stride, bn, bias
+
+
+def arch(backbone="darknet_53", na=3, nc=80):
+    """Ordered conv specs (reference state_dict order) keyed by name."""
+    specs = [ConvSpec("backbone.conv1", 3, 32, 3, 1)]
+    inpl = 32
+    for li, (planes, nb) in enumerate(zip([(32, 64), (64, 128), (128, 256), (256, 512), (512, 1024)], BLOCKS[backbone]), 1):
+        p = f"backbone.layer{li}"
+        specs.append(ConvSpec(p + ".ds_conv", inpl, planes[1], 3, 2))
+        inpl = planes[1]
+        for b in range(nb):
+            specs.append(ConvSpec(f"{p}.residual_{b}.conv1", inpl, planes[0], 1, 1))
+            specs.append(ConvSpec(f"{p}.residual_{b}.conv2", planes[0], inpl, 3, 1))
+    fo = na * (5 + nc)
+
+    def emb(name, fl, cin):
+        ch = [(cin, fl[0], 1), (fl[0], fl[1], 3), (fl[1], fl[0], 1), (fl[0], fl[1], 3), (fl[1], fl[0], 1), (fl[0], fl[1], 3)]
+        for i, (ci, co, k) in enumerate(ch):
+            specs.append(ConvSpec(f"{name}.{i}.conv", ci, co, k, 1))
+        specs.append(ConvSpec(name + ".conv_out", fl[1], fo, 1, 1, bn=False, bias=True))
+    emb("embedding0", (512, 1024), 1024)
+    specs.append(ConvSpec("embedding1_cbl.conv", 512, 256, 1, 1))
+    emb("embedding1", (256, 512), 768)
+    specs.append(ConvSpec("embedding2_cbl.conv", 256, 128, 1, 1))
+    emb("embedding2", (128, 256), 384)
+    return specs
+
+
+def bn_name(conv_name):
+    """reference BatchNorm module name next to a conv (darknet.py / yolohead.py naming)."""
+    if conv_name == "backbone.conv1":
+        return "backbone.bn1"
+    if conv_name.endswith(".ds_conv"):
+        return conv_name[:-len("ds_conv")] + "ds_bn"
+    if conv_name.endswith(".conv1"):
+        return conv_name[:-len("conv1")] + "bn1"
+    if conv_name.endswith(".conv2"):
+        return conv_name[:-len("conv2")] + "bn2"
+    return conv_name[:-len("conv")] + "bn"
+
+
+class YoloV3Engine:
+    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0):
+        lib()   # fail loudly if the HIP library is missing
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.backbone, self.na, self.nc = backbone, num_anchors, num_classes
+        self.head_c = num_anchors * (5 + num_classes)
+        self.head_ld = ops.pad_to(self.head_c, 32)
+        self.specs = arch(backbone, num_anchors, num_classes)
+        self.by_name = {s.name: s for s in self.specs}
+        self._layout_params()
+        self.reset_parameters(seed)
+        self.plans = {}
+        self.training = True
+        self.num_batches_tracked = 0
+
+    # ------------------------------------------------------------------ parameters
+    def _layout_params(self):
+        """Flat fp32 parameter/gradient buffers; views per tensor.  Conv weights OHWI [cout,k,k,cin]
+        (stem: [32, 32] im2col form, conv_out rows padded to head_ld)."""
+        off = 0
+        self.pviews = {}       # name -> (offset, numel, shape)
+        order = []
+        for s in self.specs:
+            if s.name == "backbone.conv1":
+                shape = (32, 32)
+            elif not s.bn:
+                shape = (ops.pad_to(s.cout, 32), s.k, s.k, s.cin)
+            else:
+                shape = (s.cout, s.k, s.k, s.cin)
+            n = math.prod(shape)
+            order.append((s.name + ".weight", off, n, shape))
+            off += ops.pad_to(n, 64)
+            if s.bias:
+                order.append((s.name + ".bias", off, s.cout, (s.cout,)))
+                off += ops.pad_to(s.cout, 64)
+            if s.bn:
+                b = bn_name(s.name)
+                for suffix in (".weight", ".bias"):
+                    order.append((b + suffix, off, s.cout, (s.cout,)))
+                    off += ops.pad_to(s.cout, 64)
+        self.flat_w = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.param_order = order
+        self.params, self.grads = {}, {}
+        for name, o, n, shape in order:
+            self.params[name] = self.flat_w[o:o + n].view(shape)
+            self.grads[name] = self.flat_g[o:o + n].view(shape)
+        # BN running statistics
+        self.buffers = {}
+        for s in self.specs:
+            if s.bn:
+                b = bn_name(s.name)
+                self.buffers[b + ".running_mean"] = torch.zeros(s.cout, device=self.device)
+                self.buffers[b + ".running_var"] = torch.ones(s.cout, device=self.device)
+        # packed bf16 weights
+        self.packed = {}
+        for s in self.specs:
+            shp = self._wshape(s, 1, 8, 8)   # geometry-independent sizes
+            cp = ops.cout_pad_of(shp.cout)
+            wf = torch.zeros(cp * shp.ksize * shp.ksize * shp.cin, device=self.device, dtype=torch.bfloat16)
+            wd = None
+            if s.name != "backbone.conv1":
+                wd = torch.zeros(lib().mi355det_dgrad_pack_elems(C.byref(shp)), device=self.device, dtype=torch.bfloat16)
+            self.packed[s.name] = (wf, wd)
+
+    def _wshape(self, s, n, h, w, in_ld=None, out_ld=None):
+        if s.name == "backbone.conv1":
+            return ops.conv_shape(n, h, w, 32, 32, 1, 1, in_ld, out_ld)
+        cout = s.cout if s.bn else ops.pad_to(s.cout, 32)
+        return ops.conv_shape(n, h, w, s.cin, cout, s.k, s.stride, in_ld, out_ld)
+
+    def reset_parameters(self, seed=0):
+        """Reference initialisation: conv N(0, sqrt(2/(k*k*cout))) in the backbone (darknet.py:53-59), PyTorch
+        default (kaiming-uniform a=sqrt(5)) for the head convs, BN weight 1 / bias 0."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for s in self.specs:
+            w = self.params[s.name + ".weight"]
+            if s.name.startswith("backbone."):
+                std = math.sqrt(2.0 / (s.k * s.k * s.cout))
+                t = torch.randn((s.cout, s.cin, s.k, s.k), generator=g) * std
+            else:
+                bound = 1.0 / math.sqrt(s.cin * s.k * s.k)
+                t = (torch.rand((s.cout, s.cin, s.k, s.k), generator=g) * 2 - 1) * bound
+            self._set_weight_oihw(s, t)
+            if s.bias:
+                bound = 1.0 / math.sqrt(s.cin * s.k * s.k)
+                self.params[s.name + ".bias"].copy_((torch.rand(s.cout, generator=g) * 2 - 1) * bound)
+            if s.bn:
+                b = bn_name(s.name)
+                self.params[b + ".weight"].fill_(1.0)
+                self.params[b + ".bias"].zero_()
+            del w
+
+    def _set_weight_oihw(self, s, t):
+        """Load a reference-layout [cout,cin,k,k] tensor into the engine layout."""
+        w = self.params[s.name + ".weight"]
+        t = t.to(self.device, torch.float32)
+        if s.name == "backbone.conv1":
+            w.zero_()
+            w[:, :27] = t.permute(0, 2, 3, 1).reshape(32, 27)      # k = (kh*3+kw)*3 + c
+        elif not s.bn:
+            w.zero_()
+            w[:s.cout] = t.permute(0, 2, 3, 1)
+        else:
+            w.copy_(t.permute(0, 2, 3, 1))
+
+    def _get_weight_oihw(self, s, src=None):
+        w = (src or self.params)[s.name + ".weight"]
+        if s.name == "backbone.conv1":
+            return w[:, :27].reshape(32, 3, 3, 3).permute(0, 3, 1, 2).contiguous()
+        if not s.bn:
+            return w[:s.cout].permute(0, 3, 1, 2).contiguous()
+        return w.permute(0, 3, 1, 2).contiguous()
+
+    def load_reference_state_dict(self, sd):
+        """state_dict of the reference YoloHead (keys as in darknet.py / yolohead.py)."""
+        for s in self.specs:
+            self._set_weight_oihw(s, sd[s.name + ".weight"])
+            if s.bias:
+                self.params[s.name + ".bias"].copy_(sd[s.name + ".bias"])
+            if s.bn:
+                b = bn_name(s.name)
+                self.params[b + ".weight"].copy_(sd[b + ".weight"])
+                self.params[b + ".bias"].copy_(sd[b + ".bias"])
+                for k in (".running_mean", ".running_var"):
+                    if b + k in sd:
+                        self.buffers[b + k].copy_(sd[b + k])
+                if b + ".num_batches_tracked" in sd:
+                    self.num_batches_tracked = int(sd[b + ".num_batches_tracked"])
+
+    def reference_state_dict(self, grads=False):
+        """Parameters (or their gradients) under the reference's names, layouts and key order."""
+        out = {}
+        src = self.grads if grads else self.params
+        for s in self.specs:
+            out[s.name + ".weight"] = self._get_weight_oihw(s, src)
+            if s.bias:
+                out[s.name + ".bias"] = src[s.name + ".bias"].clone()
+            if s.bn:
+                b = bn_name(s.name)
+                out[b + ".weight"] = src[b + ".weight"].clone()
+                out[b + ".bias"] = src[b + ".bias"].clone()
+                if not grads:
+                    for k in (".running_mean", ".running_var"):
+                        out[b + k] = self.buffers[b + k].clone()
+                    out[b + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked, dtype=torch.int64)
+        return out
+
+    # ------------------------------------------------------------------ plan
+    def plan(self, n, H, W, training):
+        key = (n, H, W, bool(training), torch.cuda.current_stream().cuda_stream)
+        if key not in self.plans:
+            self.plans[key] = Plan(self, n, H, W, training, key[-1])
+        return self.plans[key]
+
+    def forward(self, images, training=None):
+        """images [n,3,H,W] fp32 NCHW on the GPU -> (out0,out1,out2) NCHW-shaped fp32 views [n,A*(5+C),h,w]."""
+        training = self.training if training is None else training
+        if images.dim() != 4 or images.shape[1] != 3 or not images.is_cuda:
+            raise ValueError("expected a CUDA tensor [n,3,H,W]")
+        n, _, H, W = images.shape
+        if H % 32 or W % 32:
+            raise ValueError("input size must be a multiple of 32")
+        p = self.plan(n, H, W, training)
+        p.run_forward(images.float().contiguous())
+        self._last_plan = p
+        return p.head_outputs()
+
+    def train_step(self, images, targets, criterion, grad_scale=1.0):
+        """One fused forward+backward (train_one_epoch.py:72-73,88-90 without the optimizer): the criterion's
+        gradient goes straight into the bf16 head-gradient buffers, no autograd graph.  Returns out12
+        (loss, sub_losses[6], stats[5]) as a device tensor."""
+        heads = self.forward(images, training=True)
+        p = self._last_plan
+        p.zero_head_grads()
+        gv, _keep = ops.head_views(p.head_grad_views(), self.head_c, dtype=torch.bfloat16)
+        out12, _ = criterion._loss_impl(heads, targets, want_grad=True, grad_views=gv, grad_is_bf16=True, grad_scale=grad_scale)
+        p.run_backward()
+        return out12
+
+    def backward(self, head_grads=None):
+        """Backward of the last training forward.  head_grads: None = the plan's bf16 head-gradient buffers were
+        already filled (fused loss), or a list of NCHW fp32 tensors (autograd bridge)."""
+        p = self._last_plan
+        if head_grads is not None:
+            p.load_head_grads(head_grads)
+        p.run_backward()
+
+
+class Plan:
+    """Buffers + prepared call lists for one (batch, H, W, mode)."""
+
+    def __init__(self, eng, n, H, W, training, stream):
+        self.eng, self.n, self.H, self.W, self.training = eng, n, H, W, training
+        self.stream = C.c_void_p(stream)
+        self.fwd, self.bwd, self.pack = [], [], []
+        self.keep = []            # ctypes structs / tensors that must outlive the call lists
+        self.dz_elems = 0
+        self.layers = {}
+        dev = eng.device
+        L = lib()
+        bf = torch.bfloat16
+
+        def new_act(n_, h_, w_, c_, buf=None, ld=None, off=0):
+            if buf is None:
+                buf = torch.zeros((n_, h_, w_, c_), device=dev, dtype=bf)
+                ld = c_
+            return Act(buf, n_, h_, w_, c_, ld, off)
+
+        g5, g4, g3 = (H // 32, W // 32), (H // 16, W // 16), (H // 8, W // 8)
+        self.cat1 = new_act(n, g4[0], g4[1], 768)
+        self.cat2 = new_act(n, g3[0], g3[1], 384)
+        self.col = new_act(n, H, W, 32)
+        self.heads = [torch.zeros((n, g[0], g[1], eng.head_ld), device=dev, dtype=torch.float32) for g in (g5, g4, g3)]
+        self.head_grads = [torch.zeros((n, g[0], g[1], eng.head_ld), device=dev, dtype=bf) for g in (g5, g4, g3)]
+        self.ops = []   # forward-ordered op records for the backward builder
+
+        # ---- forward graph
+        def conv_bn(name, x, out=None, res=None):
+            s = eng.by_name[name]
+            shp = eng._wshape(s, x.n, x.h, x.w, in_ld=x.ld)
+            a = out if out is not None else new_act(x.n, shp.ho, shp.wo, shp.cout)
+            shp.out_ld = shp.cout   # z pitch
+            z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
+            rows = ops.conv_stats_rows(shp)
+            cp = ops.cout_pad_of(shp.cout)
+            stats = torch.zeros((rows, 2, cp), device=dev, dtype=torch.float32) if training else None
+            ss = torch.zeros(4 * shp.cout, device=dev, dtype=torch.float32)
+            wf, wd = eng.packed[name]
+            b = bn_name(name)
+            pixels = x.n * shp.ho * shp.wo
+            self.keep += [shp, z, stats, ss]
+            self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp), x.ptr, _vp(wf), None, _vp(z), 0, _vp(stats), cp, self.stream)))
+            if training:
+                self.fwd.append((L.mi355det_bn_finalize, (_vp(stats), rows, shp.cout, cp, pixels, _vp(eng.params[b + ".weight"]),
+                                                          _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
+                                                          _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
+                                                          _vp(ss), self.stream)))
+            else:
+                self.fwd.append((L.mi355det_bn_eval_scale_shift, (shp.cout, _vp(eng.params[b + ".weight"]), _vp(eng.params[b + ".bias"]),
+                                                                  _vp(eng.buffers[b + ".running_mean"]),
+                                                                  _vp(eng.buffers[b + ".running_var"]), BN_EPS, _vp(ss), self.stream)))
+            self.fwd.append((L.mi355det_bn_act_fwd, (_vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE, res.ptr if res else None,
+                                                     res.ld if res else 0, a.ptr, a.ld, self.stream)))
+            self.dz_elems = max(self.dz_elems, pixels * shp.cout)
+            rec = dict(kind="cbl", name=name, spec=s, shp=shp, x=x, a=a, res=res, z=z, ss=ss, pixels=pixels)
+            self.ops.append(rec)
+            self.layers[name] = rec
+            return a
+
+        def conv_out(name, x, k):
+            s = eng.by_name[name]
+            shp = eng._wshape(s, x.n, x.h, x.w, in_ld=x.ld, out_ld=eng.head_ld)
+            shp_f = ops.conv_shape(x.n, x.h, x.w, s.cin, s.cout, 1, 1, x.ld, eng.head_ld)   # true cout: masks the pad channel
+            wf, wd = eng.packed[name]
+            cp = ops.cout_pad_of(shp_f.cout)
+            self.keep += [shp, shp_f]
+            self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp_f), x.ptr, _vp(wf), _vp(eng.params[name + ".bias"]), _vp(self.heads[k]), 1,
+                                                   None, cp, self.stream)))
+            self.ops.append(dict(kind="out", name=name, spec=s, shp=shp, shp_f=shp_f, x=x, k=k))
+
+        # stem (darknet.py:74-76) as im2col + 1x1
+        self.img_call = len(self.fwd)
+        self.fwd.append((L.mi355det_stem_im2col, [None, self.col.ptr, n, H, W, self.stream]))
+        x = conv_bn("backbone.conv1", self.col)
+        feats = {}
+        for li, nb in enumerate(BLOCKS[eng.backbone], 1):
+            p = f"backbone.layer{li}"
+            x = conv_bn(p + ".ds_conv", x)
+            for b in range(nb):
+                y = conv_bn(f"{p}.residual_{b}.conv1", x)
+                out = None
+                if b == nb - 1 and li == 3:
+                    out = self.cat2.slice(128, 256)      # torch.cat([x2_in, x2], 1): backbone slice after the upsampled one
+                if b == nb - 1 and li == 4:
+                    out = self.cat1.slice(256, 512)
+                x = conv_bn(f"{p}.residual_{b}.conv2", y, out=out, res=x)
+            feats[li] = x
+
+        def branch(name, t, k):
+            br = None
+            for i in range(6):
+                t = conv_bn(f"{name}.{i}.conv", t)
+                if i == 4:
+                    br = t
+            conv_out(name + ".conv_out", t, k)
+            return br
+        b0 = branch("embedding0", feats[5], 0)
+        t = conv_bn("embedding1_cbl.conv", b0)
+        up1 = self.cat1.slice(0, 256)
+        self.fwd.append((L.mi355det_upsample2x_fwd, (t.ptr, t.ld, t.n, t.h, t.w, t.c, up1.ptr, up1.ld, self.stream)))
+        self.ops.append(dict(kind="up", x=t, cat=self.cat1, c_up=256, skip_to=feats[4]))
+        b1 = branch("embedding1", self.cat1, 1)
+        t = conv_bn("embedding2_cbl.conv", b1)
+        up2 = self.cat2.slice(0, 128)
+        self.fwd.append((L.mi355det_upsample2x_fwd, (t.ptr, t.ld, t.n, t.h, t.w, t.c, up2.ptr, up2.ld, self.stream)))
+        self.ops.append(dict(kind="up", x=t, cat=self.cat2, c_up=128, skip_to=feats[3]))
+        branch("embedding2", self.cat2, 2)
+
+        # ---- weight packing (every step: the optimizer changes the fp32 masters)
+        for s in eng.specs:
+            shp = eng._wshape(s, 1, 8, 8)
+            wf, wd = eng.packed[s.name]
+            cp = ops.cout_pad_of(shp.cout)
+            self.keep.append(shp)
+            need_d = training and wd is not None
+            self.pack.append((L.mi355det_pack_weights, (C.byref(shp), _vp(eng.params[s.name + ".weight"]), 1, _vp(wf), cp,
+                                                        _vp(wd) if need_d else None, self.stream)))
+        if training:
+            self._build_backward()
+
+    # ------------------------------------------------------------------
+    def _build_backward(self):
+        eng, L, dev = self.eng, lib(), self.eng.device
+        bf = torch.bfloat16
+        self.dz = torch.zeros(self.dz_elems, device=dev, dtype=bf)
+        nsum = sum(2 * r["shp"].cout for r in self.ops if r["kind"] == "cbl")
+        self.sums_all = torch.zeros(nsum, device=dev, dtype=torch.float32)
+        sum_off = [0]
+
+        def grad_of(a):
+            if a.grad is None:
+                a.grad = Act(torch.zeros((a.n, a.h, a.w, a.c), device=dev, dtype=bf), a.n, a.h, a.w, a.c, a.c)
+            return a.grad
+
+        def emit_dgrad(shp, dy_ptr, wd, x):
+            g = grad_of(x)
+            if g.ld != shp.in_ld:     # x is a channel slice of a concat buffer; its gradient buffer is dense
+                shp = _lib.ConvShape(shp.n, shp.h, shp.w, shp.cin, shp.ho, shp.wo, shp.cout, shp.ksize, shp.stride, shp.pad, g.ld,
+                                     shp.out_ld)
+                self.keep.append(shp)
+            if not x.grad_written:
+                r = x.skips.pop(0) if x.skips else None
+                self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, r.ptr if r else None, r.ld if r else 0,
+                                                         self.stream)))
+                x.grad_written = True
+            else:
+                self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, g.ptr, g.ld, self.stream)))
+            while x.skips:
+                r = x.skips.pop(0)
+                self.bwd.append((L.mi355det_add_bf16, (g.ptr, g.ld, r.ptr, r.ld, x.c, x.pixels, g.ptr, g.ld, self.stream)))
+
+        for rec in reversed(self.ops):
+            if rec["kind"] == "out":
+                shp, shp_f, x, k, name = rec["shp"], rec["shp_f"], rec["x"], rec["k"], rec["name"]
+                _, wd = eng.packed[name]
+                dy = _vp(self.head_grads[k])
+                self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp_f), x.ptr, dy, _vp(eng.grads[name + ".weight"]),
+                                                         _vp(eng.grads[name + ".bias"]), self.stream)))
+                emit_dgrad(shp, dy, wd, x)
+            elif rec["kind"] == "up":
+                x, cat, c_up, skip_to = rec["x"], rec["cat"], rec["c_up"], rec["skip_to"]
+                assert cat.grad is not None and cat.grad_written
+                gup = cat.grad.slice(0, c_up)
+                gx = grad_of(x)
+                self.bwd.append((L.mi355det_upsample2x_bwd, (gup.ptr, gup.ld, x.n, x.h, x.w, x.c, gx.ptr, gx.ld, self.stream)))
+                x.grad_written = True
+                skip_to.skips.append(cat.grad.slice(c_up, cat.c - c_up))
+            else:
+                name, shp, x, a, res, z, ss, pixels = (rec[k] for k in ("name", "shp", "x", "a", "res", "z", "ss", "pixels"))
+                assert a.grad is not None and a.grad_written and not a.skips, name
+                g = a.grad
+                b = bn_name(name)
+                sums = self.sums_all[sum_off[0]:sum_off[0] + 2 * shp.cout]
+                sum_off[0] += 2 * shp.cout
+                if res is not None:
+                    res.skips.append(g)
+                self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
+                                                                _vp(sums), self.stream)))
+                self.bwd.append((L.mi355det_bn_act_bwd_apply, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), _vp(sums), None, shp.cout,
+                                                               pixels, SLOPE, _vp(self.dz), shp.cout, _vp(eng.grads[b + ".weight"]),
+                                                               _vp(eng.grads[b + ".bias"]), self.stream)))
+                self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(self.dz), _vp(eng.grads[name + ".weight"]), None,
+                                                         self.stream)))
+                if name != "backbone.conv1":
+                    _, wd = eng.packed[name]
+                    emit_dgrad(shp, _vp(self.dz), wd, x)
+
+    # ------------------------------------------------------------------
+    def _run(self, calls):
+        for fn, args in calls:
+            if fn is comm_hook:
+                args[0](*args[1:])
+                continue
+            st = fn(*args)
+            if st != 0:
+                check(st, fn.__name__)
+
+    def run_forward(self, images):
+        self._img = images
+        self.fwd[self.img_call][1][0] = C.c_void_p(images.data_ptr())
+        self._run(self.pack)
+        self._run(self.fwd)
+        if self.training:
+            self.eng.num_batches_tracked += 1
+
+    def head_outputs(self):
+        c = self.eng.head_c
+        return [h[..., :c].permute(0, 3, 1, 2) for h in self.heads]
+
+    def head_grad_views(self):
+        """bf16 gradient buffers behind the same NCHW-shaped views (for the fused criterion)."""
+        c = self.eng.head_c
+        return [g[..., :c].permute(0, 3, 1, 2) for g in self.head_grads]
+
+    def zero_head_grads(self):
+        for g in self.head_grads:
+            g.zero_()
+
+    def load_head_grads(self, grads):
+        c = self.eng.head_c
+        for dst, g in zip(self.head_grads, grads):
+            dst[..., :c].copy_(g.permute(0, 2, 3, 1))
+
+    def run_backward(self):
+        self.eng.flat_g.zero_()
+        self.sums_all.zero_()
+        self._run(self.bwd)
+
+
+def comm_hook(*a):   # marker: (comm_hook, (callable, *args)) entries run a python callback inside a call list
+    raise RuntimeError("marker only")

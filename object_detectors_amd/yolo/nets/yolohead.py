@@ -1,0 +1,59 @@
+"""Mirror of yolo/nets/yolohead.py:YoloHead (+ the DarkNet backbone it wraps): same constructor
+config, same `forward(x) -> (out0, out1, out2)` with [bs, A*(5+C), H/32|16|8, W/32|16|8] outputs, and a
+state_dict with the reference's keys/layouts — executed by the MI355X engine (engine.py)."""
+import torch
+import torch.nn as nn
+
+from .engine import YoloV3Engine
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        ctx.mod = mod
+        outs = mod.engine.forward(x, training=mod.training)
+        return tuple(o for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        mod = ctx.mod
+        mod.engine.backward([g for g in gouts])
+        mod._attach_grads()
+        return (None, None) + (None,) * len(mod._plist)
+
+
+class YoloHead(nn.Module):
+    def __init__(self, config, is_training=True):
+        super().__init__()
+        self.config = config
+        cfgb = config["backbone"]
+        na = len(config["dataset"]["anchors"][0])
+        nc = config["yolo"]["classes"]
+        self.engine = YoloV3Engine(cfgb.get("backbone_name", "darknet_53"), na, nc)
+        self.layers_out_filters = [64, 128, 256, 512, 1024]
+        # parameters are views into the engine's flat master buffer (conv weights in OHWI layout)
+        self._pnames, self._plist = [], nn.ParameterList()
+        for name, _o, _n, _shape in self.engine.param_order:
+            self._pnames.append(name)
+            self._plist.append(nn.Parameter(self.engine.params[name]))
+        self.train(is_training)
+
+    def _attach_grads(self):
+        for name, p in zip(self._pnames, self._plist):
+            p.grad = self.engine.grads[name]
+
+    def named_reference_parameters(self):
+        return list(zip(self._pnames, self._plist))
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and self.training:
+            return _EngineFn.apply(self, x, *self._plist)
+        return tuple(self.engine.forward(x, training=self.training))
+
+    # reference-compatible checkpoints (initialize.py:12-25,57-104 save/load model.state_dict())
+    def state_dict(self, *a, **k):
+        return self.engine.reference_state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.engine.load_reference_state_dict(sd)

@@ -1,0 +1,230 @@
+"""GPU parity of the YOLOv3 engine (Darknet + head, fwd/bwd).
+
+Deep randomly-initialised BN networks amplify rounding differences (~1.15x per layer measured on the
+golden network), so an end-to-end bf16-vs-fp32 comparison of the 75-conv graph is only meaningful at a
+loose tolerance.  The tight checks are therefore LOCAL and exhaustive: every layer's forward and
+backward is compared with a plain PyTorch fp32 evaluation of that layer on the engine's own stored
+operands, and every activation gradient must equal the sum of its consumers' contributions (which pins
+the graph wiring: residual skips, concat slices, upsample, branch points).  End-to-end runs against
+oracle/net_oracle.py (pinned to the reference's golden outputs) use a damped-residual weight set.
+"""
+import numpy as np
+import pytest
+
+from oracle import detrand, net_oracle
+from oracle import yolo_oracle as yo
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+ANCHORS = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf16q(t):
+    return t.bfloat16().float()
+
+
+def make_engine(bname, wseed, damp=None):
+    from object_detectors_amd.yolo.nets.engine import YoloV3Engine
+    eng = YoloV3Engine(bname, 3, 80, device=dev())
+    sd = net_oracle.det_state(bname, wseed)
+    if damp:
+        for k in sd:
+            if k.endswith(".bn2.weight"):
+                sd[k] = sd[k] * damp
+    eng.load_reference_state_dict(sd)
+    return eng, sd
+
+
+def view(a):
+    return a.buf.view(a.n, a.h, a.w, -1)[..., a.ch_off:a.ch_off + a.c].float().permute(0, 3, 1, 2).cpu()
+
+
+def rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("bname,px,bs", [("darknet_21", 96, 2), ("darknet_53", 96, 2)])
+def test_engine_local_parity_and_wiring(bname, px, bs):
+    from object_detectors_amd.yolo.nets.engine import bn_name
+    eng, sd = make_engine(bname, 5000)
+    x = detrand.uniform(4242, (bs, 3, px, px), -2.0, 2.0)
+    outs = eng.forward(torch.from_numpy(x).to(dev()), training=True)
+    cots = [detrand.uniform(4300 + k, tuple(o.shape), -1.0, 1.0) for k, o in enumerate(outs)]
+    eng.backward([torch.from_numpy(c).to(dev()) for c in cots])
+    plan = eng._last_plan
+    got = eng.reference_state_dict(grads=True)
+    contrib = {}      # id(Act) -> expected gradient (sum of consumer contributions), fp32 torch
+
+    def add(act, t):
+        contrib[id(act)] = contrib.get(id(act), 0) + t
+    acts = {}
+    bad = []
+    for rec in plan.ops:
+        if rec["kind"] == "up":
+            xa, cat, c_up = rec["x"], rec["cat"], rec["c_up"]
+            gcat = view(cat.grad)
+            g = gcat[:, :c_up]
+            add(xa, g.reshape(g.shape[0], g.shape[1], xa.h, 2, xa.w, 2).sum((3, 5)))
+            add(rec["skip_to"], gcat[:, c_up:])
+            acts[id(xa)], acts[id(rec["skip_to"])] = xa, rec["skip_to"]
+            # forward of the upsample + concat
+            up = F.interpolate(view(xa), scale_factor=2, mode="nearest")
+            assert torch.equal(view(cat)[:, :c_up], up)
+            continue
+        s, xa, name = rec["spec"], rec["x"], rec["name"]
+        acts[id(xa)] = xa
+        xin = view(xa).requires_grad_(True)
+        if rec["kind"] == "out":
+            k = rec["k"]
+            w = bf16q(sd[name + ".weight"]).requires_grad_(True)
+            bb = sd[name + ".bias"].clone().requires_grad_(True)
+            y = F.conv2d(xin, w, bb)
+            o = outs[k].cpu()
+            if (o - y.detach()).abs().max() > 1e-2 * y.abs().max():
+                bad.append((name, "fwd"))
+            y.backward(bf16q(torch.from_numpy(cots[k])))
+            if rel(got[name + ".weight"].cpu(), w.grad) > 2e-2 or rel(got[name + ".bias"].cpu(), bb.grad) > 2e-2:
+                bad.append((name, "dW/db", rel(got[name + ".weight"].cpu(), w.grad)))
+            add(xa, xin.grad)
+            continue
+        a, b = rec["a"], bn_name(name)
+        # ---- forward: z = conv(x), a = lrelu(bn(z)) (+res) on the engine's own operands
+        zg = rec["z"].float().permute(0, 3, 1, 2).cpu()
+        if name == "backbone.conv1":
+            zz = F.conv2d(bf16q(torch.from_numpy(x)), bf16q(sd[name + ".weight"]), padding=1)
+        else:
+            zz = F.conv2d(xin.detach(), bf16q(sd[name + ".weight"]), stride=s.stride, padding=(s.k - 1) // 2)
+        if (zg - zz).abs().max() > 1e-2 * zz.abs().max():
+            bad.append((name, "z", float((zg - zz).abs().max() / zz.abs().max())))
+        z = zg.clone().requires_grad_(True)
+        gam, bet = sd[b + ".weight"].clone().requires_grad_(True), sd[b + ".bias"].clone().requires_grad_(True)
+        y = F.leaky_relu(F.batch_norm(z, None, None, gam, bet, True, 0.1, 1e-5), 0.1)
+        yy = y.detach() + (view(rec["res"]) if rec["res"] is not None else 0)
+        if (view(a) - yy).abs().max() > 1.5e-2 * yy.abs().max():
+            bad.append((name, "a", float((view(a) - yy).abs().max() / yy.abs().max())))
+        # ---- backward given the engine's gradient of a
+        G = view(a.grad)
+        y.backward(G)
+        if rel(got[b + ".weight"].cpu(), gam.grad) > 2e-2 or rel(got[b + ".bias"].cpu(), bet.grad) > 8e-2:
+            bad.append((name, "dgamma/dbeta", rel(got[b + ".weight"].cpu(), gam.grad), rel(got[b + ".bias"].cpu(), bet.grad)))
+        dz = bf16q(z.grad)
+        if name == "backbone.conv1":
+            xi = bf16q(torch.from_numpy(x)).requires_grad_(True)
+            w = bf16q(sd[name + ".weight"]).requires_grad_(True)
+            F.conv2d(xi, w, padding=1).backward(dz)
+        else:
+            w = bf16q(sd[name + ".weight"]).requires_grad_(True)
+            F.conv2d(xin, w, stride=s.stride, padding=(s.k - 1) // 2).backward(dz)
+            add(xa, xin.grad)
+        if rel(got[name + ".weight"].cpu(), w.grad) > 6e-2:
+            bad.append((name, "dW", rel(got[name + ".weight"].cpu(), w.grad)))
+        if rec["res"] is not None:
+            add(rec["res"], G)
+            acts[id(rec["res"])] = rec["res"]
+    # ---- wiring: every activation gradient == sum of its consumers' contributions
+    for key, exp in contrib.items():
+        act = acts[key]
+        if act is plan.col:
+            continue
+        g = view(act.grad)
+        if rel(g, exp) > 3e-2:
+            bad.append(("grad-sum", act.c, act.h, rel(g, exp)))
+    assert not bad, bad[:12]
+
+
+def test_engine_end_to_end_vs_oracle(golden):
+    """End to end against the pinned torch oracle with bf16-rounded storage, damped residual branches."""
+    bname, px, bs = "darknet_21", 128, 4
+    eng, sd = make_engine(bname, 5000, damp=0.2)
+    x = detrand.uniform(4242, (bs, 3, px, px), -2.0, 2.0)
+    outs = eng.forward(torch.from_numpy(x).to(dev()), training=True)
+    sdq = {k: v.clone() for k, v in sd.items()}
+    for k, v in sdq.items():
+        if v.dtype == torch.float32:
+            v.requires_grad_(not k.endswith(("running_mean", "running_var")))
+    ref_outs = net_oracle.forward(sdq, torch.from_numpy(x), bname, training=True, quant=bf16q)
+    errs = []
+    for k, o in enumerate(outs):
+        r = ref_outs[k].detach()
+        errs.append(rel(o.cpu(), r))
+    assert max(errs) < 0.08, errs
+    cots = [detrand.uniform(4300 + k, tuple(o.shape), -1.0, 1.0) for k, o in enumerate(outs)]
+    sum((o * torch.from_numpy(c)).sum() for o, c in zip(ref_outs, cots)).backward()
+    eng.backward([torch.from_numpy(c).to(dev()) for c in cots])
+    got = eng.reference_state_dict(grads=True)
+    coss = []
+    for n, v in sdq.items():
+        if v.grad is None:
+            continue
+        gg, og = got[n].cpu().double(), v.grad.double()
+        coss.append((float((gg * og).sum() / (gg.norm() * og.norm() + 1e-30)), n))
+    coss.sort()
+    assert coss[len(coss) // 10][0] > 0.8, coss[:8]          # 90 % of the tensors: cosine > 0.8
+    assert coss[0][0] > 0.5, coss[:8]
+
+
+def test_engine_golden_reference_outputs(golden):
+    """Against the REFERENCE modules' own outputs (fixture g8, 64 px): loose, bf16 through 40-75 chaotic layers."""
+    g = golden("g8_network")
+    for bname in ("darknet_21", "darknet_53"):
+        wseed, xseed, cseed, px, bs = [int(v) for v in g[bname + "_meta"]]
+        eng, sd = make_engine(bname, wseed)
+        x = detrand.uniform(xseed, (bs, 3, px, px), -2.0, 2.0)
+        outs = eng.forward(torch.from_numpy(x).to(dev()), training=True)
+        for k, o in enumerate(outs):
+            ref = torch.from_numpy(g[f"{bname}_out{k}"])
+            assert rel(o.cpu(), ref) < 0.35, (bname, k, rel(o.cpu(), ref))
+        # first-layer running statistics are exact to bf16 input rounding
+        np.testing.assert_allclose(eng.buffers["backbone.bn1.running_mean"].cpu().numpy(), g[bname + "_rm_stem"], rtol=2e-2, atol=2e-3)
+        np.testing.assert_allclose(eng.buffers["backbone.bn1.running_var"].cpu().numpy(), g[bname + "_rv_stem"], rtol=2e-2, atol=2e-3)
+        ev = eng.forward(torch.from_numpy(x).to(dev()), training=False)
+        for k, o in enumerate(ev):
+            ref = torch.from_numpy(g[f"{bname}_evalout{k}"])
+            assert rel(o.cpu(), ref) < 0.35, (bname, "eval", k, rel(o.cpu(), ref))
+
+
+def test_yolohead_module_autograd_and_fused_step():
+    """drop-in modules: loss.backward() through YoloHead + YOLOForw == fused engine.train_step."""
+    from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
+    from object_detectors_amd.yolo.nets.yolohead import YoloHead
+    from tests.helpers import synth_targets
+    cfg = {"backbone": {"backbone_name": "darknet_21", "backbone_pretrained": ""}, "dataset": {"anchors": ANCHORS},
+           "yolo": {"classes": 80}}
+    model = YoloHead(cfg).to(dev())
+    crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=128).to(dev())
+    x = torch.from_numpy(detrand.uniform(5, (2, 3, 128, 128), -2, 2)).to(dev())
+    tg = [{"bbox": torch.from_numpy(b).to(dev()), "category_id": torch.from_numpy(l).to(dev())}
+          for b, l in synth_targets(77, (5, 3), 80)]
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    out = model(x)
+    assert [tuple(o.shape) for o in out] == [(2, 255, 4, 4), (2, 255, 8, 8), (2, 255, 16, 16)]
+    loss, sub, stats = crit(out, tg)
+    loss.backward()
+    g_auto = model.engine.flat_g.clone()
+    assert all(p.grad is not None for p in model.parameters())
+    out12 = model.engine.train_step(x, tg, crit)
+    g_fused = model.engine.flat_g
+    np.testing.assert_allclose(out12[0].item(), loss.item(), rtol=1e-5)
+    # fused path rounds the head gradient to bf16 once more: same direction
+    cos = float((g_auto.double() * g_fused.double()).sum() / (g_auto.double().norm() * g_fused.double().norm()))
+    assert cos > 0.999
+    # the criterion on the engine's NHWC views equals the oracle on the same logits
+    heads = [o.detach().cpu().numpy() for o in model.engine.forward(x, training=True)]
+    spec = yo.YoloSpec(ANCHORS, 80, 128)
+    ref = yo.yolo_loss(spec, heads, synth_targets(77, (5, 3), 80), want_grad=False)
+    np.testing.assert_allclose(out12[0].item(), ref["loss"], rtol=2e-3)
+    # reference-format checkpoint round trip
+    sd = model.state_dict()
+    m2 = YoloHead(cfg).to(dev())
+    m2.load_state_dict({"module." + k: v for k, v in sd.items()})
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k].cpu()), k
+    assert list(sd.keys()) == [k for k, _ in net_oracle.state_keys("darknet_21")]
