@@ -179,7 +179,8 @@ typedef struct {
  *   (fp32, row pitch 2*cout_pad, plain stores, deterministic) for training BatchNorm. */
 int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias,
                       void* y, int out_f32, float* stats, int32_t cout_pad, void* stream);
-/* number of rows of the `stats` partial buffer [rows][2][cout_pad] the forward writes (one per pixel tile) */
+/* number of rows of the `stats` partial buffer [rows][2][cout_pad] the forward writes (one per pixel tile);
+ * allocate rows+64: bn_finalize uses the 64 spare rows as scratch for its two-stage reduction */
 int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad);
 /* Darknet stem (darknet.py:41, 3->32 3x3): NCHW fp32 image -> im2col rows [n*h*w][32] bf16
  * (k=(kh*3+kw)*3+c, 27 valid) consumed by conv_fwd / conv_wgrad as a 1x1 convolution with cin=32. */

@@ -94,6 +94,7 @@ def lib():
             raise Mi355detError(
                 f"{LIB_PATH} not found: build it with `python -m object_detectors_amd.build` "
                 "(there is no CPU/PyTorch fallback for the hot path)")
+        import torch  # noqa: F401  (load torch's bundled HIP runtime first so both sides share ONE libamdhip64)
         L = C.CDLL(LIB_PATH)
         missing = []
         for name, (res, args) in PROTOTYPES.items():

@@ -10,6 +10,14 @@ namespace {
 struct bf8 {
   float v[8];
 };
+__device__ __forceinline__ bf8 unpack8(const uint4 u) {
+  bf8 r;
+  r.v[0] = bf2f((bf16_t)(u.x & 0xFFFF)); r.v[1] = bf2f((bf16_t)(u.x >> 16));
+  r.v[2] = bf2f((bf16_t)(u.y & 0xFFFF)); r.v[3] = bf2f((bf16_t)(u.y >> 16));
+  r.v[4] = bf2f((bf16_t)(u.z & 0xFFFF)); r.v[5] = bf2f((bf16_t)(u.z >> 16));
+  r.v[6] = bf2f((bf16_t)(u.w & 0xFFFF)); r.v[7] = bf2f((bf16_t)(u.w >> 16));
+  return r;
+}
 __device__ __forceinline__ bf8 ld8(const bf16_t* p) {
   const uint4 u = *(const uint4*)p;
   bf8 r;
@@ -64,6 +72,32 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
       const double unb = count > 1 ? var * count / (count - 1) : var;
       rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
     }
+  }
+}
+
+// stage 1 of the statistics reduction for layers with many pixel tiles: [rows][2][c_pad] -> [chunks][2][c_pad]
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ partial, int rows, int c_pad, int chunk,
+                                                         float* __restrict__ out) {
+  __shared__ float sh[8][32][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+  float s1 = 0.f, s2 = 0.f;
+  if (ch < c_pad)
+    for (int r = r0 + rl; r < r1; r += 8) {
+      s1 += partial[(size_t)r * 2 * c_pad + ch];
+      s2 += partial[(size_t)r * 2 * c_pad + c_pad + ch];
+    }
+  sh[rl][cl][0] = s1;
+  sh[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c_pad) {
+    for (int r = 1; r < 8; ++r) {
+      s1 += sh[r][cl][0];
+      s2 += sh[r][cl][1];
+    }
+    out[(size_t)blockIdx.y * 2 * c_pad + ch] = s1;
+    out[(size_t)blockIdx.y * 2 * c_pad + c_pad + ch] = s2;
   }
 }
 
@@ -128,20 +162,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     a2[k] = 0.f;
   }
   const long long mA = (long long)blockIdx.x * pix_per_block, mB = min(pixels, mA + pix_per_block);
-  for (long long m = mA + pl; m < mB; m += npl) {
-    bf8 g = ld8(g1 + m * g1_ld + c0);
-    if (g2) {
-      const bf8 h = ld8(g2 + m * g2_ld + c0);
+  for (long long m = mA + pl; m < mB; m += 4 * npl) {
+    uint4 gu[4], zu[4], hu[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) g.v[k] += h.v[k];
+    for (int u = 0; u < 4; ++u) {   // issue all loads first: 8-12 x 16 B in flight per lane
+      const long long mm = m + (long long)u * npl;
+      const bool ok = mm < mB;
+      gu[u] = ok ? *(const uint4*)(g1 + mm * g1_ld + c0) : make_uint4(0, 0, 0, 0);
+      zu[u] = ok ? *(const uint4*)(z + mm * z_ld + c0) : make_uint4(0, 0, 0, 0);
+      if (g2) hu[u] = ok ? *(const uint4*)(g2 + mm * g2_ld + c0) : make_uint4(0, 0, 0, 0);
     }
-    const bf8 zz = ld8(z + m * z_ld + c0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float y = zz.v[k] * sc[k] + sh[k];
-      const float dy = y > 0.f ? g.v[k] : g.v[k] * slope;
-      a1[k] += dy;
-      a2[k] += dy * ((zz.v[k] - mu[k]) * is[k]);
+    for (int u = 0; u < 4; ++u) {
+      bf8 g = unpack8(gu[u]);
+      if (g2) {
+        const bf8 h = unpack8(hu[u]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g.v[k] += h.v[k];
+      }
+      const bf8 zz = unpack8(zu[u]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float y = zz.v[k] * sc[k] + sh[k];
+        const float dy = y > 0.f ? g.v[k] : g.v[k] * slope;   // zero-filled tail lanes contribute dy = 0
+        a1[k] += dy;
+        a2[k] += dy * ((zz.v[k] - mu[k]) * is[k]);
+      }
     }
   }
 #pragma unroll
@@ -284,6 +330,14 @@ extern "C" {
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
+  if (rows > 256) {
+    // two stages (deterministic): 64 row-chunks reduced in parallel into the 64 spare rows behind the partials
+    const int chunks = 64, chunk = (rows + chunks - 1) / chunks;
+    float* scratch = const_cast<float*>(stats) + (size_t)rows * 2 * c_pad;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((c_pad + 31) / 32, chunks), dim3(256), 0, S(stream), stats, rows, c_pad, chunk, scratch);
+    stats = scratch;
+    rows = chunks;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale_shift);
   return check_launch("bn_finalize");
@@ -310,7 +364,7 @@ int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, in
   if (c <= 0 || c % 8 != 0 || groups > 256 || (groups & (groups - 1)) != 0)
     return fail(MI355DET_EINVAL, "%s: channels/8 must be a power of two <= 256 (got c=%lld)", "bn_act_bwd_reduce", c);
   const int npl = 256 / groups;
-  long long ppb = (long long)npl * 64;   // 64 pixels per pixel-lane
+  long long ppb = (long long)npl * 32;   // 32 pixels per pixel-lane
   long long blocks = (pixels + ppb - 1) / ppb;
   if (blocks > 8192) {
     ppb = (pixels + 8191) / 8192;

@@ -43,6 +43,7 @@ struct WgradParams {
   const bf16_t* zero;
   int M, Ho, Wo, H, W, ldx, lddy, Cin, Cout, stride, pad, ks, T, NP;   // NP = T*Cin
   int co_tiles, np_tiles, splits, chunk;                                // chunk = pixels per split (multiple of 64)
+  int step_q, step_r;                                                   // 64 = step_q*Wo + step_r
   FastDiv dWo, dHo, dCin;
 };
 
@@ -104,6 +105,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
   const bool dy_ok0 = dy_off[0] < p.Cout, dy_ok1 = dy_off[1] < p.Cout;
 
+  // each lane stages 4 fixed tile rows; their output pixels advance by 64 per k-step, so (n, ho, wo) is
+  // kept incrementally (one conditional wrap per axis) instead of two divisions per row per step
+  int r_n[4], r_ho[4], r_wo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned um = (unsigned)(mA + (wid * 4 + i) * 4 + lrow);
+    const unsigned q1 = fdiv(um, p.dWo);
+    r_wo[i] = (int)(um - q1 * p.Wo);
+    const unsigned n = fdiv(q1, p.dHo);
+    r_ho[i] = (int)(q1 - n * p.Ho);
+    r_n[i] = (int)n;
+  }
+
   auto stage = [&](int m_base, int buf) {
     char* sd = smem + buf * STAGE;
     char* sx = sd + WG_BKP * WG_ROWB;
@@ -118,16 +132,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       const bf16_t* sdy = (mv && (ph ? dy_ok1 : dy_ok0)) ? p.dy + (long long)m * p.lddy + (ph ? dy_off[1] : dy_off[0]) : p.zero;
       glds16(sdy, sd + instr * 1024);
       // X tile: gather the input pixel of tap(t) for output pixel m
-      const unsigned um = (unsigned)(mv ? m : 0);
-      const unsigned q1 = fdiv(um, p.dWo);
-      const int wo = (int)(um - q1 * p.Wo);
-      const unsigned n = fdiv(q1, p.dHo);
-      const int ho = (int)(q1 - n * p.Ho);
-      const int iy = ho * p.stride + (ph ? x_tapdy[1] : x_tapdy[0]);
-      const int ix = wo * p.stride + (ph ? x_tapdx[1] : x_tapdx[0]);
+      const int iy = r_ho[i] * p.stride + (ph ? x_tapdy[1] : x_tapdy[0]);
+      const int ix = r_wo[i] * p.stride + (ph ? x_tapdx[1] : x_tapdx[0]);
       const bool ok = mv && (ph ? x_ok[1] : x_ok[0]) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const bf16_t* sxp = ok ? p.x + ((long long)((int)n * p.H + iy) * p.W + ix) * p.ldx + (ph ? x_off[1] : x_off[0]) : p.zero;
+      const bf16_t* sxp = ok ? p.x + ((long long)(r_n[i] * p.H + iy) * p.W + ix) * p.ldx + (ph ? x_off[1] : x_off[0]) : p.zero;
       glds16(sxp, sx + instr * 1024);
+      // advance this row by 64 pixels
+      r_wo[i] += p.step_r;
+      r_ho[i] += p.step_q;
+      if (r_wo[i] >= p.Wo) {
+        r_wo[i] -= p.Wo;
+        r_ho[i] += 1;
+      }
+      while (r_ho[i] >= p.Ho) {
+        r_ho[i] -= p.Ho;
+        r_n[i] += 1;
+      }
     }
   };
 
@@ -247,16 +267,24 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   p.co_tiles = (p.Cout + WG_TILE - 1) / WG_TILE;
   p.np_tiles = (p.NP + WG_TILE - 1) / WG_TILE;
   const int tiles = p.co_tiles * p.np_tiles;
-  // split the pixel axis so that ~2 workgroups per CU are busy but every workgroup still reduces
-  // >= 4096 pixels (atomic bytes per MFMA flop stay small)
-  int splits = (512 + tiles - 1) / tiles;
-  const int max_splits = max(1, p.M / 4096);
-  splits = max(1, min(splits, max_splits));
+  // split the pixel axis: enough workgroups to fill 256 CUs x 2, bounded so that the fp32 atomic
+  // traffic (splits * |dW| * 4 B at ~1.3 TB/s chip-wide) stays below ~half of the MFMA time at ~1 PFLOP/s
+  // (or 10 us for small layers), and every workgroup still reduces >= 512 pixels.
+  const double flops = 2.0 * p.M * (double)p.Cout * p.NP;
+  const double out_bytes = 4.0 * p.Cout * (double)p.NP;
+  const double t_mfma = flops / 1.0e15;
+  const double budget = t_mfma * 0.5 > 10e-6 ? t_mfma * 0.5 : 10e-6;
+  int max_by_atomics = (int)(budget * 1.3e12 / out_bytes);
+  int splits = (768 + tiles - 1) / tiles;
+  splits = min(splits, max(1, max_by_atomics));
+  splits = max(1, min(splits, max(1, p.M / 512)));
   int chunk = (p.M + splits - 1) / splits;
   chunk = (chunk + WG_BKP - 1) / WG_BKP * WG_BKP;
   splits = (p.M + chunk - 1) / chunk;
   p.splits = splits;
   p.chunk = chunk;
+  p.step_q = WG_BKP / p.Wo;
+  p.step_r = WG_BKP % p.Wo;
   p.dWo = make_fastdiv((unsigned)p.Wo);
   p.dHo = make_fastdiv((unsigned)p.Ho);
   p.dCin = make_fastdiv((unsigned)p.Cin);

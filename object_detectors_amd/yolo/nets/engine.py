@@ -319,7 +319,7 @@ class Plan:
             z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
             rows = ops.conv_stats_rows(shp)
             cp = ops.cout_pad_of(shp.cout)
-            stats = torch.zeros((rows, 2, cp), device=dev, dtype=torch.float32) if training else None
+            stats = torch.zeros((rows + 64, 2, cp), device=dev, dtype=torch.float32) if training else None
             ss = torch.zeros(4 * shp.cout, device=dev, dtype=torch.float32)
             wf, wd = eng.packed[name]
             b = bn_name(name)
@@ -435,7 +435,11 @@ class Plan:
                 r = x.skips.pop(0)
                 self.bwd.append((L.mi355det_add_bf16, (g.ptr, g.ld, r.ptr, r.ld, x.c, x.pixels, g.ptr, g.ld, self.stream)))
 
+        self.bwd_marks = []      # (index into self.bwd after the layer's calls, lowest flat_g offset completed)
+        first_off = {name: o for name, o, _n, _s in eng.param_order}
         for rec in reversed(self.ops):
+            if rec["kind"] in ("out", "cbl"):
+                self._mark_name = rec["name"]
             if rec["kind"] == "out":
                 shp, shp_f, x, k, name = rec["shp"], rec["shp_f"], rec["x"], rec["k"], rec["name"]
                 _, wd = eng.packed[name]
@@ -470,6 +474,8 @@ class Plan:
                 if name != "backbone.conv1":
                     _, wd = eng.packed[name]
                     emit_dgrad(shp, _vp(self.dz), wd, x)
+            if rec["kind"] in ("out", "cbl"):
+                self.bwd_marks.append((len(self.bwd), first_off[rec["name"] + ".weight"]))
 
     # ------------------------------------------------------------------
     def _run(self, calls):

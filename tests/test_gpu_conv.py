@@ -61,14 +61,14 @@ def test_conv_fwd_dgrad_wgrad(case):
     y = torch.empty(n, shape.ho, shape.wo, cout, dtype=torch.bfloat16, device=dev())
     rows = ops.conv_stats_rows(shape)
     cp = ops.cout_pad_of(cout)
-    stats = torch.zeros(rows, 2, cp, device=dev())
+    stats = torch.zeros(rows + 64, 2, cp, device=dev())
     ops.conv_fwd(shape, xd, wf, y, stats=stats)
     got = y.float().permute(0, 3, 1, 2).cpu()
     tol = 2e-2 * y_ref.abs().max().item()
     assert (got - y_ref.detach()).abs().max().item() < tol
     # BN statistics are those of the STORED (bf16-rounded) tensor
-    s1 = stats[:, 0, :cout].sum(0).cpu()
-    s2 = stats[:, 1, :cout].sum(0).cpu()
+    s1 = stats[:rows, 0, :cout].sum(0).cpu()
+    s2 = stats[:rows, 1, :cout].sum(0).cpu()
     np.testing.assert_allclose(s1, got.sum((0, 2, 3)), rtol=1e-4, atol=1e-4 * got.abs().sum((0, 2, 3)).max().item())
     np.testing.assert_allclose(s2, (got ** 2).sum((0, 2, 3)), rtol=1e-4)
     # dgrad
