@@ -1,0 +1,84 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the data-parallel gradient path: bucket planning over the
+flat gradient buffer and averaged all-reduce woven into a backward call list."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plan_buckets_cover_buffer_once():
+    from object_detectors_amd.parallel import plan_buckets
+    # 10 layers of 1000 elements, backward order = decreasing offsets
+    marks = [(3 * (i + 1), 9000 - 1000 * i) for i in range(10)]
+    b = plan_buckets(marks, 10000, 2500)
+    covered = sorted((lo, hi) for _p, lo, hi in b)
+    assert covered[0][0] == 0 and covered[-1][1] == 10000
+    for (a0, a1), (b0, b1) in zip(covered, covered[1:]):
+        assert a1 == b0
+    # positions are non-decreasing in backward order and every bucket is complete when it fires
+    for pos, lo, hi in b:
+        done = [o for p, o in marks if p <= pos]
+        assert min(done) <= lo
+    # tiny bucket size: one bucket per layer; huge: a single bucket at the end
+    assert len(plan_buckets(marks, 10000, 1)) == 10
+    one = plan_buckets(marks, 10000, 10 ** 9)
+    assert one == [(marks[-1][0], 0, 10000)]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_detectors_amd.parallel import GradSync
+    from object_detectors_amd.yolo.nets.engine import comm_hook
+
+    class FakePlan:
+        pass
+    n_layers, per = 12, 777
+    flat = torch.zeros(n_layers * per)
+    plan = FakePlan()
+    order = []
+
+    def make_layer(i):
+        def f():
+            flat[i * per:(i + 1) * per] = float(rank + 1) * (i + 1)      # "wgrad" of layer i
+            order.append(i)
+            return 0
+        f.__name__ = f"layer{i}"
+        return f
+    plan.bwd = [(make_layer(i), ()) for i in reversed(range(n_layers))]
+    plan.bwd_marks = [(k + 1, (n_layers - 1 - k) * per) for k in range(n_layers)]
+    sync = GradSync(flat, bucket_mb=per * 4 * 3 / (1 << 20))          # ~3 layers per bucket
+    sync.install(plan)
+    hooks = sum(1 for fn, _a in plan.bwd if fn is comm_hook)
+    for fn, args in plan.bwd:
+        if fn is comm_hook:
+            args[0](*args[1:])
+        else:
+            fn(*args)
+    sync.wait()
+    expect = torch.cat([torch.full((per,), (1 + 2) / 2.0 * (i + 1)) for i in range(n_layers)])
+    ok = bool(torch.allclose(flat, expect)) and hooks >= 3 and order == list(reversed(range(n_layers)))
+    q.put((rank, ok, hooks))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _r, ok, _h in res), res
