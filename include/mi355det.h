@@ -35,6 +35,8 @@ extern "C" {
 #define MI355DET_MAX_ANCHORS 8
 
 const char* mi355det_last_error(void);
+int mi355det_debug_set(int key, int value);   /* bring-up / tuning knobs; key 0 = conv tile configuration */
+int mi355det_debug_ptr(int key, void* ptr);   /* key 0 = device buffer for the diagnostic (phase-stamp) conv build */
 int mi355det_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -179,6 +181,9 @@ typedef struct {
  *   (fp32, row pitch 2*cout_pad, plain stores, deterministic) for training BatchNorm. */
 int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias,
                       void* y, int out_f32, float* stats, int32_t cout_pad, void* stream);
+/* plan-build helper (synchronises; never part of the step): while the mode is on, mi355det_conv_fwd / _dgrad time
+ * their candidate tile configurations on the caller's buffers and remember the fastest per shape. */
+int mi355det_conv_autotune_mode(int on);
 /* number of rows of the `stats` partial buffer [rows][2][cout_pad] the forward writes (one per pixel tile);
  * allocate rows+64: bn_finalize uses the 64 spare rows as scratch for its two-stage reduction */
 int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad);
@@ -191,10 +196,16 @@ int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int3
 int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx,
                         const void* residual, int32_t residual_ld, void* stream);
 
-/* Weight gradient: dw[cout][k*k*cin] fp32 += x^T dy (split over pixels, fp32 atomics; caller zeroes).
+/* Weight gradient: dw[cout][k*k*cin] fp32 += x^T dy.  Split over the pixel axis; partial 128x128 tiles go to
+ * `workspace` with plain stores and are summed into dw in a fixed order (deterministic, no atomics).
  * dbias != NULL: dbias[cout] += sum_pixels dy. */
+size_t mi355det_conv_wgrad_workspace(const mi355det_conv_shape* s);
+/* plan-build helper (synchronises; not part of the step): times the candidate split counts for this shape on the
+ * caller's buffers and remembers the fastest.  Returns the chosen split count; dw is clobbered. */
+int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw,
-                        float* dbias, void* stream);
+                        float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* fp32 master weights, torch OIHW [cout][cin][k][k] or engine OHWI [cout][k][k][cin] (w_is_ohwi) -> bf16 fwd pack [cout_pad][k][k][cin] and
  * dgrad pack (stride 1: [cin_pad][k][k][cout] taps flipped; stride 2: 4 parity classes). */

@@ -41,6 +41,8 @@ PROTOTYPES = {
     # name: (restype, argtypes)
     "mi355det_last_error": (C.c_char_p, []),
     "mi355det_version": (C.c_int, []),
+    "mi355det_debug_set": (C.c_int, [C.c_int, C.c_int]),
+    "mi355det_debug_ptr": (C.c_int, [C.c_int, vp]),
     "mi355det_bbox_iou": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
     "mi355det_yolo_assign": (C.c_int, [P(YoloGeom), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "mi355det_yolo_loss_workspace": (sz, [i32, i64]),
@@ -61,10 +63,13 @@ PROTOTYPES = {
     "mi355det_retina_cls_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
     "mi355det_conv_fwd": (C.c_int, [P(ConvShape), vp, vp, vp, vp, C.c_int, vp, i32, vp]),
     "mi355det_conv_dgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp]),
-    "mi355det_conv_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, vp]),
+    "mi355det_conv_wgrad_workspace": (sz, [P(ConvShape)]),
+    "mi355det_conv_wgrad_autotune": (C.c_int, [P(ConvShape), vp, vp, vp, vp, sz, vp]),
+    "mi355det_conv_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, vp, sz, vp]),
     "mi355det_dgrad_pack_elems": (sz, [P(ConvShape)]),
     "mi355det_pack_weights": (C.c_int, [P(ConvShape), vp, C.c_int, vp, i32, vp, vp]),
     "mi355det_unpack_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp]),
+    "mi355det_conv_autotune_mode": (C.c_int, [C.c_int]),
     "mi355det_conv_stats_rows": (C.c_int, [P(ConvShape), i32]),
     "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),

@@ -16,6 +16,8 @@
 //   2 workgroups per CU overlap each other's waits.
 #include "common.h"
 
+#include <unordered_map>
+
 using namespace mi355;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -23,6 +25,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
 
 #define MAX_TAPS 9
+
+// division by a launch-invariant divisor without the ~40-instruction integer divide (n < 2^31)
+struct FastDiv {
+  unsigned mul, shift;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) { return (__umulhi(f.mul, n) + n) >> f.shift; }
 
 struct IgemmParams {
   const bf16_t* x;       // input activations (fwd: x, dgrad: dy)
@@ -38,6 +54,10 @@ struct IgemmParams {
   int Cout, CoutPad, ldres;
   int T;
   int dy[MAX_TAPS], dx[MAX_TAPS];
+  FastDiv dMW, dMH;
+  int tap_pad;           // elements: -min over taps of (dy*Win+dx)*ldin, >= 0 (keeps scalar tap offsets non-negative)
+  unsigned long long dy_pack, dx_pack;   // 4-bit fields (value+2) per tap: the tap table in two scalar registers
+  unsigned long long* dbg;   // diagnostic build only (PROF): per-wave phase cycle sums
 };
 
 enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3 };
@@ -49,25 +69,57 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) 
                                    (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor: per-lane 32-bit byte offset + SCALAR offset (the tap / k-step part of the
+// address costs no vector instruction); a lane whose voffset is out of range gets zeros written to LDS, which is
+// exactly the convolution's zero padding.
+__device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t rsrc, void* lds_dst_uniform, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, voffset, soffset, 0, 0);
+}
+#define OOB_VOFF ((int)0x80000000)
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane: 4 VALU+DPP ops, no LDS traffic
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 template <int BK>
 __device__ __forceinline__ int swz(int row) {
   return BK == 64 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3);
 }
 
-// WM x WN waves; each wave computes 64 pixels x (TN*16) channels.
-template <int WM, int WN, int TN, int BK, int EPI>
-__global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams p) {
+// WM x WN waves; each wave computes 64 pixels x (TN*16) channels.  NST-deep LDS ring: the LDS-DMA of
+// k-steps s+1 .. s+NST-1 stays in flight (counted vmcnt, raw s_barrier) while k-step s runs on the MFMAs —
+// with ~1.5-2 us of loaded-memory latency the bytes in flight per CU, not the MFMA rate, set the speed.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#define STAMP(v) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+
+template <int WM, int WN, int TM, int TN, int BK, int NST, int EPI, bool PROF = false, bool ILV = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0, t_begin = 0, t_loop = 0;
+  STAMP(t_begin);
   constexpr int NT = WM * WN * 64;
   constexpr int NW = WM * WN;
-  constexpr int BM = WM * 64, BN = WN * TN * 16;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int ROWB = BK * 2;               // bytes per LDS row
   constexpr int R = 1024 / ROWB;             // rows per LDS-DMA wave instruction
   constexpr int CPR = BK / 8;                // 16-B chunks per row
   constexpr int A_INSTR = BM / R, B_INSTR = BN / R;
   constexpr int A_PER = (A_INSTR + NW - 1) / NW, B_PER = (B_INSTR + NW - 1) / NW;
+  constexpr int PER = A_PER + B_PER;         // LDS-DMA instructions per wave per stage (same for every wave)
   constexpr int STAGE = (BM + BN) * ROWB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages; reused by the epilogue
-  __shared__ int s_toff[MAX_TAPS];
+  constexpr int D = NST - 1;                 // prefetch distance
+  static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
+  // ALL LDS lives in this one array (a second __shared__ object makes hipcc drain vmcnt before ds_reads)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_toff = (int*)(smem + NST * STAGE);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,106 +137,195 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
   const int mt = bid / ntn, nt = bid - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  if (tid < p.T) s_toff[tid] = (p.dy[tid] * p.Win + p.dx[tid]) * p.ldin;
+  // scalar (per-tap) byte offsets, made non-negative by moving tap_pad into the descriptor base
+  if (tid == 0) {
+#pragma unroll
+    for (int t = 0; t < MAX_TAPS; ++t)
+      if (t < p.T) s_toff[t] = ((p.dy[t] * p.Win + p.dx[t]) * p.ldin + p.tap_pad) * 2;
+  }
 
-  // ---- per-lane source descriptors for the rows this lane stages
+  unsigned long long t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0;
+  STAMP(t_p1);
+  // ---- buffer descriptors (wave-uniform): activations relative to the first image this tile touches
+  const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
+  const int Ktot = p.T * p.Cin;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+
+  // ---- per-lane byte offsets of the rows this lane stages
   const int lrow = lane / CPR, cpos = lane % CPR;
-  long long a_base[A_PER];
+  int a_voff[A_PER];
   unsigned a_valid[A_PER];
-  int a_chunk[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int instr = wid * A_PER + i;
     const int row = instr * R + lrow;
     const int m = m0 + row;
-    a_chunk[i] = (cpos ^ swz<BK>(row)) * 8;
     unsigned vm = 0;
-    long long base = 0;
-    if (instr < A_INSTR && m < p.M) {
-      const int xx = m % p.MW, t1 = m / p.MW, yy = t1 % p.MH, n = t1 / p.MH;
+    int voff = OOB_VOFF;
+    if (m < p.M) {
+      const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+      const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
       const int iy0 = yy * p.sin, ix0 = xx * p.sin;
-      base = ((long long)(n * p.Hin + iy0) * p.Win + ix0) * p.ldin;
-      for (int t = 0; t < p.T; ++t) {
-        const int iy = iy0 + p.dy[t], ix = ix0 + p.dx[t];
-        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) vm |= 1u << t;
+      voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ swz<BK>(row)) * 8) * 2;
+#pragma unroll
+      for (int t = 0; t < MAX_TAPS; ++t) {   // tap table unpacked from two scalar registers (no memory access)
+        const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
+        const bool ok = t < p.T && (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
+        vm |= ok ? (1u << t) : 0u;
       }
     }
-    a_base[i] = base;
+    a_voff[i] = voff;
     a_valid[i] = vm;
   }
-  const int Ktot = p.T * p.Cin;
-  const bf16_t* b_ptr[B_PER];
+  if (PROF) asm volatile("s_nop 0" ::"v"(a_voff[0]), "v"(a_valid[A_PER - 1]));
+  STAMP(t_p2);
+  int b_voff[B_PER], b_instr[B_PER];
 #pragma unroll
   for (int i = 0; i < B_PER; ++i) {
-    const int instr = wid * B_PER + i;
+    // when the B tile has fewer LDS-DMA pieces than waves, several waves write the same piece (same bytes)
+    const int instr = (wid * B_PER + i) % B_INSTR;
     const int row = instr * R + lrow;
-    b_ptr[i] = p.w + (long long)(n0 + (instr < B_INSTR ? row : 0)) * Ktot + (cpos ^ swz<BK>(row)) * 8;
+    b_instr[i] = instr;
+    b_voff[i] = (row * Ktot + (cpos ^ swz<BK>(row)) * 8) * 2;
   }
-  __syncthreads();
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): s_toff written
+  STAMP(t_p3);
+  __builtin_amdgcn_s_barrier();
+  STAMP(t_p4);
 
   const int ksteps = Ktot / BK;
   const int cin_steps = p.Cin / BK;
+  int pf_t = 0, pf_c = 0;   // (tap, cin-step) of the next stage to prefetch
 
   auto stage = [&](int s, int buf) {
-    const int t = s / cin_steps, c0 = (s - t * cin_steps) * BK;
-    const int toff = s_toff[t] + c0;
+    const int soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
     char* sa = smem + buf * STAGE;
     char* sb = sa + BM * ROWB;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int instr = wid * A_PER + i;
-      if (A_INSTR % NW == 0 || instr < A_INSTR) {
-        const bf16_t* src = ((a_valid[i] >> t) & 1u) ? p.x + a_base[i] + toff + a_chunk[i] : p.zero + cpos * 8;
-        glds16(src, sa + instr * 1024);
-      }
+      bufld16(rsrc_x, sa + instr * 1024, ((a_valid[i] >> pf_t) & 1u) ? a_voff[i] : OOB_VOFF, soff);
     }
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int instr = wid * B_PER + i;
-      if (B_INSTR % NW == 0 || instr < B_INSTR) glds16(b_ptr[i] + (long long)s * BK, sb + instr * 1024);
+    for (int i = 0; i < B_PER; ++i) bufld16(rsrc_w, sb + b_instr[i] * 1024, b_voff[i], s * (BK * 2));
+    if (++pf_c == cin_steps) {
+      pf_c = 0;
+      ++pf_t;
     }
   };
 
-  f32x4_t acc[TN][4];
+  // one LDS-DMA piece of the stage being prefetched (q < A_PER: activation rows, else weight rows)
+  auto issue_piece = [&](int q, int s, int soff, int tap, int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + BM * ROWB;
+    if (q < A_PER) {
+      const int instr = wid * A_PER + q;
+      bufld16(rsrc_x, sa + instr * 1024, ((a_valid[q] >> tap) & 1u) ? a_voff[q] : OOB_VOFF, soff);
+    } else {
+      bufld16(rsrc_w, sb + b_instr[q - A_PER] * 1024, b_voff[q - A_PER], s * (BK * 2));
+    }
+  };
+
+  f32x4_t acc[TN][TM];
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < ksteps) stage(s, s);
 
   const int fr = lane & 15, fq = lane >> 4;
+  int buf = 0;
+  STAMP(t_loop);
   for (int s = 0; s < ksteps; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < ksteps) stage(s + 1, buf ^ 1);
+    STAMP(t_a);
+    // stage s has landed once at most min(D-1, ksteps-1-s) younger stages of THIS wave are still in flight
+    const int younger = min(D - 1, ksteps - 1 - s);
+    if (D >= 1 && younger >= D - 1) wait_vmcnt<(D - 1 > 0 ? D - 1 : 0) * PER>();
+    else if (D >= 3 && younger == D - 2) wait_vmcnt<(D - 2 > 0 ? D - 2 : 0) * PER>();
+    else if (D >= 4 && younger == D - 3) wait_vmcnt<(D - 3 > 0 ? D - 3 : 0) * PER>();
+    else if (D >= 5 && younger == D - 4) wait_vmcnt<(D - 4 > 0 ? D - 4 : 0) * PER>();
+    else if (D >= 6 && younger == D - 5) wait_vmcnt<(D - 5 > 0 ? D - 5 : 0) * PER>();
+    else wait_vmcnt<0>();
+    STAMP(t_b);
+    __builtin_amdgcn_s_barrier();             // everyone's pieces of stage s landed; everyone left buffer (s-1)%NST
+    STAMP(t_c);
+    const bool pf = s + D < ksteps;
+    const int pbuf = buf == 0 ? NST - 1 : buf - 1;
+    int il_soff = 0, il_tap = 0;
+    if (!ILV) {
+      if (pf) stage(s + D, pbuf);
+    } else if (pf) {
+      il_tap = pf_t;
+      il_soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
+      if (++pf_c == cin_steps) {
+        pf_c = 0;
+        ++pf_t;
+      }
+    }
+    STAMP(t_d);
     const char* sa = smem + buf * STAGE;
     const char* sb = sa + BM * ROWB;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8_t wf[TN], af[4];
+      bf16x8_t wf[TN], af[TM];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn * (TN * 16) + i * 16 + fr;
         wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = wm * 64 + j * 16 + fr;
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm * (TM * 16) + j * 16 + fr;
         af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
+      constexpr int NMF = TN * TM * (BK / 32);            // MFMAs per k-step per wave
+      constexpr int G = NMF / PER > 0 ? NMF / PER : 1;     // MFMAs between two LDS-DMA pieces
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          if (ILV) {
+            // spread the next stage's LDS-DMA pieces between the MFMAs: a piece costs ~100+ issue cycles, which
+            // then overlap with this wave's own MFMAs still running in the matrix pipe
+            const int cnt = ks * TN * TM + i * TM + j + 1;
+            if (cnt % G == 0 && cnt / G - 1 < PER) {
+              if (pf) issue_piece(cnt / G - 1, s + D, il_soff, il_tap, pbuf);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    if (PROF) {
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[TN - 1][TM - 1][3]));
+      STAMP(t_e);
+      c_wait += t_b - t_a;
+      c_bar += t_c - t_b;
+      c_issue += t_d - t_c;
+      c_comp += t_e - t_d;
+    }
   }
+  if (PROF) {
+    STAMP(t_e);
+    if (lane == 0 && p.dbg) {
+      unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wid) * 8;
+      d[0] = c_wait; d[1] = c_bar; d[2] = c_issue; d[3] = c_comp; d[4] = t_loop - t_begin; d[5] = t_e - t_loop;
+      d[6] = ((t_p1 - t_begin) << 32) | (t_p2 - t_p1);
+      d[7] = ((t_p3 - t_p2) << 32) | (t_p4 - t_p3);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
 
   // ---- epilogue: lane holds channels co = n0 + wn*TN*16 + i*16 + fq*4 + r (r=0..3) of pixel
-  //      m = m0 + wm*64 + j*16 + fr
+  //      m = m0 + wm*TM*16 + j*16 + fr
   if (EPI == EPI_STATS) {
     float* sred = (float*)smem;   // [WM][BN][2]
 #pragma unroll
@@ -193,17 +334,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
       for (int r = 0; r < 4; ++r) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TM; ++j) {
           // statistics of the STORED (bf16-rounded) tensor: the BN backward formulas then hold exactly
           const float v = bf2f(f2bf(acc[i][j][r]));
           s1 += v;
           s2 += v * v;
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s1 += __shfl_xor(s1, o, 64);
-          s2 += __shfl_xor(s2, o, 64);
-        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
         if (fr == 0) {
           const int c = wn * (TN * 16) + i * 16 + fq * 4 + r;
           sred[(wm * BN + c) * 2 + 0] = s1;
@@ -225,10 +363,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void igemm_kernel(const IgemmParams
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + fr;
+  for (int j = 0; j < TM; ++j) {
+    const int m = m0 + wm * (TM * 16) + j * 16 + fr;
     if (m >= p.M) continue;
-    const int xx = m % p.MW, t1 = m / p.MW, yy = t1 % p.MH, n = t1 / p.MH;
+    const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+    const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
     const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
     if (oy >= p.Hout || ox >= p.Wout) continue;
     const long long pix = (long long)(n * p.Hout + oy) * p.Wout + ox;
@@ -351,12 +490,16 @@ int ensure_zero_page() {
   return 0;
 }
 
-template <int WM, int WN, int TN, int BK, int EPI>
-int launch_cfg(const IgemmParams& p, hipStream_t st) {
-  constexpr int BM = WM * 64, BN = WN * TN * 16;
-  constexpr int lds = 2 * (BM + BN) * BK * 2;
+unsigned long long* g_dbg = nullptr;
+
+template <int WM, int WN, int TM, int TN, int BK, int NST, int EPI, bool PROF = false, bool ILV = false>
+int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
+  IgemmParams p = p_in;
+  p.dbg = PROF ? g_dbg : nullptr;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int lds = NST * (BM + BN) * BK * 2 + 64;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
-  auto k = igemm_kernel<WM, WN, TN, BK, EPI>;
+  auto k = igemm_kernel<WM, WN, TM, TN, BK, NST, EPI, PROF, ILV>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -366,14 +509,96 @@ int launch_cfg(const IgemmParams& p, hipStream_t st) {
   return check_launch("igemm");
 }
 
+int g_tune = 0;   // bring-up knob (mi355det_debug_set(0, v)): forces a tile configuration
+std::unordered_map<unsigned long long, int> g_igemm_tuned;   // shape key -> configuration found by mi355det_conv_autotune
+
+unsigned long long igemm_key(const IgemmParams& p, int epi) {
+  unsigned long long k = (unsigned long long)p.M;
+  k = k * 4099 + p.CoutPad;
+  k = k * 4099 + p.Cin;
+  k = k * 31 + p.T;
+  k = k * 7 + p.sin * 2 + p.so;
+  k = k * 5 + epi;
+  return k;
+}
+
+// tile configurations for Cout % 128 == 0 and Cin % 64 == 0 (pixels x channels x k-step, ring depth):
+//   1: 128x128x64 x2, 4 waves of 64x64, 2 workgroups/CU        2: 256x128x32 x2, 4 waves of 128x64, 48 KB
+//   3: 256x256x64 x2, 8 waves of 128x64, 1 workgroup/CU        4: 128x128x32 x3, 4 waves of 64x64, 3 workgroups/CU
+template <int EPI>
+int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
+  switch (cfg) {
+    case 2: return launch_cfg<2, 2, 8, 4, 32, 2, EPI>(p, st);
+    case 3: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 64, 2, EPI>(p, st); break;
+    case 4: return launch_cfg<2, 2, 4, 4, 32, 3, EPI>(p, st);
+    case 99: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, true>(p, st); break;   // phase-stamp diagnostic build
+    default: break;
+  }
+  return launch_cfg<2, 2, 4, 4, 64, 2, EPI>(p, st);
+}
+
 template <int EPI>
 int launch_igemm(const IgemmParams& p, hipStream_t st) {
   if (p.Cin % 32 != 0) return fail(MI355DET_EINVAL, "%s: Cin must be a multiple of 32 (got %lld)", "conv", p.Cin);
   const bool k64 = p.Cin % 64 == 0;
-  if (p.CoutPad % 128 == 0) return k64 ? launch_cfg<2, 2, 4, 64, EPI>(p, st) : launch_cfg<2, 2, 4, 32, EPI>(p, st);
-  if (p.CoutPad % 64 == 0) return k64 ? launch_cfg<4, 1, 4, 64, EPI>(p, st) : launch_cfg<4, 1, 4, 32, EPI>(p, st);
-  if (p.CoutPad % 32 == 0) return k64 ? launch_cfg<4, 1, 2, 64, EPI>(p, st) : launch_cfg<4, 1, 2, 32, EPI>(p, st);
+  if (p.CoutPad % 128 == 0 && k64) {
+    int cfg = 1;
+    auto it = g_igemm_tuned.find(igemm_key(p, EPI));
+    if (it != g_igemm_tuned.end()) cfg = it->second;
+    if (g_tune) cfg = g_tune;
+    return run_cfg<EPI>(cfg, p, st);
+  }
+  if (p.CoutPad % 128 == 0) return launch_cfg<2, 2, 4, 4, 32, 3, EPI>(p, st);
+  if (p.CoutPad % 64 == 0) return k64 ? launch_cfg<4, 1, 4, 4, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 4, 32, 3, EPI>(p, st);
+  if (p.CoutPad % 32 == 0) return k64 ? launch_cfg<4, 1, 4, 2, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 2, 32, 4, EPI>(p, st);
   return fail(MI355DET_EINVAL, "%s: padded Cout must be a multiple of 32 (got %lld)", "conv", p.CoutPad);
+}
+
+// plan-build helper: time the candidate configurations of one launch and remember the fastest
+template <int EPI>
+int autotune_igemm(const IgemmParams& p, hipStream_t st) {
+  if (!(p.CoutPad % 128 == 0 && p.Cin % 64 == 0)) return 0;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
+  int best = 1;
+  float best_ms = 1e30f;
+  for (int cfg = 1; cfg <= 4; ++cfg) {
+    if (cfg == 3 && p.CoutPad % 256 != 0) continue;
+    int e = run_cfg<EPI>(cfg, p, st);
+    if (e) return e;
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < 3; ++r) (void)run_cfg<EPI>(cfg, p, st);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best_ms) {
+      best_ms = ms;
+      best = cfg;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  g_igemm_tuned[igemm_key(p, EPI)] = best;
+  return best;
+}
+
+bool g_autotune_mode = false;   // set by mi355det_conv_autotune around a regular entry-point call
+
+template <int EPI>
+int dispatch_igemm(const IgemmParams& p, hipStream_t st) {
+  return g_autotune_mode ? autotune_igemm<EPI>(p, st) : launch_igemm<EPI>(p, st);
+}
+
+void set_tap_pad(IgemmParams& p) {
+  int mn = 0;
+  p.dy_pack = p.dx_pack = 0;
+  for (int t = 0; t < p.T; ++t) {
+    mn = min(mn, (p.dy[t] * p.Win + p.dx[t]) * p.ldin);
+    p.dy_pack |= (unsigned long long)(p.dy[t] + 2) << (4 * t);
+    p.dx_pack |= (unsigned long long)(p.dx[t] + 2) << (4 * t);
+  }
+  p.tap_pad = -mn;
 }
 
 int check_shape(const mi355det_conv_shape* s, const char* what) {
@@ -387,7 +612,8 @@ int check_shape(const mi355det_conv_shape* s, const char* what) {
 }
 
 int grid_m_rows(const mi355det_conv_shape* s, int cout_pad) {
-  const int bm = cout_pad % 128 == 0 ? 128 : 256;
+  (void)cout_pad;
+  const int bm = 128;   // upper bound on the number of pixel tiles of any configuration
   const long long M = (long long)s->n * s->ho * s->wo;
   return (int)((M + bm - 1) / bm);
 }
@@ -395,6 +621,23 @@ int grid_m_rows(const mi355det_conv_shape* s, int cout_pad) {
 }  // namespace
 
 extern "C" {
+
+int mi355det_debug_set(int key, int value) {
+  if (key == 0) g_tune = value;
+  return 0;
+}
+
+// plan-build helper (synchronises; never part of the step): the next conv_fwd / conv_dgrad calls made while the mode
+// is on time their candidate tile configurations and remember the fastest per shape.
+int mi355det_conv_autotune_mode(int on) {
+  g_autotune_mode = on != 0;
+  return 0;
+}
+
+int mi355det_debug_ptr(int key, void* ptr) {
+  if (key == 0) g_dbg = (unsigned long long*)ptr;
+  return 0;
+}
 
 int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad) {
   if (!s) return 0;
@@ -425,9 +668,11 @@ int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w
       p.dy[kh * s->ksize + kw] = kh - s->pad;
       p.dx[kh * s->ksize + kw] = kw - s->pad;
     }
-  if (out_f32) return launch_igemm<EPI_F32>(p, S(stream));
-  if (stats) return launch_igemm<EPI_STATS>(p, S(stream));
-  return launch_igemm<EPI_PLAIN>(p, S(stream));
+  p.dMW = make_fastdiv((unsigned)p.MW);
+  p.dMH = make_fastdiv((unsigned)p.MH);
+  set_tap_pad(p);
+  const int r = out_f32 ? dispatch_igemm<EPI_F32>(p, S(stream)) : stats ? dispatch_igemm<EPI_STATS>(p, S(stream)) : dispatch_igemm<EPI_PLAIN>(p, S(stream));
+  return r < 0 ? r : 0;
 }
 
 // dgrad tap lists.  stride 1: dx[y,x] = sum_{kh,kw} dy[y+p-kh, x+p-kw] * w[kh,kw]  -> tap j=(kh,kw): d = p-kh.
@@ -524,8 +769,11 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
     p.Hin = s->ho; p.Win = s->wo; p.ldin = s->out_ld; p.Cin = s->cout; p.sin = 1;
     p.Hout = s->h; p.Wout = s->w; p.ldout = s->in_ld;
     p.Cout = s->cin; p.CoutPad = cin_pad;
-    int e = residual ? launch_igemm<EPI_RES>(p, S(stream)) : launch_igemm<EPI_PLAIN>(p, S(stream));
-    if (e) return e;
+    p.dMW = make_fastdiv((unsigned)p.MW);
+    p.dMH = make_fastdiv((unsigned)p.MH);
+    set_tap_pad(p);
+    int e = residual ? dispatch_igemm<EPI_RES>(p, S(stream)) : dispatch_igemm<EPI_PLAIN>(p, S(stream));
+    if (e < 0) return e;
     wp += (long long)cin_pad * p.T * s->cout;
   }
   return 0;

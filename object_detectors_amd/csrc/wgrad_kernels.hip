@@ -11,6 +11,8 @@
 // segment), sized so atomic bytes stay far below the MFMA time (wgrad).
 #include "common.h"
 
+#include <unordered_map>
+
 using namespace mi355;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -39,7 +41,8 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) {
 struct WgradParams {
   const bf16_t* x;      // [n,h,w,cin] pitch ldx
   const bf16_t* dy;     // [n,ho,wo,cout] pitch lddy
-  float* dw;            // [cout][T*cin] fp32, accumulated atomically
+  float* dw;            // [cout][T*cin] fp32 (+=)
+  float* slab;          // split-K partial tiles [split][tile][128*128] fp32, or nullptr (single split: direct +=)
   const bf16_t* zero;
   int M, Ho, Wo, H, W, ldx, lddy, Cin, Cout, stride, pad, ks, T, NP;   // NP = T*Cin
   int co_tiles, np_tiles, splits, chunk;                                // chunk = pixels per split (multiple of 64)
@@ -207,6 +210,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
   // D[row = co][col = n']: lane holds rows fq*4+r, column fr
   const int fr = lane & 15, fq = lane >> 4;
+  if (p.slab) {
+    // split-K: plain stores of the partial tile (6 TB/s class) instead of fp32 atomics (1.3 TB/s class, contended);
+    // wgrad_reduce_kernel adds the slabs into dW in a fixed order (deterministic)
+    float* dst = p.slab + ((size_t)split * tiles + tile) * (WG_TILE * WG_TILE);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dst[(wr * 64 + i * 16 + fq * 4 + r) * WG_TILE + wc * 64 + j * 16 + fr] = acc[i][j][r];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -216,8 +232,42 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int np = np0 + wc * 64 + j * 16 + fr;
-        if (np < p.NP) atomicAdd(p.dw + (long long)co * p.NP + np, acc[i][j][r]);
+        if (np < p.NP) p.dw[(long long)co * p.NP + np] += acc[i][j][r];   // single split: this block owns the tile
       }
+    }
+  }
+}
+
+// dW[co][np] += sum_split slab[split][tile(co,np)][...]   (float4 per thread, coalesced over np).
+// blockIdx.y strides over groups of 8 splits (8 independent loads in flight per lane); a single group adds
+// into dW directly (deterministic), several groups combine with a few fp32 atomics.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int NP, int co_tiles,
+                                                           int np_tiles, int splits) {
+  const int tiles = co_tiles * np_tiles;
+  const long long total = (long long)Cout * (NP / 4);
+  const size_t sstride = (size_t)tiles * (WG_TILE * WG_TILE);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int co = (int)(i / (NP / 4)), np = (int)(i - (long long)co * (NP / 4)) * 4;
+    const int ct = co / WG_TILE, nt = np / WG_TILE;
+    const int tile = nt * co_tiles + ct;
+    const float* src = slab + (size_t)tile * (WG_TILE * WG_TILE) + (co - ct * WG_TILE) * WG_TILE + (np - nt * WG_TILE);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = blockIdx.y * 8; s0 < splits; s0 += gridDim.y * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s0 + u < splits ? *(const float4*)(src + (size_t)(s0 + u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+      }
+    }
+    float* d = dw + (long long)co * NP + np;
+    if (gridDim.y == 1) {
+      float4 o = *(const float4*)d;
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      *(float4*)d = o;
+    } else {
+      atomicAdd(d + 0, a.x); atomicAdd(d + 1, a.y); atomicAdd(d + 2, a.z); atomicAdd(d + 3, a.w);
     }
   }
 }
@@ -235,6 +285,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   if (pl == 0 && ch < c) atomicAdd(out + ch, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// Split count over the pixel axis from a small cost model (us): whole rounds of 512 resident workgroups, ~0.85 us per
+// 64-pixel k-step at 2 workgroups/CU, plus the slab round trip (~3 TB/s) and one extra launch when splitting.
+int choose_splits(int tiles, int M, double out_bytes) {
+  (void)out_bytes;
+  // default when the shape was not autotuned: fill (not exceed) one round of 512 resident workgroups
+  int sp = max(1, min(1024, 512 / max(1, tiles)));
+  sp = max(1, min(sp, M / 2048));
+  while (sp > 1) {
+    const int chunk = ((M + sp - 1) / sp + WG_BKP - 1) / WG_BKP * WG_BKP;
+    if ((M + chunk - 1) / chunk == sp) break;
+    --sp;
+  }
+  return sp;
+}
+
+std::unordered_map<unsigned long long, int> g_wgrad_tuned;   // shape key -> split count found by mi355det_conv_autotune
+int g_wgrad_force = 0;
+
+unsigned long long wgrad_key(const mi355det_conv_shape* s) {
+  unsigned long long k = (unsigned long long)(s->n * s->ho * s->wo);
+  k = k * 4099 + s->cout;
+  k = k * 4099 + s->cin;
+  k = k * 17 + s->ksize * 4 + s->stride;
+  return k;
+}
+
+bool split_valid(int M, int sp) {
+  const int chunk = ((M + sp - 1) / sp + WG_BKP - 1) / WG_BKP * WG_BKP;
+  return (M + chunk - 1) / chunk == sp;
+}
+
 bf16_t* g_zero_page_w = nullptr;
 int ensure_zero_page_w() {
   if (g_zero_page_w) return 0;
@@ -248,7 +329,55 @@ int ensure_zero_page_w() {
 
 extern "C" {
 
-int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw, float* dbias, void* stream) {
+size_t mi355det_conv_wgrad_workspace(const mi355det_conv_shape* s) {
+  if (!s) return 0;
+  // room for the largest split count the autotuner may pick (capped at 128 MiB)
+  const size_t tiles = (size_t)((s->cout + WG_TILE - 1) / WG_TILE) * (size_t)((s->ksize * s->ksize * s->cin + WG_TILE - 1) / WG_TILE);
+  const size_t per_split = tiles * WG_TILE * WG_TILE * sizeof(float);
+  size_t splits = 1024;
+  while (splits > 1 && splits * per_split > ((size_t)128 << 20)) --splits;
+  return splits * per_split;
+}
+
+// Times the candidate split counts on the caller's buffers (synchronises: plan-build time only, never in the step)
+// and remembers the fastest for this shape.  dw receives garbage accumulations: the caller re-zeroes it.
+int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!s) return fail(MI355DET_EINVAL, "%s: null shape", "wgrad_autotune");
+  const int M = s->n * s->ho * s->wo;
+  const size_t tiles = (size_t)((s->cout + WG_TILE - 1) / WG_TILE) * (size_t)((s->ksize * s->ksize * s->cin + WG_TILE - 1) / WG_TILE);
+  const size_t per_split = tiles * WG_TILE * WG_TILE * sizeof(float);
+  const int cands[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 96, 128, 192, 256, 384, 512, 768, 1024};
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "wgrad_autotune");
+  int best = -1;
+  float best_ms = 1e30f;
+  for (int sp : cands) {
+    if (sp > 1 && (sp * per_split > workspace_bytes || M / sp < 512 || (size_t)sp * tiles > 4096)) continue;
+    if (!split_valid(M, sp)) continue;
+    g_wgrad_force = sp;
+    int e = mi355det_conv_wgrad(s, x, dy, dw, nullptr, workspace, workspace_bytes, stream);   // warm-up
+    if (e) { g_wgrad_force = 0; return e; }
+    (void)hipEventRecord(e0, S(stream));
+    for (int r = 0; r < 3; ++r) (void)mi355det_conv_wgrad(s, x, dy, dw, nullptr, workspace, workspace_bytes, stream);
+    (void)hipEventRecord(e1, S(stream));
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best_ms) {
+      best_ms = ms;
+      best = sp;
+    }
+  }
+  g_wgrad_force = 0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (best > 0) g_wgrad_tuned[wgrad_key(s)] = best;
+  return best;
+}
+
+int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw, float* dbias, void* workspace,
+                        size_t workspace_bytes, void* stream) {
   if (!s) return fail(MI355DET_EINVAL, "%s: null shape", "conv_wgrad");
   if (int e = ensure_zero_page_w()) return e;
   if (s->cin % 8 != 0) return fail(MI355DET_EINVAL, "%s: Cin must be a multiple of 8 (got %lld)", "conv_wgrad", s->cin);
@@ -267,22 +396,26 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   p.co_tiles = (p.Cout + WG_TILE - 1) / WG_TILE;
   p.np_tiles = (p.NP + WG_TILE - 1) / WG_TILE;
   const int tiles = p.co_tiles * p.np_tiles;
-  // split the pixel axis: enough workgroups to fill 256 CUs x 2, bounded so that the fp32 atomic
-  // traffic (splits * |dW| * 4 B at ~1.3 TB/s chip-wide) stays below ~half of the MFMA time at ~1 PFLOP/s
-  // (or 10 us for small layers), and every workgroup still reduces >= 512 pixels.
-  const double flops = 2.0 * p.M * (double)p.Cout * p.NP;
-  const double out_bytes = 4.0 * p.Cout * (double)p.NP;
-  const double t_mfma = flops / 1.0e15;
-  const double budget = t_mfma * 0.5 > 10e-6 ? t_mfma * 0.5 : 10e-6;
-  int max_by_atomics = (int)(budget * 1.3e12 / out_bytes);
-  int splits = (768 + tiles - 1) / tiles;
-  splits = min(splits, max(1, max_by_atomics));
-  splits = max(1, min(splits, max(1, p.M / 512)));
+  int splits = choose_splits(tiles, p.M, 4.0 * p.Cout * (double)p.NP);
+  {
+    auto it = g_wgrad_tuned.find(wgrad_key(s));
+    if (it != g_wgrad_tuned.end()) splits = it->second;
+    if (g_wgrad_force > 0 && split_valid(p.M, g_wgrad_force)) splits = g_wgrad_force;
+    const size_t per_split = (size_t)tiles * WG_TILE * WG_TILE * sizeof(float);
+    while (splits > 1 && (splits * per_split > workspace_bytes || !split_valid(p.M, splits))) --splits;
+  }
   int chunk = (p.M + splits - 1) / splits;
   chunk = (chunk + WG_BKP - 1) / WG_BKP * WG_BKP;
   splits = (p.M + chunk - 1) / chunk;
   p.splits = splits;
   p.chunk = chunk;
+  p.slab = nullptr;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * tiles * WG_TILE * WG_TILE * sizeof(float);
+    if (!workspace || workspace_bytes < need) return fail(MI355DET_EWORKSPACE, "%s: workspace too small (%lld bytes needed)", "conv_wgrad", (long long)need);
+    if (p.NP % 4 != 0) return fail(MI355DET_EINVAL, "%s: k*k*Cin must be a multiple of 4", "conv_wgrad");
+    p.slab = (float*)workspace;
+  }
   p.step_q = WG_BKP / p.Wo;
   p.step_r = WG_BKP % p.Wo;
   p.dWo = make_fastdiv((unsigned)p.Wo);
@@ -295,6 +428,12 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     attr_done = true;
   }
   hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), lds, S(stream), p);
+  if (p.slab) {
+    const long long total = (long long)p.Cout * (p.NP / 4);
+    const int gx = (int)min((long long)2048, (total + 255) / 256);
+    const int gy = splits > 8 && gx < 512 ? min((splits + 7) / 8, max(1, 1024 / gx)) : 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, S(stream), p.slab, dw, p.Cout, p.NP, p.co_tiles, p.np_tiles, splits);
+  }
   if (dbias) {
     const int gy = (int)min((long long)256, ((long long)p.M + 255) / 256);
     hipLaunchKernelGGL(colsum_kernel, dim3((p.Cout + 63) / 64, gy), dim3(256), 0, S(stream), (const bf16_t*)dy, s->out_ld, s->cout, (long long)p.M, dbias);

@@ -277,5 +277,15 @@ def conv_dgrad(shape, dy, w_dgrad, dx, residual=None, residual_ld=0):
           "conv_dgrad")
 
 
-def conv_wgrad(shape, x, dy, dw, dbias=None):
-    check(lib().mi355det_conv_wgrad(C.byref(shape), ptr(x), ptr(dy), ptr(dw), ptr(dbias), stream_ptr()), "conv_wgrad")
+_WGRAD_WS = {}
+
+
+def conv_wgrad(shape, x, dy, dw, dbias=None, workspace=None):
+    need = lib().mi355det_conv_wgrad_workspace(C.byref(shape))
+    if workspace is None and need:
+        key = dw.device
+        if key not in _WGRAD_WS or _WGRAD_WS[key].numel() < need:
+            _WGRAD_WS[key] = torch.empty(need, device=dw.device, dtype=torch.uint8)
+        workspace = _WGRAD_WS[key]
+    check(lib().mi355det_conv_wgrad(C.byref(shape), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(workspace),
+                                    workspace.numel() if workspace is not None else 0, stream_ptr()), "conv_wgrad")

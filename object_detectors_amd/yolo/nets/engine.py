@@ -403,12 +403,17 @@ class Plan:
                                                         _vp(wd) if need_d else None, self.stream)))
         if training:
             self._build_backward()
+            self._autotune()
 
     # ------------------------------------------------------------------
     def _build_backward(self):
         eng, L, dev = self.eng, lib(), self.eng.device
         bf = torch.bfloat16
         self.dz = torch.zeros(self.dz_elems, device=dev, dtype=bf)
+        ws_need = max(L.mi355det_conv_wgrad_workspace(C.byref(r["shp_f"] if r["kind"] == "out" else r["shp"]))
+                      for r in self.ops if r["kind"] in ("cbl", "out"))
+        self.wgrad_ws = torch.empty(max(ws_need, 16), device=dev, dtype=torch.uint8)
+        ws_ptr, ws_bytes = _vp(self.wgrad_ws), self.wgrad_ws.numel()
         nsum = sum(2 * r["shp"].cout for r in self.ops if r["kind"] == "cbl")
         self.sums_all = torch.zeros(nsum, device=dev, dtype=torch.float32)
         sum_off = [0]
@@ -445,7 +450,7 @@ class Plan:
                 _, wd = eng.packed[name]
                 dy = _vp(self.head_grads[k])
                 self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp_f), x.ptr, dy, _vp(eng.grads[name + ".weight"]),
-                                                         _vp(eng.grads[name + ".bias"]), self.stream)))
+                                                         _vp(eng.grads[name + ".bias"]), ws_ptr, ws_bytes, self.stream)))
                 emit_dgrad(shp, dy, wd, x)
             elif rec["kind"] == "up":
                 x, cat, c_up, skip_to = rec["x"], rec["cat"], rec["c_up"], rec["skip_to"]
@@ -470,12 +475,46 @@ class Plan:
                                                                pixels, SLOPE, _vp(self.dz), shp.cout, _vp(eng.grads[b + ".weight"]),
                                                                _vp(eng.grads[b + ".bias"]), self.stream)))
                 self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(self.dz), _vp(eng.grads[name + ".weight"]), None,
-                                                         self.stream)))
+                                                         ws_ptr, ws_bytes, self.stream)))
                 if name != "backbone.conv1":
                     _, wd = eng.packed[name]
                     emit_dgrad(shp, _vp(self.dz), wd, x)
             if rec["kind"] in ("out", "cbl"):
                 self.bwd_marks.append((len(self.bwd), first_off[rec["name"] + ".weight"]))
+
+    def _autotune(self):
+        """Plan-build time only: let the library time its candidate tile configurations / split counts for every
+        conv shape of this plan on the plan's own buffers (mi355det_conv_autotune_mode, _wgrad_autotune)."""
+        eng, L = self.eng, lib()
+        saved = {k: v.clone() for k, v in eng.buffers.items()}
+        img = torch.randn((self.n, 3, self.H, self.W), device=eng.device)
+        self.fwd[self.img_call][1][0] = C.c_void_p(img.data_ptr())
+        for g in self.head_grads:
+            g.normal_(0, 1e-2)
+        L.mi355det_conv_autotune_mode(1)
+        try:
+            self._run(self.pack)
+            self._run(self.fwd)
+            self._run(self.bwd)
+        finally:
+            L.mi355det_conv_autotune_mode(0)
+        ws_ptr, ws_bytes = _vp(self.wgrad_ws), self.wgrad_ws.numel()
+        for rec in self.ops:
+            if rec["kind"] == "cbl":
+                st = L.mi355det_conv_wgrad_autotune(C.byref(rec["shp"]), rec["x"].ptr, _vp(self.dz), _vp(eng.grads[rec["name"] + ".weight"]),
+                                                    ws_ptr, ws_bytes, self.stream)
+            elif rec["kind"] == "out":
+                st = L.mi355det_conv_wgrad_autotune(C.byref(rec["shp_f"]), rec["x"].ptr, _vp(self.head_grads[rec["k"]]),
+                                                    _vp(eng.grads[rec["name"] + ".weight"]), ws_ptr, ws_bytes, self.stream)
+            else:
+                continue
+            if st < 0:
+                check(st, "conv_wgrad_autotune")
+        torch.cuda.synchronize()
+        for k, v in saved.items():
+            eng.buffers[k].copy_(v)
+        eng.flat_g.zero_()
+        self.zero_head_grads()
 
     # ------------------------------------------------------------------
     def _run(self, calls):

@@ -1,0 +1,42 @@
+"""Per-layer conv micro-benchmark on the GPU box: fwd / dgrad / wgrad TFLOP/s for the YOLOv3@640 bs-32 shapes.
+    python tools/bench_conv.py [tune values ...]"""
+import sys, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detectors_amd import ops
+from object_detectors_amd._lib import lib
+dev = torch.device('cuda:0')
+SHAPES = [  # n, h, w, cin, cout, k, s
+    (32, 80, 80, 128, 256, 3, 1), (32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1),
+    (32, 80, 80, 256, 128, 1, 1), (32, 40, 40, 512, 256, 1, 1), (32, 20, 20, 1024, 512, 1, 1),
+    (32, 160, 160, 64, 128, 3, 1), (32, 160, 160, 128, 256, 3, 2), (32, 320, 320, 32, 64, 3, 1),
+]
+tunes = [int(v) for v in sys.argv[1:]] or [0]
+which = 'fdw'
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+for (n, h, w, cin, cout, k, s) in SHAPES:
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s)
+    x = (torch.randn(n, h, w, cin, device=dev)).bfloat16()
+    wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    wf, wd = ops.pack_weights(shape, wt)
+    y = torch.empty(n, shape.ho, shape.wo, cout, device=dev, dtype=torch.bfloat16)
+    dy = torch.randn(n, shape.ho, shape.wo, cout, device=dev).bfloat16()
+    dx = torch.empty_like(x)
+    dw = torch.zeros(cout, k * k * cin, device=dev)
+    rows = ops.conv_stats_rows(shape)
+    stats = torch.zeros(rows + 64, 2, ops.cout_pad_of(cout), device=dev)
+    fl = 2.0 * n * shape.ho * shape.wo * cout * cin * k * k
+    msg = f"{cin:4d}->{cout:4d} k{k} s{s} @{shape.ho:3d}: "
+    for t in tunes:
+        lib().mi355det_debug_set(0, t)
+        us = timeit(lambda: ops.conv_fwd(shape, x, wf, y, stats=stats))
+        msg += f" fwd[t{t}] {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
+    lib().mi355det_debug_set(0, 0)
+    us = timeit(lambda: ops.conv_dgrad(shape, dy, wd, dx)); msg += f" dgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
+    us = timeit(lambda: ops.conv_wgrad(shape, x, dy, dw)); msg += f" wgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF"
+    print(msg, flush=True)
