@@ -61,6 +61,8 @@ struct IgemmParams {
 };
 
 enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3 };
+#define EPI_LDS_OFF 4096                               // epilogue staging starts behind the BN-statistics scratch
+#define EPI_LDS_BYTES(nwaves) (EPI_LDS_OFF + (nwaves) * (64 * (8 * 16 * 2 + 16) + 256))   // upper bound (TN <= 8)
 
 namespace {
 
@@ -99,10 +101,141 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---- shared epilogue.  `consumer` = this wave holds accumulators (false for a dedicated loader wave, which only
+//      takes part in the barrier and the final statistics write)
+template <int WM, int WN, int TM, int TN, int EPI>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&acc)[TN][TM], char* smem, int tid, int nthreads, bool consumer,
+                                               int wm, int wn, int lane, int mt, int n0, int m0) {
+  constexpr int BN = WN * TN * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  // ---- epilogue: lane holds channels co = n0 + wn*TN*16 + i*16 + fq*4 + r (r=0..3) of pixel
+  //      m = m0 + wm*TM*16 + j*16 + fr
+  if (EPI == EPI_STATS) {
+    float* sred = (float*)smem;   // [WM][BN][2]
+#pragma unroll
+    for (int i = 0; consumer && i < TN; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          // statistics of the STORED (bf16-rounded) tensor: the BN backward formulas then hold exactly
+          const float v = bf2f(f2bf(acc[i][j][r]));
+          s1 += v;
+          s2 += v * v;
+        }
+        s1 = row16_sum(s1);
+        s2 = row16_sum(s2);
+        if (fr == 0) {
+          const int c = wn * (TN * 16) + i * 16 + fq * 4 + r;
+          sred[(wm * BN + c) * 2 + 0] = s1;
+          sred[(wm * BN + c) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += nthreads) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        s1 += sred[(w * BN + c) * 2 + 0];
+        s2 += sred[(w * BN + c) * 2 + 1];
+      }
+      float* dst = p.stats + (long long)mt * 2 * p.CoutPad;
+      dst[n0 + c] = s1;
+      dst[p.CoutPad + n0 + c] = s2;
+    }
+  }
+  if (!consumer) return;
+  if (EPI == EPI_F32) {
+    // head conv_out: fp32 + bias, 255 channels (tiny layers): direct stores from the accumulator layout
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * (TM * 16) + j * 16 + fr;
+      if (m >= p.M) continue;
+      const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+      const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+      const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+      if (oy >= p.Hout || ox >= p.Wout) continue;
+      const long long pix = (long long)(n * p.Hout + oy) * p.Wout + ox;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int co = n0 + wn * (TN * 16) + i * 16 + fq * 4;
+        if (co >= p.Cout) continue;
+        float* o = (float*)p.y + pix * p.ldout + co;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.Cout) o[r] = acc[i][j][r] + (p.bias ? p.bias[co + r] : 0.f);
+      }
+    }
+    return;
+  }
+  // bf16 outputs: the accumulator layout gives each lane 4 channels of one pixel (8-byte pieces scattered over
+  // 16 rows per instruction = partial-line writes).  Stage the wave's tile through a wave-private LDS region and
+  // write whole 128-byte channel runs with 16-byte stores (and read the residual the same way).
+  constexpr int CW = TN * 16;                 // channels per wave
+  constexpr int PITCH = CW * 2 + 16;          // bytes per staged pixel row (+16: spreads the 8-byte writes over banks)
+  constexpr int CH16 = CW / 8;                // 16-byte chunks per row
+  constexpr int RPP = 64 / CH16;              // rows per pass of the wave
+  const int wid = wm + wn * WM;
+  char* reg = smem + EPI_LDS_OFF + wid * (64 * PITCH + 256);
+  int* rowpix = (int*)(reg + 64 * PITCH);     // pixel index (or -1) of the 64 staged rows
+#pragma unroll
+  for (int jh = 0; jh < TM / 4; ++jh) {       // 64 pixels at a time
+    {
+      const int m = m0 + wm * (TM * 16) + jh * 64 + lane;
+      int pixi = -1;
+      if (m < p.M) {
+        const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+        const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+        const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+        if (oy < p.Hout && ox < p.Wout) pixi = (n * p.Hout + oy) * p.Wout + ox;
+      }
+      rowpix[lane] = pixi;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = jh * 4 + jj;
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const f32x4_t v = acc[i][j];
+        uint2 o;
+        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fq * 4) * 2) = o;
+      }
+    }
+    const int ch = lane % CH16, rsub = lane / CH16;
+    const int co = n0 + wn * CW + ch * 8;
+#pragma unroll
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+      const int row = pass * RPP + rsub;
+      const int pixi = rowpix[row];
+      uint4 v = *(const uint4*)(reg + row * PITCH + ch * 16);
+      if (pixi >= 0 && co < p.Cout) {
+        if (EPI == EPI_RES) {
+          const uint4 rr = *(const uint4*)(p.res + (long long)pixi * p.ldres + co);
+          const unsigned vi[4] = {v.x, v.y, v.z, v.w}, ri[4] = {rr.x, rr.y, rr.z, rr.w};
+          unsigned oo[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = bf2f((bf16_t)(vi[q] & 0xFFFF)) + bf2f((bf16_t)(ri[q] & 0xFFFF));
+            const float hi = bf2f((bf16_t)(vi[q] >> 16)) + bf2f((bf16_t)(ri[q] >> 16));
+            oo[q] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+          }
+          v = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+        }
+        *(uint4*)((bf16_t*)p.y + (long long)pixi * p.ldout + co) = v;
+      }
+    }
+  }
+}
+
 #define STAMP(v) do { if (PROF) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 
-template <int WM, int WN, int TM, int TN, int BK, int NST, int EPI, bool PROF = false, bool ILV = false>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_kernel(const IgemmParams p) {
+// ABL (ablation, diagnostic builds only): 1 = no LDS-DMA loads, 2 = no fragment reads, 3 = no MFMAs
+template <int WM, int WN, int TM, int TN, int BK, int NST, int EPI, bool PROF = false, bool ILV = false, int OCC = 0, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1))) void igemm_kernel(const IgemmParams p) {
   unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, c_wait = 0, c_bar = 0, c_issue = 0, c_comp = 0, t_begin = 0, t_loop = 0;
   STAMP(t_begin);
   constexpr int NT = WM * WN * 64;
@@ -196,7 +329,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_ker
   __builtin_amdgcn_s_barrier();
   STAMP(t_p4);
 
-  const int ksteps = Ktot / BK;
+  const int ksteps = ABL == 5 ? 0 : Ktot / BK;   // ABL 5: prologue + epilogue only
   const int cin_steps = p.Cin / BK;
   int pf_t = 0, pf_c = 0;   // (tap, cin-step) of the next stage to prefetch
 
@@ -237,7 +370,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_ker
 
 #pragma unroll
   for (int s = 0; s < D; ++s)
-    if (s < ksteps) stage(s, s);
+    if (s < ksteps && ABL != 1) stage(s, s);
 
   const int fr = lane & 15, fq = lane >> 4;
   int buf = 0;
@@ -259,7 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_ker
     const int pbuf = buf == 0 ? NST - 1 : buf - 1;
     int il_soff = 0, il_tap = 0;
     if (!ILV) {
-      if (pf) stage(s + D, pbuf);
+      if (pf && ABL != 1) stage(s + D, pbuf);
     } else if (pf) {
       il_tap = pf_t;
       il_soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
@@ -277,12 +410,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_ker
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn * (TN * 16) + i * 16 + fr;
-        wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        if (ABL == 2) { wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(row, s, ks, i)); asm volatile("" : "+v"(wf[i])); }
+        else wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm * (TM * 16) + j * 16 + fr;
-        af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        if (ABL == 2) { af[j] = __builtin_bit_cast(bf16x8_t, make_uint4(row, s, ks, j)); asm volatile("" : "+v"(af[j])); }
+        else af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
       constexpr int NMF = TN * TM * (BK / 32);            // MFMAs per k-step per wave
       constexpr int G = NMF / PER > 0 ? NMF / PER : 1;     // MFMAs between two LDS-DMA pieces
@@ -290,7 +425,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_ker
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          if (ABL == 3) { asm volatile("" ::"v"(wf[i]), "v"(af[j])); acc[i][j][0] += 1.0f; }
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
           if (ILV) {
             // spread the next stage's LDS-DMA pieces between the MFMAs: a piece costs ~100+ issue cycles, which
             // then overlap with this wave's own MFMAs still running in the matrix pipe
@@ -324,78 +460,161 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_ker
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
 
-  // ---- epilogue: lane holds channels co = n0 + wn*TN*16 + i*16 + fq*4 + r (r=0..3) of pixel
-  //      m = m0 + wm*TM*16 + j*16 + fr
-  if (EPI == EPI_STATS) {
-    float* sred = (float*)smem;   // [WM][BN][2]
+  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
+}
+
+// Warp-specialised variant: LW dedicated LOADER waves drive the LDS-DMA ring while the WM x WN CONSUMER waves only
+// read fragments and issue MFMAs.  Measured on the unified kernel above: a wave spends ~740 cycles per k-step issuing
+// its 8 LDS-DMA pieces (the CU's texture-address path is saturated meanwhile) and ~930 cycles in ds_read+MFMA, one
+// after the other, so the matrix pipe idles half the time; with separate roles the two phases overlap.
+template <int WM, int WN, int TM, int TN, int BK, int NST, int LW, int EPI>
+__global__ __launch_bounds__((WM * WN + LW) * 64, 2) void igemm_ws_kernel(const IgemmParams p) {
+  constexpr int NC = WM * WN;                 // consumer waves
+  constexpr int NT = (NC + LW) * 64;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int ROWB = BK * 2, R = 1024 / ROWB, CPR = BK / 8;
+  constexpr int A_INSTR = BM / R, B_INSTR = BN / R;
+  constexpr int A_PER = A_INSTR / LW, B_PER = B_INSTR / LW;      // pieces per loader wave per stage
+  constexpr int PER = A_PER + B_PER;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int D = NST - 1;
+  static_assert(A_INSTR % LW == 0 && B_INSTR % LW == 0, "pieces must split evenly over the loader waves");
+  static_assert((D - 1) * PER <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_toff = (int*)(smem + NST * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wid < NC;
+  const int wm = consumer ? wid % WM : 0, wn = consumer ? wid / WM : 0;
+
+  const int ntn = p.CoutPad / BN;
+  const int nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = bid / ntn, nt = bid - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int Ktot = p.T * p.Cin;
+  const int ksteps = Ktot / BK;
+
+  if (tid == 0) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
+    for (int t = 0; t < MAX_TAPS; ++t)
+      if (t < p.T) s_toff[t] = ((p.dy[t] * p.Win + p.dx[t]) * p.ldin + p.tap_pad) * 2;
+  }
+
+  f32x4_t acc[TN][TM];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  if (!consumer) {
+    // ================================ loader wave ================================
+    const int lw = wid - NC;
+    const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+    const int lrow = lane / CPR, cpos = lane % CPR;
+    int a_voff[A_PER], b_voff[B_PER];
+    unsigned a_valid[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int row = (lw * A_PER + i) * R + lrow;
+      const int m = m0 + row;
+      unsigned vm = 0;
+      int voff = OOB_VOFF;
+      if (m < p.M) {
+        const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+        const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+        const int iy0 = yy * p.sin, ix0 = xx * p.sin;
+        voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ swz<BK>(row)) * 8) * 2;
+#pragma unroll
+        for (int t = 0; t < MAX_TAPS; ++t) {
+          const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
+          const bool ok = t < p.T && (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
+          vm |= ok ? (1u << t) : 0u;
+        }
+      }
+      a_voff[i] = voff;
+      a_valid[i] = vm;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int row = (lw * B_PER + i) * R + lrow;
+      b_voff[i] = (row * Ktot + (cpos ^ swz<BK>(row)) * 8) * 2;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();             // s_toff visible
+    const int cin_steps = p.Cin / BK;
+    int pf_t = 0, pf_c = 0;
+    auto stage = [&](int s, int buf) {
+      const int soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
+      char* sa = smem + buf * STAGE;
+      char* sb = sa + BM * ROWB;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i)
+        bufld16(rsrc_x, sa + (lw * A_PER + i) * 1024, ((a_valid[i] >> pf_t) & 1u) ? a_voff[i] : OOB_VOFF, soff);
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) bufld16(rsrc_w, sb + (lw * B_PER + i) * 1024, b_voff[i], s * (BK * 2));
+      if (++pf_c == cin_steps) {
+        pf_c = 0;
+        ++pf_t;
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+      if (s < ksteps) stage(s, s);
+    int buf = 0;
+    for (int s = 0; s < ksteps; ++s) {
+      const int younger = min(D - 1, ksteps - 1 - s);
+      if (younger >= D - 1) wait_vmcnt<(D - 1 > 0 ? D - 1 : 0) * PER>();
+      else if (D >= 3 && younger == D - 2) wait_vmcnt<(D - 2 > 0 ? D - 2 : 0) * PER>();
+      else if (D >= 4 && younger == D - 3) wait_vmcnt<(D - 3 > 0 ? D - 3 : 0) * PER>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();           // stage s published; consumers have left buffer (s-1)%NST
+      if (s + D < ksteps) stage(s + D, buf == 0 ? NST - 1 : buf - 1);
+      buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+  } else {
+    // ================================ consumer waves ================================
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0;
+    for (int s = 0; s < ksteps; ++s) {
+      __builtin_amdgcn_s_barrier();
+      const char* sa = smem + buf * STAGE;
+      const char* sb = sa + BM * ROWB;
+#pragma unroll
+      for (int ks = 0; ks < BK / 32; ++ks) {
+        bf16x8_t wf[TN], af[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int row = wn * (TN * 16) + i * 16 + fr;
+          wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          // statistics of the STORED (bf16-rounded) tensor: the BN backward formulas then hold exactly
-          const float v = bf2f(f2bf(acc[i][j][r]));
-          s1 += v;
-          s2 += v * v;
+          const int row = wm * (TM * 16) + j * 16 + fr;
+          af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
         }
-        s1 = row16_sum(s1);
-        s2 = row16_sum(s2);
-        if (fr == 0) {
-          const int c = wn * (TN * 16) + i * 16 + fq * 4 + r;
-          sred[(wm * BN + c) * 2 + 0] = s1;
-          sred[(wm * BN + c) * 2 + 1] = s2;
-        }
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s1 += sred[(w * BN + c) * 2 + 0];
-        s2 += sred[(w * BN + c) * 2 + 1];
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
       }
-      float* dst = p.stats + (long long)mt * 2 * p.CoutPad;
-      dst[n0 + c] = s1;
-      dst[p.CoutPad + n0 + c] = s2;
+      buf = buf + 1 == NST ? 0 : buf + 1;
     }
   }
-#pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int m = m0 + wm * (TM * 16) + j * 16 + fr;
-    if (m >= p.M) continue;
-    const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
-    const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
-    const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
-    if (oy >= p.Hout || ox >= p.Wout) continue;
-    const long long pix = (long long)(n * p.Hout + oy) * p.Wout + ox;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int co = n0 + wn * (TN * 16) + i * 16 + fq * 4;
-      if (co >= p.Cout) continue;
-      f32x4_t v = acc[i][j];
-      if (EPI == EPI_F32) {
-        float* o = (float*)p.y + pix * p.ldout + co;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (co + r < p.Cout) o[r] = v[r] + (p.bias ? p.bias[co + r] : 0.f);
-      } else {
-        if (EPI == EPI_RES) {
-          const uint2 rr = *(const uint2*)(p.res + pix * p.ldres + co);
-          v[0] += bf2f((bf16_t)(rr.x & 0xFFFF));
-          v[1] += bf2f((bf16_t)(rr.x >> 16));
-          v[2] += bf2f((bf16_t)(rr.y & 0xFFFF));
-          v[3] += bf2f((bf16_t)(rr.y >> 16));
-        }
-        uint2 o;
-        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *(uint2*)((bf16_t*)p.y + pix * p.ldout + co) = o;
-      }
-    }
-  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
+  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, consumer, wm, wn, lane, mt, n0, m0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,14 +711,16 @@ int ensure_zero_page() {
 
 unsigned long long* g_dbg = nullptr;
 
-template <int WM, int WN, int TM, int TN, int BK, int NST, int EPI, bool PROF = false, bool ILV = false>
+template <int WM, int WN, int TM, int TN, int BK, int NST, int EPI, bool PROF = false, bool ILV = false, int OCC = 0, int ABL = 0>
 int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
   IgemmParams p = p_in;
   p.dbg = PROF ? g_dbg : nullptr;
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds = NST * (BM + BN) * BK * 2 + 64;
+  constexpr int lds_ring = NST * (BM + BN) * BK * 2 + 64;
+  constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
+  constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
-  auto k = igemm_kernel<WM, WN, TM, TN, BK, NST, EPI, PROF, ILV>;
+  auto k = igemm_kernel<WM, WN, TM, TN, BK, NST, EPI, PROF, ILV, OCC, ABL>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -507,6 +728,23 @@ int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
   }
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm");
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int NST, int LW, int EPI>
+int launch_ws(const IgemmParams& p, hipStream_t st) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int lds_ring = NST * (BM + BN) * BK * 2 + 64;
+  constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
+  constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
+  auto k = igemm_ws_kernel<WM, WN, TM, TN, BK, NST, LW, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(gm * gn), dim3((WM * WN + LW) * 64), lds, st, p);
+  return check_launch("igemm_ws");
 }
 
 int g_tune = 0;   // bring-up knob (mi355det_debug_set(0, v)): forces a tile configuration
@@ -531,6 +769,21 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 2: return launch_cfg<2, 2, 8, 4, 32, 2, EPI>(p, st);
     case 3: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 64, 2, EPI>(p, st); break;
     case 4: return launch_cfg<2, 2, 4, 4, 32, 3, EPI>(p, st);
+    case 5: return launch_cfg<2, 2, 4, 4, 32, 2, EPI, false, false, 4>(p, st);   // 32 KB LDS, <=128 VGPR: 4 workgroups/CU
+    case 7: return launch_ws<2, 2, 4, 4, 32, 4, 1, EPI>(p, st);    // warp-specialised 128x128x32, ring 4 (64 KB), 1 loader
+    case 8: return launch_ws<2, 2, 4, 4, 64, 2, 2, EPI>(p, st);    // warp-specialised 128x128x64, 2 buffers, 2 loaders
+    case 9: return launch_ws<2, 2, 8, 4, 32, 3, 1, EPI>(p, st);    // warp-specialised 256x128x32 (wave 128x64), ring 3 (72 KB)
+    case 10: return launch_ws<2, 2, 8, 4, 64, 2, 2, EPI>(p, st);   // warp-specialised 256x128x64, 2 buffers (96 KB), 2 loaders
+    case 11: return launch_ws<2, 2, 4, 4, 64, 3, 2, EPI>(p, st);   // ws 128x128x64 ring 3 (96 KB, 1 WG/CU), 2 loaders
+    case 12: return launch_ws<2, 2, 8, 4, 64, 3, 2, EPI>(p, st);   // ws 256x128x64 ring 3 (144 KB), 2 loaders
+    case 13: return launch_ws<2, 2, 8, 4, 64, 3, 4, EPI>(p, st);   // ws 256x128x64 ring 3, 4 loaders
+    case 14: return launch_ws<2, 2, 4, 4, 32, 4, 2, EPI>(p, st);   // ws 128x128x32 ring 4 (64 KB, 2 WG/CU), 2 loaders
+    case 6: return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 3>(p, st);   // 64 KB: still 2/CU by LDS, tighter regs
+    case 21: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 1>(p, st); break;   // ablations of cfg 1
+    case 22: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 2>(p, st); break;
+    case 23: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 3>(p, st); break;
+    case 31: if (EPI == EPI_PLAIN) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, true>(p, st); break;   // interleaved issue
+    case 25: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 5>(p, st); break;
     case 99: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, true>(p, st); break;   // phase-stamp diagnostic build
     default: break;
   }
@@ -562,7 +815,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
   float best_ms = 1e30f;
-  for (int cfg = 1; cfg <= 4; ++cfg) {
+  for (int cfg = 1; cfg <= 5; ++cfg) {
     if (cfg == 3 && p.CoutPad % 256 != 0) continue;
     int e = run_cfg<EPI>(cfg, p, st);
     if (e) return e;
