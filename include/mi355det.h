@@ -164,6 +164,22 @@ int mi355det_retina_cls_loss(const float* logits, const int64_t* matched, const 
                              const float* scale, int64_t rows, int32_t k, float alpha, float gamma,
                              float grad_scale, float* loss_sum, float* grad, void* stream);
 
+/* torchvision.ops.roi_align / MultiScaleRoIAlign (tvision/frcnn.py:208-211, roi_heads.py:818): NCHW fp32 features.
+ *   feats/hs/ws/scales: HOST arrays of num_levels (1..4) device pointers / sizes / spatial scales; with several levels
+ *   the LevelMapper (k = floor(4 + log2(sqrt(area)/224) + 1e-6) clamped to [k_min,k_max]) picks the level per RoI.
+ *   rois [K,5] = (batch index, x1,y1,x2,y2).  Forward: out [K,C,ph,pw].  Backward (grad_out != NULL): scatters
+ *   grad_out into grad_feats (fp32 atomics, caller zeroes), `out` unused. */
+int mi355det_roi_align(const float* const* feats, const int32_t* hs, const int32_t* ws, const float* scales,
+                       int32_t num_levels, const float* rois, int32_t num_rois, int32_t channels,
+                       int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio, int aligned, int32_t k_min,
+                       int32_t k_max, float* out, const float* grad_out, float* const* grad_feats, void* stream);
+
+/* Tensor.topk(k, dim=1) on [rows, n] (tvision/rpn.py:215-228, retinanet.py:437-445): indices (and values) of the k
+ * largest entries per row in descending order, ties -> lower index; entries <= min_value are never selected
+ * (the "> score_thresh" filter).  idx_out/val_out [rows,k], count_out [rows] = number selected; k <= 16384. */
+int mi355det_topk(const float* x, int32_t rows, int64_t n, int64_t row_stride, int32_t k, float min_value,
+                  int64_t* idx_out, float* val_out, int32_t* count_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution path (yolo/nets/backbone/darknet.py:13-20,41-43,64-66; yolo/nets/yolohead.py:41-61):
  * NHWC bf16 activations, fp32 accumulation on MFMA.  See conv section in DESIGN.md.

@@ -21,6 +21,7 @@ SOURCES = [
     ("lib.cpp", []),
     ("yolo_kernels.hip", ["-ffp-contract=off"]),
     ("box_kernels.hip", ["-ffp-contract=off"]),
+    ("roi_kernels.hip", ["-ffp-contract=off"]),
     ("conv_kernels.hip", []),
     ("wgrad_kernels.hip", []),
     ("elem_kernels.hip", []),

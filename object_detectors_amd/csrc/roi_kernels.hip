@@ -1,0 +1,301 @@
+// RoIAlign / MultiScaleRoIAlign (torchvision.ops.roi_align semantics, call sites tvision/frcnn.py:208-211,
+// tvision/roi_heads.py:818) and per-row top-k selection (tvision/rpn.py:215-228, retinanet.py:437-445).
+// HBM/latency-bound gather kernels; -ffp-contract=off like the other box kernels.
+#include "common.h"
+
+using namespace mi355;
+
+namespace {
+
+struct Levels {
+  const float* feat[4];
+  int h[4], w[4];
+  float scale[4];
+  int num;
+};
+
+__device__ __forceinline__ float bilinear(const float* __restrict__ f, int H, int W, float y, float x) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int yl = (int)y, xl = (int)x, yh, xh;
+  if (yl >= H - 1) {
+    yh = yl = H - 1;
+    y = (float)yl;
+  } else yh = yl + 1;
+  if (xl >= W - 1) {
+    xh = xl = W - 1;
+    x = (float)xl;
+  } else xh = xl + 1;
+  const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+  return hy * hx * f[yl * W + xl] + hy * lx * f[yl * W + xh] + ly * hx * f[yh * W + xl] + ly * lx * f[yh * W + xh];
+}
+
+__device__ __forceinline__ void bilinear_grad(float* __restrict__ g, int H, int W, float y, float x, float v) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int yl = (int)y, xl = (int)x, yh, xh;
+  if (yl >= H - 1) {
+    yh = yl = H - 1;
+    y = (float)yl;
+  } else yh = yl + 1;
+  if (xl >= W - 1) {
+    xh = xl = W - 1;
+    x = (float)xl;
+  } else xh = xl + 1;
+  const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+  atomicAdd(g + yl * W + xl, v * hy * hx);
+  atomicAdd(g + yl * W + xh, v * hy * lx);
+  atomicAdd(g + yh * W + xl, v * ly * hx);
+  atomicAdd(g + yh * W + xh, v * ly * lx);
+}
+
+// LevelMapper of MultiScaleRoIAlign: k = floor(4 + log2(sqrt(area)/224) + 1e-6) clamped to the pyramid
+__device__ __forceinline__ int map_level(const float4 r, int k_min, int k_max) {
+  const float s = sqrtf((r.z - r.x) * (r.w - r.y));
+  int k = (int)floorf(4.0f + log2f(s / 224.0f) + 1e-6f);
+  k = min(max(k, k_min), k_max);
+  return k - k_min;
+}
+
+// rois [K,5] = (batch, x1,y1,x2,y2); out [K,C,ph,pw].  MULTI: level chosen per RoI, else level 0.
+template <bool MULTI, bool BWD>
+__global__ __launch_bounds__(256) void roi_align_kernel(Levels L, const float* __restrict__ rois, int K, int C, int ph, int pw, int sampling,
+                                                        int aligned, int k_min, int k_max, float* __restrict__ out, const float* __restrict__ gout,
+                                                        float* __restrict__ gfeat0, float* __restrict__ gfeat1, float* __restrict__ gfeat2,
+                                                        float* __restrict__ gfeat3) {
+  const long long total = (long long)K * C * ph * pw;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int px = (int)(i % pw), py = (int)((i / pw) % ph), c = (int)((i / ((long long)pw * ph)) % C), k = (int)(i / ((long long)pw * ph * C));
+    const float* r = rois + 5 * (size_t)k;
+    const int b = (int)r[0];
+    const float4 box = make_float4(r[1], r[2], r[3], r[4]);
+    int lv = 0;
+    if (MULTI) lv = map_level(box, k_min, k_max);
+    int H = L.h[0], W = L.w[0];
+    float sc = L.scale[0];
+    const float* f = L.feat[0];
+    float* gf = gfeat0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (lv == q) {
+        H = L.h[q]; W = L.w[q]; sc = L.scale[q]; f = L.feat[q];
+        gf = q == 1 ? gfeat1 : (q == 2 ? gfeat2 : gfeat3);
+      }
+    const float off = aligned ? 0.5f : 0.0f;
+    const float x1 = box.x * sc - off, y1 = box.y * sc - off, x2 = box.z * sc - off, y2 = box.w * sc - off;
+    float rw = x2 - x1, rh = y2 - y1;
+    if (!aligned) {
+      rw = fmaxf(rw, 1.0f);
+      rh = fmaxf(rh, 1.0f);
+    }
+    const float bh = rh / (float)ph, bw = rw / (float)pw;
+    const int gh = sampling > 0 ? sampling : (int)ceilf(rh / (float)ph), gw = sampling > 0 ? sampling : (int)ceilf(rw / (float)pw);
+    const float cnt = fmaxf((float)(gh * gw), 1.0f);
+    const size_t plane = ((size_t)b * C + c) * (size_t)H * W;
+    if (!BWD) {
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float y = y1 + py * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float x = x1 + px * bw + ((float)ix + 0.5f) * bw / (float)gw;
+          acc += bilinear(f + plane, H, W, y, x);
+        }
+      }
+      out[i] = acc / cnt;
+    } else {
+      const float g = gout[i] / cnt;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float y = y1 + py * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float x = x1 + px * bw + ((float)ix + 0.5f) * bw / (float)gw;
+          bilinear_grad(gf + plane, H, W, y, x, g);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-row top-k (descending, ties -> lower index first), one workgroup per row:
+// 3-pass radix select (11+11+10 bits of the order-preserving key) in LDS histograms, ordered compaction of the
+// selected elements, bitonic sort of the <= 16384 survivors.  Elements <= min_value are never selected.
+#define TOPK_THREADS 1024
+#define TOPK_MAXK 16384
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ x, long long n, long long row_stride, int k,
+                                                            float min_value, long long* __restrict__ idx_out, float* __restrict__ val_out,
+                                                            int* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // TOPK_MAXK keys; histogram aliases the front
+  __shared__ unsigned s_prefix, s_need, s_total;
+  __shared__ int wsum[TOPK_THREADS / WAVE];
+  __shared__ int s_base, s_tiebase;
+  unsigned* hist = (unsigned*)keys;
+  const int row = blockIdx.x;
+  const float* xr = x + (size_t)row * row_stride;
+  const unsigned min_key = f2ord(min_value);
+  if (threadIdx.x == 0) {
+    s_prefix = 0;
+    s_need = (unsigned)k;
+  }
+  __syncthreads();
+  // --- radix select of the k-th largest key among keys > min_key
+  const int shifts[3] = {21, 10, 0};
+  const int bits[3] = {11, 11, 10};
+  unsigned mask_hi = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = threadIdx.x; i < 2048; i += TOPK_THREADS) hist[i] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    for (long long i = threadIdx.x; i < n; i += TOPK_THREADS) {
+      const unsigned key = f2ord(xr[i]);
+      if (key > min_key && (key & mask_hi) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned need = s_need, acc = 0;
+      int bsel = -1;
+      for (int bkt = nb - 1; bkt >= 0; --bkt) {
+        if (acc + hist[bkt] >= need) {
+          bsel = bkt;
+          break;
+        }
+        acc += hist[bkt];
+      }
+      if (bsel < 0) {   // fewer than k valid elements: select everything valid
+        s_total = acc;
+        s_need = 0;
+        s_prefix = 0xFFFFFFFFu;   // marker
+      } else {
+        s_need = need - acc;
+        s_prefix = prefix | ((unsigned)bsel << shifts[pass]);
+      }
+    }
+    __syncthreads();
+    if (s_prefix == 0xFFFFFFFFu) break;
+    mask_hi |= (unsigned)((1 << bits[pass]) - 1) << shifts[pass];
+  }
+  const bool all_valid = s_prefix == 0xFFFFFFFFu;
+  const unsigned thr = all_valid ? min_key : s_prefix;      // select key > thr, plus the first s_need elements == thr
+  const unsigned ties_needed = all_valid ? 0u : s_need;
+  __syncthreads();
+  // --- ordered compaction (index order) of the selected elements into keys[]
+  if (threadIdx.x == 0) {
+    s_base = 0;
+    s_tiebase = 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  for (long long i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+    const long long i = i0 + threadIdx.x;
+    const unsigned key = i < n ? f2ord(xr[i]) : 0u;
+    const bool gt = i < n && key > thr && key > min_key;
+    const bool tie = i < n && !all_valid && key == thr && key > min_key;
+    // ties: prefix count in index order
+    const unsigned long long tb = __ballot(tie);
+    const int tpre = __popcll(tb & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wid] = __popcll(tb);
+    __syncthreads();
+    int toff = s_tiebase;
+    for (int w = 0; w < wid; ++w) toff += wsum[w];
+    const bool take_tie = tie && (unsigned)(toff + tpre) < ties_needed;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < TOPK_THREADS / WAVE; ++w) t += wsum[w];
+      s_tiebase += t;
+    }
+    const bool sel = gt || take_tie;
+    const unsigned long long sb = __ballot(sel);
+    const int spre = __popcll(sb & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) wsum[wid] = __popcll(sb);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    if (sel && off + spre < TOPK_MAXK) keys[off + spre] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - (unsigned)i);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < TOPK_THREADS / WAVE; ++w) t += wsum[w];
+      s_base += t;
+    }
+    __syncthreads();
+  }
+  const int m = min(s_base, TOPK_MAXK);
+  int npad = 64;
+  while (npad < m) npad <<= 1;
+  for (int i = m + threadIdx.x; i < npad; i += TOPK_THREADS) keys[i] = 0;
+  __syncthreads();
+  for (int kk = 2; kk <= npad; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npad; i += TOPK_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long a = keys[i], c = keys[ixj];
+          if (((i & kk) == 0) ? a < c : a > c) {
+            keys[i] = c;
+            keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < m; i += TOPK_THREADS) {
+    const unsigned long long kv = keys[i];
+    idx_out[(size_t)row * k + i] = (long long)(0xFFFFFFFFu - (unsigned)(kv & 0xFFFFFFFFull));
+    if (val_out) val_out[(size_t)row * k + i] = ord2f((unsigned)(kv >> 32));
+  }
+  if (threadIdx.x == 0) count_out[row] = m;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355det_roi_align(const float* const* feats, const int32_t* hs, const int32_t* ws, const float* scales, int32_t num_levels,
+                       const float* rois, int32_t num_rois, int32_t channels, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio,
+                       int aligned, int32_t k_min, int32_t k_max, float* out, const float* grad_out, float* const* grad_feats, void* stream) {
+  if (num_levels < 1 || num_levels > 4 || num_rois < 0 || channels <= 0 || pooled_h <= 0 || pooled_w <= 0)
+    return fail(MI355DET_EINVAL, "%s: bad arguments", "roi_align");
+  if (num_rois == 0) return 0;
+  Levels L{};
+  L.num = num_levels;
+  float* gf[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int q = 0; q < num_levels; ++q) {
+    L.feat[q] = feats ? feats[q] : nullptr;
+    L.h[q] = hs[q];
+    L.w[q] = ws[q];
+    L.scale[q] = scales[q];
+    if (grad_feats) gf[q] = grad_feats[q];
+  }
+  const long long total = (long long)num_rois * channels * pooled_h * pooled_w;
+  const int blocks = (int)min((long long)256 * 16, (total + 255) / 256);
+  const bool multi = num_levels > 1, bwd = grad_out != nullptr;
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, S(stream), L, rois, num_rois, channels, pooled_h, pooled_w, sampling_ratio, aligned, k_min,
+                       k_max, out, grad_out, gf[0], gf[1], gf[2], gf[3]);
+  };
+  if (multi && bwd) launch(roi_align_kernel<true, true>);
+  else if (multi) launch(roi_align_kernel<true, false>);
+  else if (bwd) launch(roi_align_kernel<false, true>);
+  else launch(roi_align_kernel<false, false>);
+  return check_launch("roi_align");
+}
+
+int mi355det_topk(const float* x, int32_t rows, int64_t n, int64_t row_stride, int32_t k, float min_value, int64_t* idx_out, float* val_out,
+                  int32_t* count_out, void* stream) {
+  if (rows <= 0 || n <= 0 || k <= 0 || k > TOPK_MAXK || n >= (1ll << 32)) return fail(MI355DET_EINVAL, "%s: need 1 <= k <= 16384 and n < 2^32", "topk");
+  const int lds = TOPK_MAXK * 8;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(TOPK_THREADS), lds, S(stream), x, (long long)n, (long long)row_stride, k, min_value,
+                     (long long*)idx_out, val_out, count_out);
+  return check_launch("topk");
+}
+
+}  // extern "C"

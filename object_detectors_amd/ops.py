@@ -289,3 +289,40 @@ def conv_wgrad(shape, x, dy, dw, dbias=None, workspace=None):
         workspace = _WGRAD_WS[key]
     check(lib().mi355det_conv_wgrad(C.byref(shape), ptr(x), ptr(dy), ptr(dw), ptr(dbias), ptr(workspace),
                                     workspace.numel() if workspace is not None else 0, stream_ptr()), "conv_wgrad")
+
+
+# ------------------------------------------------------------------------------------ RoIAlign / top-k
+def roi_align_multi(feats, rois, output_size, scales, sampling_ratio=2, aligned=False, k_min=2, k_max=5, grad_out=None):
+    """feats: list of NCHW fp32 maps (1..4 levels); rois [K,5].  Forward -> [K,C,ph,pw]; with grad_out -> list of dfeats."""
+    feats = [_f32c(f) for f in feats]
+    rois = _f32c(rois)
+    nl = len(feats)
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    K, Cc = rois.shape[0], feats[0].shape[1]
+    P = (C.c_void_p * nl)(*[f.data_ptr() for f in feats])
+    hs = (C.c_int32 * nl)(*[f.shape[2] for f in feats])
+    ws = (C.c_int32 * nl)(*[f.shape[3] for f in feats])
+    sc = (C.c_float * nl)(*[float(s) for s in scales])
+    if grad_out is None:
+        out = torch.empty((K, Cc, ph, pw), device=rois.device, dtype=torch.float32)
+        check(lib().mi355det_roi_align(P, hs, ws, sc, nl, ptr(rois), K, Cc, ph, pw, int(sampling_ratio), int(aligned), k_min, k_max,
+                                       ptr(out), None, None, stream_ptr()), "roi_align")
+        return out
+    g = _f32c(grad_out)
+    dfs = [torch.zeros_like(f) for f in feats]
+    G = (C.c_void_p * nl)(*[d.data_ptr() for d in dfs])
+    check(lib().mi355det_roi_align(P, hs, ws, sc, nl, ptr(rois), K, Cc, ph, pw, int(sampling_ratio), int(aligned), k_min, k_max,
+                                   None, ptr(g), G, stream_ptr()), "roi_align_bwd")
+    return dfs
+
+
+def topk_rows(x, k, min_value=float("-inf")):
+    """x [rows,n] fp32 -> (values [rows,k], indices [rows,k] i64, count [rows] i32), descending, ties lower index first."""
+    x = _f32c(x)
+    rows, n = x.shape
+    k = int(min(k, n))
+    idx = torch.zeros((rows, k), device=x.device, dtype=torch.int64)
+    val = torch.zeros((rows, k), device=x.device, dtype=torch.float32)
+    cnt = torch.empty(rows, device=x.device, dtype=torch.int32)
+    check(lib().mi355det_topk(ptr(x), rows, n, x.stride(0), k, float(min_value), ptr(idx), ptr(val), ptr(cnt), stream_ptr()), "topk")
+    return val, idx, cnt

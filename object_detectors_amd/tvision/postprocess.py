@@ -1,0 +1,98 @@
+"""Mirrors of the proposal / detection post-processing of the torchvision_models path, composed from the HIP kernels:
+  RegionProposalNetwork._get_top_n_idx + filter_proposals   tvision/rpn.py:215-280
+  RetinaNet.postprocess_detections                          tvision/retinanet.py:414-472
+  RoIHeads.postprocess_detections                           tvision/roi_heads.py:715-781
+Only index bookkeeping (gather by the selected indices, concatenation, ragged python lists) stays in torch."""
+import math
+
+import torch
+
+from .. import ops
+from . import boxes as box_ops
+from ._utils import BoxCoder
+
+
+def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level, pre_nms_top_n, post_nms_top_n,
+                         nms_thresh=0.7, score_thresh=0.0, min_size=1e-3):
+    """proposals [N, A, 4] decoded boxes, objectness [N, A] logits -> (list of boxes [<=post,4], list of scores)."""
+    num_images = proposals.shape[0]
+    objectness = objectness.detach().reshape(num_images, -1)
+    idx_parts, lvl_parts, off = [], [], 0
+    for li, n in enumerate(num_anchors_per_level):
+        k = min(pre_nms_top_n, n)
+        _v, idx, _c = ops.topk_rows(objectness[:, off:off + n], k)          # per-level top-k for every image at once
+        idx_parts.append(idx + off)
+        lvl_parts.append(torch.full((k,), li, dtype=torch.int64, device=proposals.device))
+        off += n
+    top_idx = torch.cat(idx_parts, dim=1)
+    levels = torch.cat(lvl_parts).unsqueeze(0).expand(num_images, -1)
+    batch = torch.arange(num_images, device=proposals.device)[:, None]
+    obj = torch.sigmoid(objectness[batch, top_idx])
+    props = proposals[batch, top_idx]
+    final_boxes, final_scores = [], []
+    for boxes, scores, lvl, shape in zip(props, obj, levels, image_shapes):
+        boxes = box_ops.clip_boxes_to_image(boxes, shape)
+        keep = box_ops.remove_small_boxes(boxes, min_size)
+        boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+        keep = torch.where(scores >= score_thresh)[0]
+        boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
+        keep = box_ops.batched_nms(boxes, scores, lvl, nms_thresh)[:post_nms_top_n]
+        final_boxes.append(boxes[keep])
+        final_scores.append(scores[keep])
+    return final_boxes, final_scores
+
+
+def retinanet_postprocess_detections(cls_logits_per_level, bbox_reg_per_level, anchors_per_level, image_shapes, tfidf_post=None,
+                                     score_thresh=0.05, topk_candidates=1000, nms_thresh=0.5, detections_per_img=300):
+    """cls_logits_per_level: list of [N, HWA, K]; bbox_reg_per_level: list of [N, HWA, 4]; anchors_per_level: list of [HWA, 4]."""
+    coder = BoxCoder((1.0, 1.0, 1.0, 1.0))
+    num_images = cls_logits_per_level[0].shape[0]
+    detections = []
+    # sigmoid is monotone: select on the (tf-idf scaled) logits with the threshold mapped to logit space
+    thr_logit = math.log(score_thresh / (1.0 - score_thresh)) if 0.0 < score_thresh < 1.0 else float("-inf")
+    for i in range(num_images):
+        ib, isc, il = [], [], []
+        for logits, reg, anchors in zip(cls_logits_per_level, bbox_reg_per_level, anchors_per_level):
+            lg = logits[i] if tfidf_post is None else logits[i] * tfidf_post
+            K = lg.shape[-1]
+            flat = lg.reshape(1, -1)
+            k = min(topk_candidates, flat.shape[1])
+            val, idx, cnt = ops.topk_rows(flat, k, min_value=thr_logit)
+            c = int(cnt.item())
+            idx, val = idx[0, :c], val[0, :c]
+            a_idx, lab = idx // K, idx % K
+            bx = coder.decode_single(reg[i][a_idx], anchors[a_idx])
+            ib.append(box_ops.clip_boxes_to_image(bx, image_shapes[i]))
+            isc.append(torch.sigmoid(val))
+            il.append(lab)
+        b, s, l = torch.cat(ib), torch.cat(isc), torch.cat(il)
+        keep = box_ops.batched_nms(b, s, l, nms_thresh)[:detections_per_img]
+        detections.append({"boxes": b[keep], "scores": s[keep], "labels": l[keep]})
+    return detections
+
+
+def roi_heads_postprocess_detections(class_logits, box_regression, proposals, image_shapes, tfidf_post=1.0, score_thresh=0.05,
+                                     nms_thresh=0.5, detections_per_img=100, weights=(10.0, 10.0, 5.0, 5.0)):
+    """RoIHeads.postprocess_detections, 'ce' scores (softmax), per-class batched NMS."""
+    coder = BoxCoder(weights)
+    num_classes = class_logits.shape[-1]
+    per_img = [len(p) for p in proposals]
+    pred_boxes = coder.decode(box_regression, proposals)
+    pred_scores = torch.softmax(tfidf_post * class_logits, -1)
+    out_b, out_s, out_l = [], [], []
+    for boxes, scores, shape in zip(pred_boxes.split(per_img, 0), pred_scores.split(per_img, 0), image_shapes):
+        boxes = box_ops.clip_boxes_to_image(boxes, shape)
+        labels = torch.arange(num_classes, device=boxes.device).view(1, -1).expand_as(scores)
+        boxes, scores, labels = boxes[:, 1:].reshape(-1, 4), scores[:, 1:].reshape(-1), labels[:, 1:].reshape(-1)
+        inds = torch.nonzero(scores > score_thresh).squeeze(1)
+        boxes, scores, labels = boxes[inds], scores[inds], labels[inds]
+        keep = box_ops.remove_small_boxes(boxes, 1e-2)
+        boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+        if boxes.shape[0] > 16384:   # NMS kernel capacity: keep the best 16384 candidates (sorted anyway by NMS)
+            _v, top, _c = ops.topk_rows(scores.reshape(1, -1), 16384)
+            boxes, scores, labels = boxes[top[0]], scores[top[0]], labels[top[0]]
+        keep = box_ops.batched_nms(boxes, scores, labels, nms_thresh)[:detections_per_img]
+        out_b.append(boxes[keep])
+        out_s.append(scores[keep])
+        out_l.append(labels[keep])
+    return out_b, out_s, out_l

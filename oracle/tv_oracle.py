@@ -195,3 +195,59 @@ def retinanet_loss(cls_logits, bbox_reg, anchors_xyxy, gts, tfidf=None, high=0.5
         rl.append(np.abs(d).sum() / nfg)
         greg[i][idx] = np.sign(d) / nfg / max(1, b)
     return F32(sum(cl) / b), F32(sum(rl) / max(1, b)), mis, (gcls.astype(F32), greg.astype(F32))
+
+
+def _bilinear(f, y, x):
+    H, W = f.shape
+    if y < -1.0 or y > H or x < -1.0 or x > W:
+        return 0.0
+    y, x = max(y, 0.0), max(x, 0.0)
+    yl, xl = int(y), int(x)
+    if yl >= H - 1:
+        yh = yl = H - 1
+        y = float(yl)
+    else:
+        yh = yl + 1
+    if xl >= W - 1:
+        xh = xl = W - 1
+        x = float(xl)
+    else:
+        xh = xl + 1
+    ly, lx = y - yl, x - xl
+    hy, hx = 1 - ly, 1 - lx
+    return hy * hx * f[yl, xl] + hy * lx * f[yl, xh] + ly * hx * f[yh, xl] + ly * lx * f[yh, xh]
+
+
+def roi_align(feat, rois, out_size, scale, sampling_ratio=2, aligned=False):
+    """torchvision.ops.roi_align, float64 loops — small cases only.  feat [N,C,H,W], rois [K,5]."""
+    ph, pw = out_size
+    K, C = rois.shape[0], feat.shape[1]
+    out = np.zeros((K, C, ph, pw), np.float64)
+    off = 0.5 if aligned else 0.0
+    for k in range(K):
+        b = int(rois[k, 0])
+        x1, y1, x2, y2 = [float(v) * scale - off for v in rois[k, 1:]]
+        rw, rh = x2 - x1, y2 - y1
+        if not aligned:
+            rw, rh = max(rw, 1.0), max(rh, 1.0)
+        bh, bw = rh / ph, rw / pw
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / ph))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / pw))
+        for c in range(C):
+            f = feat[b, c].astype(np.float64)
+            for py in range(ph):
+                for px in range(pw):
+                    acc = 0.0
+                    for iy in range(gh):
+                        y = y1 + py * bh + (iy + 0.5) * bh / gh
+                        for ix in range(gw):
+                            x = x1 + px * bw + (ix + 0.5) * bw / gw
+                            acc += _bilinear(f, y, x)
+                    out[k, c, py, px] = acc / max(gh * gw, 1)
+    return out.astype(F32)
+
+
+def map_levels(boxes, k_min, k_max):
+    s = np.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).astype(F32)
+    k = np.floor(F32(4) + np.log2(s / F32(224)) + F32(1e-6))
+    return (np.clip(k, k_min, k_max) - k_min).astype(np.int64)

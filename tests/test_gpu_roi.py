@@ -1,0 +1,148 @@
+"""GPU parity: RoIAlign / MultiScaleRoIAlign, top-k, RPN proposal filtering and RetinaNet post-processing vs
+oracle/tv_oracle.py (torchvision semantics restated; parity unpinned by the reference, see oracle header)."""
+import numpy as np
+import pytest
+
+from oracle import detrand
+from oracle import tv_oracle as tv
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def rand_rois(seed, k, nimg, extent):
+    tl = detrand.uniform(seed, (k, 2), 0, extent * 0.7)
+    wh = np.exp(detrand.uniform(seed + 1, (k, 2), np.log(4), np.log(extent * 0.6))).astype(np.float32)
+    b = detrand.randint(seed + 2, (k, 1), 0, nimg).astype(np.float32)
+    return np.concatenate([b, tl, np.minimum(tl + wh, extent)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("aligned,sr", [(False, 2), (True, 2), (False, -1)])
+def test_roi_align_single_level(aligned, sr):
+    from object_detectors_amd.tvision.roi_align import roi_align
+    feat = detrand.uniform(5, (2, 5, 20, 24), -1, 1)
+    rois = rand_rois(6, 23, 2, 80.0)
+    rois[0, 1:] = [-5, -5, 3, 2]          # partly outside
+    rois[1, 1:] = [70, 60, 110, 100]      # beyond the map
+    ft = T(feat).requires_grad_(True)
+    out = roi_align(ft, T(rois), (7, 7), 0.25, sr, aligned)
+    ref = tv.roi_align(feat, rois, (7, 7), 0.25, sr, aligned)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+    # backward == adjoint of the forward (linearity property): <g, A f> == <A^T g, f>
+    g = detrand.uniform(7, tuple(out.shape), -1, 1)
+    out.backward(T(g))
+    lhs = float((out.detach().cpu().numpy().astype(np.float64) * g).sum())
+    rhs = float((ft.grad.cpu().numpy().astype(np.float64) * feat).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_multiscale_roi_align():
+    from object_detectors_amd.tvision.roi_align import MultiScaleRoIAlign
+    img = (768, 1024)
+    feats = {str(i): detrand.uniform(20 + i, (2, 4, img[0] // s, img[1] // s), -1, 1) for i, s in enumerate((4, 8, 16, 32))}
+    feats["pool"] = detrand.uniform(30, (2, 4, 4, 5), -1, 1)       # ignored (not in featmap_names)
+    boxes = [rand_rois(40 + i, 30, 1, 760.0)[:, 1:] for i in range(2)]
+    m = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = m({k: T(v) for k, v in feats.items()}, [T(b) for b in boxes], [img, img]).cpu().numpy()
+    allb = np.concatenate(boxes)
+    bid = np.concatenate([np.full(len(b), i, np.float32) for i, b in enumerate(boxes)])
+    lv = tv.map_levels(allb, 2, 5)
+    assert len(set(lv.tolist())) >= 3
+    ref = np.zeros_like(out)
+    for q, s in enumerate((4, 8, 16, 32)):
+        sel = np.nonzero(lv == q)[0]
+        if len(sel):
+            rois = np.concatenate([bid[sel, None], allb[sel]], 1)
+            ref[sel] = tv.roi_align(feats[str(q)], rois, (7, 7), 1.0 / s, 2, False)
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=5e-5)   # fp32 kernel vs fp64 oracle
+
+
+@pytest.mark.parametrize("n,k", [(100, 100), (5000, 1000), (120000, 2000), (40000, 16384)])
+def test_topk_rows(n, k):
+    from object_detectors_amd import ops
+    x = detrand.uniform(50 + n, (3, n), -8, 8)
+    x[1, 10:200] = x[1, 5]               # many equal values around the selection boundary
+    x[2] = np.round(x[2] * 4) / 4        # heavy ties everywhere
+    val, idx, cnt = ops.topk_rows(T(x), k)
+    assert cnt.tolist() == [min(k, n)] * 3
+    for r in range(3):
+        order = np.lexsort((np.arange(n), -x[r].astype(np.float64)))[:k]      # descending value, ties lower index
+        assert np.array_equal(idx[r].cpu().numpy(), order)
+        assert np.array_equal(val[r].cpu().numpy(), x[r][order])
+    # threshold: fewer than k valid
+    val, idx, cnt = ops.topk_rows(T(x[:1]), k, min_value=7.5)
+    c = int(cnt.item())
+    assert c == min(k, int((x[0] > 7.5).sum()))
+    assert (val[0, :c].cpu().numpy() > 7.5).all()
+
+
+def test_rpn_filter_proposals_vs_oracle():
+    from object_detectors_amd.tvision.postprocess import rpn_filter_proposals
+    levels = [3000, 900, 300]
+    A = sum(levels)
+    N = 2
+    ctr = detrand.uniform(60, (N, A, 2), -20, 420)
+    wh = np.exp(detrand.uniform(61, (N, A, 2), np.log(0.5), np.log(200))).astype(np.float32)
+    props = np.concatenate([ctr - wh / 2, ctr + wh / 2], 2).astype(np.float32)
+    obj = detrand.uniform(62, (N, A), -6, 6)
+    shapes = [(400, 380), (360, 400)]
+    gb, gs = rpn_filter_proposals(T(props), T(obj), shapes, levels, pre_nms_top_n=600, post_nms_top_n=200, nms_thresh=0.7)
+    for i in range(N):
+        # numpy restatement of rpn.py:215-280
+        idx, lvl, off = [], [], 0
+        for li, n in enumerate(levels):
+            k = min(600, n)
+            o = obj[i, off:off + n]
+            top = np.lexsort((np.arange(n), -o.astype(np.float64)))[:k]
+            idx.append(top + off)
+            lvl.append(np.full(k, li))
+            off += n
+        idx, lvl = np.concatenate(idx), np.concatenate(lvl)
+        sc = (1.0 / (1.0 + np.exp(-obj[i, idx].astype(np.float64)))).astype(np.float32)
+        bx = tv.clip_boxes_to_image(props[i, idx], shapes[i])
+        keep = tv.remove_small_boxes(bx, 1e-3)
+        bx, sc, lvl = bx[keep], sc[keep], lvl[keep]
+        keep = tv.batched_nms(bx, sc, lvl, 0.7)[:200]
+        got_b, got_s = gb[i].cpu().numpy(), gs[i].cpu().numpy()
+        assert got_b.shape == bx[keep].shape
+        np.testing.assert_allclose(got_b, bx[keep], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(got_s, sc[keep], rtol=1e-5, atol=1e-6)
+
+
+def test_retinanet_postprocess_vs_oracle():
+    from object_detectors_amd.tvision.postprocess import retinanet_postprocess_detections
+    K, N = 11, 2
+    grids = [(16, 20), (8, 10), (4, 5)]
+    sizes = [(32, 40, 50), (64, 80, 101), (128, 161, 203)]
+    anchors = [tv.anchors([s], [(0.5, 1.0, 2.0)], (128, 160), [g]) for s, g in zip(sizes, grids)]
+    logits = [detrand.uniform(70 + i, (N, a.shape[0], K), -7, 1) for i, a in enumerate(anchors)]
+    regs = [detrand.uniform(80 + i, (N, a.shape[0], 4), -0.5, 0.5) for i, a in enumerate(anchors)]
+    tfidf = detrand.uniform(90, (K,), 0.6, 1.6)
+    shapes = [(128, 160), (120, 150)]
+    det = retinanet_postprocess_detections([T(l) for l in logits], [T(r) for r in regs], [T(a) for a in anchors], shapes,
+                                           tfidf_post=T(tfidf), topk_candidates=300, detections_per_img=100)
+    for i in range(N):
+        ib, isc, il = [], [], []
+        for lg, rg, an in zip(logits, regs, anchors):
+            s = 1.0 / (1.0 + np.exp(-(lg[i] * tfidf[None, :]).astype(np.float64).reshape(-1)))
+            valid = np.nonzero(s > 0.05)[0]
+            order = valid[np.lexsort((valid, -s[valid]))][:300]
+            a_idx, lab = order // K, order % K
+            bx = tv.decode_boxes(rg[i][a_idx], an[a_idx], (1, 1, 1, 1))
+            ib.append(tv.clip_boxes_to_image(bx, shapes[i]))
+            isc.append(s[order].astype(np.float32))
+            il.append(lab)
+        b, s, l = np.concatenate(ib), np.concatenate(isc), np.concatenate(il)
+        keep = tv.batched_nms(b, s, l, 0.5)[:100]
+        assert det[i]["boxes"].shape[0] == len(keep)
+        np.testing.assert_allclose(det[i]["boxes"].cpu().numpy(), b[keep], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(det[i]["scores"].cpu().numpy(), s[keep], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(det[i]["labels"].cpu().numpy(), l[keep])
