@@ -97,16 +97,20 @@ int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_
                        void* stream);
 
 /* YOLOForw.forward, inference branch (yolo_forw.py:163-176): out [bs,N,attrs] fp32 contiguous.
- * softmax_cls!=0: class_loss is CrossEntropy (softmax), else sigmoid. */
+ * softmax_cls!=0: class_loss is CrossEntropy (softmax), else sigmoid.
+ * score_out/label_out [bs,N] (optional, channels-last heads only): conf*max(cls) and arg-max class
+ * (test_one_epoch.py:25,35) produced in the same pass. */
 int mi355det_yolo_decode(const mi355det_yolo_geom* geom, const mi355det_head_view* heads,
-                         const float* idf, int32_t bs, int softmax_cls, float* out, void* stream);
+                         const float* idf, int32_t bs, int softmax_cls, float* out, float* score_out,
+                         int32_t* label_out, void* stream);
 
 /* test_one_epoch.py:24-35: get_abs_coord + score=conf*max(cls) + threshold + row build.
  * pred [bs,N,attrs] (decoded). cand [bs,max_cand,6] = (x1,y1,x2,y2,score,label), count [bs] int32
  * (true number of passing boxes, may exceed max_cand: caller must check).  Candidates keep the
  * anchor order of the reference's boolean mask. */
 size_t mi355det_yolo_candidates_workspace(int32_t bs, int64_t n);
-int mi355det_yolo_candidates(const float* pred, int32_t bs, int64_t n, int32_t attrs, float conf_thr,
+int mi355det_yolo_candidates(const float* pred, const float* score_in /* optional: from yolo_decode */,
+                             const int32_t* label_in, int32_t bs, int64_t n, int32_t attrs, float conf_thr,
                              float* cand, int32_t* count, int32_t max_cand, void* workspace,
                              size_t workspace_bytes, void* stream);
 

@@ -48,9 +48,9 @@ PROTOTYPES = {
     "mi355det_yolo_loss_workspace": (sz, [i32, i64]),
     "mi355det_yolo_loss": (C.c_int, [P(YoloGeom), P(YoloLossCfg), P(HeadView), P(HeadView), vp, vp, vp, vp, vp, vp,
                                       i32, i32, vp, sz, vp, vp]),
-    "mi355det_yolo_decode": (C.c_int, [P(YoloGeom), P(HeadView), vp, i32, C.c_int, vp, vp]),
+    "mi355det_yolo_decode": (C.c_int, [P(YoloGeom), P(HeadView), vp, i32, C.c_int, vp, vp, vp, vp]),
     "mi355det_yolo_candidates_workspace": (sz, [i32, i64]),
-    "mi355det_yolo_candidates": (C.c_int, [vp, i32, i64, i32, f32, vp, vp, i32, vp, sz, vp]),
+    "mi355det_yolo_candidates": (C.c_int, [vp, vp, vp, i32, i64, i32, f32, vp, vp, i32, vp, sz, vp]),
     "mi355det_nms_workspace": (sz, [i32, i32]),
     "mi355det_nms_majority": (C.c_int, [vp, vp, i32, i32, f32, i32, vp, vp, vp, vp, sz, vp]),
     "mi355det_box_iou": (C.c_int, [vp, vp, vp, i64, i64, vp]),

@@ -195,25 +195,44 @@ __global__ __launch_bounds__(WAVE) void nms_scan_kernel(char* __restrict__ ws_ba
     // kept list in order
     if ((kept_bits >> lane) & 1ull) kept[kc + __popcll(kept_bits & ((1ull << lane) - 1ull))] = row;
     kc += __popcll(kept_bits);
-    // OR the kept rows into the removed bitmap for words > t, assigning first removers
+    // OR the kept rows into the removed bitmap for words > t, assigning first removers.  The rows of up to 8 kept
+    // boxes are loaded together (independent loads in flight) and then applied in keep order.
     unsigned long long kb = kept_bits;
     while (kb) {
-      const int j = __ffsll((long long)kb) - 1;
-      kb &= kb - 1;
-      const int krow = t * 64 + j;
-      const unsigned long long* mrow = mask + (size_t)krow * L.words;
+      int rows8[8];
+      int nr = 0;
 #pragma unroll
-      for (int s = 0; s < SCAN_SLOTS; ++s) {
-        const int w = lane + 64 * s;
-        if (w > t && w < words) {
-          const unsigned long long m = mrow[w];
-          unsigned long long newly = m & ~removed[s];
-          removed[s] |= m;
-          while (newly) {
-            const int bit = __ffsll((long long)newly) - 1;
-            newly &= newly - 1;
-            const int col = w * 64 + bit;
-            if (col < n) remover[col] = krow;
+      for (int r = 0; r < 8; ++r) {
+        rows8[r] = 0;
+        if (kb) {
+          const int j = __ffsll((long long)kb) - 1;
+          kb &= kb - 1;
+          rows8[r] = t * 64 + j;
+          nr = r + 1;
+        }
+      }
+      unsigned long long m8[8][SCAN_SLOTS];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int s = 0; s < SCAN_SLOTS; ++s) {
+          const int w = lane + 64 * s;
+          m8[r][s] = (r < nr && w > t && w < words) ? mask[(size_t)rows8[r] * L.words + w] : 0ull;
+        }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (r < nr) {
+#pragma unroll
+          for (int s = 0; s < SCAN_SLOTS; ++s) {
+            const int w = lane + 64 * s;
+            unsigned long long newly = m8[r][s] & ~removed[s];
+            removed[s] |= m8[r][s];
+            while (newly) {
+              const int bit = __ffsll((long long)newly) - 1;
+              newly &= newly - 1;
+              const int col = w * 64 + bit;
+              if (col < n) remover[col] = rows8[r];
+            }
           }
         }
       }
@@ -447,29 +466,61 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
                                                     float gscale, float* __restrict__ loss_sum, float* __restrict__ grad) {
   __shared__ float red[4];
   const long long total = rows * k;
+  const bool vec = (total & 3) == 0;      // 4 consecutive elements per lane: 16-byte loads/stores of logits and gradients
   float acc = 0.f;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long r = i / k;
-    const int c = (int)(i - r * k);
-    bool ok;
-    float tv;
-    if (TGT_MODE == 0) {
-      ok = !valid || valid[r];
-      tv = t[i];
+  const long long nvec = vec ? total / 4 : total;
+  for (long long q = blockIdx.x * 256ll + threadIdx.x; q < nvec; q += (long long)gridDim.x * 256) {
+    const long long i0 = vec ? q * 4 : q;
+    long long r = i0 / k;
+    int c = (int)(i0 - r * k);
+    float xv[4], tv4[4], gv[4];
+    const int cnt = vec ? 4 : 1;
+    if (vec) {
+      const float4 v = *(const float4*)(x + i0);
+      xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+      if (TGT_MODE == 0) {
+        const float4 w = *(const float4*)(t + i0);
+        tv4[0] = w.x; tv4[1] = w.y; tv4[2] = w.z; tv4[3] = w.w;
+      }
     } else {
-      const long long mi = matched[r];
-      ok = mi != -2;   // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135)
-      tv = (mi >= 0 && gt_labels[mi] == c) ? 1.0f : 0.0f;
+      xv[0] = x[i0];
+      if (TGT_MODE == 0) tv4[0] = t[i0];
     }
-    float g = 0.f;
-    if (ok) {
-      const float s = scale ? scale[c] : 1.0f;
-      float l;
-      sfl(s * x[i], tv, alpha, gamma, l, g);
-      acc += l;
-      g *= s * gscale;
+    long long mi = 0, lab = -1;
+    bool ok = true;
+    bool fresh = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e >= cnt) break;
+      if (fresh) {
+        if (TGT_MODE == 0) ok = !valid || valid[r];
+        else {
+          mi = matched[r];
+          ok = mi != -2;                                   // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135)
+          lab = mi >= 0 ? gt_labels[mi] : -1;
+        }
+        fresh = false;
+      }
+      const float tv = TGT_MODE == 0 ? tv4[e] : (lab == c ? 1.0f : 0.0f);
+      float g = 0.f;
+      if (ok) {
+        const float sc = scale ? scale[c] : 1.0f;
+        float l;
+        sfl(sc * xv[e], tv, alpha, gamma, l, g);
+        acc += l;
+        g *= sc * gscale;
+      }
+      gv[e] = g;
+      if (++c == k) {
+        c = 0;
+        ++r;
+        fresh = true;
+      }
     }
-    if (grad) grad[i] = g;
+    if (grad) {
+      if (vec) *(float4*)(grad + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      else grad[i0] = gv[0];
+    }
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = acc;

@@ -516,6 +516,91 @@ __global__ __launch_bounds__(DEC_WAVES* WAVE) void yolo_decode_kernel(mi355det_y
   }
 }
 
+// Channels-last fast path of the decode (engine-native NHWC heads, sc == 1): a workgroup stages DEC_PIX pixels x
+// (na*attrs) floats in LDS with coalesced 16-byte loads, one thread per (pixel, anchor) row does the box decode +
+// sigmoid + softmax in place (row stride 85 floats: odd -> conflict-free), and the [rows,attrs] output — contiguous in
+// the reference's flattened order — is written back with coalesced stores.  Optionally emits score = conf*max(cls) and
+// the arg-max class (test_one_epoch.py:25,35) so the candidate filter never re-reads the 85-wide rows.
+#define DEC_PIX 64
+__global__ __launch_bounds__(256) void yolo_decode_cl_kernel(mi355det_yolo_geom geom, mi355det_head_view hv, int scale, const float* __restrict__ idf,
+                                                             int softmax_cls, float* __restrict__ out, float* __restrict__ score_out,
+                                                             int* __restrict__ label_out, int n_total) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  __shared__ Geom g;
+  load_geom(g, geom);
+  const int W = g.grid[scale], hw = W * W, na = g.na, attrs = g.attrs, C = g.num_classes;
+  const int chans = na * attrs;                       // floats used per pixel
+  const int pitch = (int)hv.sp;                       // floats per pixel in memory (>= chans)
+  const int b = blockIdx.y, pix0 = blockIdx.x * DEC_PIX, npix = min(DEC_PIX, hw - pix0);
+  const float* src = (const float*)hv.ptr + (long long)b * hv.sb + (long long)pix0 * pitch;
+  const int nfl = npix * pitch;
+  if ((pitch & 3) == 0 && ((size_t)src & 15) == 0) {
+    for (int i = threadIdx.x * 4; i < nfl; i += 256 * 4) *(float4*)(tile + i) = *(const float4*)(src + i);
+  } else {
+    for (int i = threadIdx.x; i < nfl; i += 256) tile[i] = src[i];
+  }
+  __syncthreads();
+  const float gridf = (float)W, stride = g.img_size / gridf;
+  for (int r = threadIdx.x; r < npix * na; r += 256) {
+    const int pl = r / na, a = r - pl * na, pix = pix0 + pl;
+    float* row = tile + pl * pitch + a * attrs;
+    const int y = pix / W, x = pix - y * W;
+    const float cx = ((float)x + 0.5f) / gridf, cy = ((float)y + 0.5f) / gridf;
+    row[0] = (1.0f / (1.0f + __expf(-row[0])) + cx * gridf - 0.5f) * stride;
+    row[1] = (1.0f / (1.0f + __expf(-row[1])) + cy * gridf - 0.5f) * stride;
+    row[2] = __expf(row[2]) * g.aw[scale][a] * gridf * stride;
+    row[3] = __expf(row[3]) * g.ah[scale][a] * gridf * stride;
+    const float conf = 1.0f / (1.0f + __expf(-row[4]));
+    row[4] = conf;
+    float best = -INFINITY;
+    int arg = 0;
+    if (softmax_cls) {
+      float m = -INFINITY;
+      for (int c = 0; c < C; ++c) {
+        const float z = (idf ? idf[c] : 1.0f) * row[5 + c];
+        row[5 + c] = z;
+        m = fmaxf(m, z);
+      }
+      float se = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float e = __expf(row[5 + c] - m);
+        row[5 + c] = e;
+        se += e;
+      }
+      const float inv = 1.0f / se;
+      for (int c = 0; c < C; ++c) {
+        const float pc = row[5 + c] * inv;
+        row[5 + c] = pc;
+        if (pc > best) {
+          best = pc;
+          arg = c;
+        }
+      }
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const float pc = 1.0f / (1.0f + __expf(-(idf ? idf[c] : 1.0f) * row[5 + c]));
+        row[5 + c] = pc;
+        if (pc > best) {
+          best = pc;
+          arg = c;
+        }
+      }
+    }
+    if (score_out) {
+      const long long n = (long long)b * n_total + g.off[scale] + (long long)pix * na + a;
+      score_out[n] = conf * best;
+      label_out[n] = arg;
+    }
+  }
+  __syncthreads();
+  float* dst = out + ((long long)b * n_total + g.off[scale] + (long long)pix0 * na) * attrs;
+  const int nout = npix * chans;
+  for (int j = threadIdx.x; j < nout; j += 256) {
+    const int pl = j / chans, rem = j - pl * chans;
+    dst[j] = tile[pl * pitch + rem];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // test_one_epoch.py:24-35 — score = conf*max(cls) (first maximum, as torch.max), one wave per row;
 // then per image an ORDERED compaction (the reference's boolean-mask order) of rows with score>thr.
@@ -676,10 +761,25 @@ int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_
 }
 
 int mi355det_yolo_decode(const mi355det_yolo_geom* geom, const mi355det_head_view* heads, const float* idf, int32_t bs, int softmax_cls,
-                         float* out, void* stream) {
+                         float* out, float* score_out, int32_t* label_out, void* stream) {
   if (int e = check_geom(geom)) return e;
   if (!heads || bs <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "yolo_decode");
   const int N = geom->off[geom->num_scales];
+  bool channels_last = true;
+  for (int k = 0; k < geom->num_scales; ++k)
+    channels_last = channels_last && heads[k].sc == 1 && heads[k].sp >= geom->na * (geom->num_classes + 5) && heads[k].sp <= 4096 / 4 * 4;
+  if (channels_last) {
+    for (int k = 0; k < geom->num_scales; ++k) {
+      const int hw = geom->grid[k] * geom->grid[k];
+      const int lds = DEC_PIX * (int)heads[k].sp * 4;
+      if (lds > 160 * 1024) return fail(MI355DET_EINVAL, "%s: pixel pitch too large for the LDS tile", "yolo_decode");
+      (void)hipFuncSetAttribute((const void*)yolo_decode_cl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(yolo_decode_cl_kernel, dim3((hw + DEC_PIX - 1) / DEC_PIX, bs), dim3(256), lds, S(stream), *geom, heads[k], k, idf,
+                         softmax_cls, out, score_out, (int*)label_out, N);
+    }
+    return check_launch("yolo_decode");
+  }
+  if (score_out) return fail(MI355DET_EINVAL, "%s: fused score output needs channels-last heads", "yolo_decode");
   Views hv;
   for (int k = 0; k < MI355DET_MAX_SCALES; ++k) hv.h[k] = k < geom->num_scales ? heads[k] : mi355det_head_view{nullptr, 0, 0, 0};
   const long long rows = (long long)bs * N;
@@ -690,15 +790,22 @@ int mi355det_yolo_decode(const mi355det_yolo_geom* geom, const mi355det_head_vie
 
 size_t mi355det_yolo_candidates_workspace(int32_t bs, int64_t n) { return (size_t)bs * (size_t)n * 8; }
 
-int mi355det_yolo_candidates(const float* pred, int32_t bs, int64_t n, int32_t attrs, float conf_thr, float* cand, int32_t* count,
-                             int32_t max_cand, void* workspace, size_t workspace_bytes, void* stream) {
+int mi355det_yolo_candidates(const float* pred, const float* score_in, const int32_t* label_in, int32_t bs, int64_t n, int32_t attrs,
+                             float conf_thr, float* cand, int32_t* count, int32_t max_cand, void* workspace, size_t workspace_bytes,
+                             void* stream) {
   if (bs <= 0 || n <= 0 || attrs < 6 || max_cand <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "yolo_candidates");
-  if (workspace_bytes < mi355det_yolo_candidates_workspace(bs, n)) return fail(MI355DET_EWORKSPACE, "%s: workspace too small", "yolo_candidates");
-  float* score = (float*)workspace;
-  int* label = (int*)(score + (size_t)bs * n);
-  const long long rows = (long long)bs * n;
-  const int blocks = (int)min((long long)256 * 16, (rows + DEC_WAVES - 1) / DEC_WAVES);
-  hipLaunchKernelGGL(yolo_score_kernel, dim3(blocks), dim3(DEC_WAVES * WAVE), 0, S(stream), pred, rows, attrs, score, label);
+  const float* score = score_in;
+  const int* label = (const int*)label_in;
+  if (!score_in || !label_in) {
+    if (workspace_bytes < mi355det_yolo_candidates_workspace(bs, n)) return fail(MI355DET_EWORKSPACE, "%s: workspace too small", "yolo_candidates");
+    float* sc = (float*)workspace;
+    int* lb = (int*)(sc + (size_t)bs * n);
+    const long long rows = (long long)bs * n;
+    const int blocks = (int)min((long long)256 * 16, (rows + DEC_WAVES - 1) / DEC_WAVES);
+    hipLaunchKernelGGL(yolo_score_kernel, dim3(blocks), dim3(DEC_WAVES * WAVE), 0, S(stream), pred, rows, attrs, sc, lb);
+    score = sc;
+    label = lb;
+  }
   hipLaunchKernelGGL(yolo_candidates_kernel, dim3(bs), dim3(CAND_THREADS), 0, S(stream), pred, score, label, (long long)n, attrs, conf_thr,
                      cand, count, max_cand);
   return check_launch("yolo_candidates");

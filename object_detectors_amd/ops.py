@@ -112,16 +112,22 @@ def yolo_loss(geom, cfg, hviews, gviews, off, labels, obj_idx, tgt, noobj, idf, 
     return out12
 
 
-def yolo_decode(geom, hviews, idf, bs, softmax_cls=True):
+def yolo_decode(geom, hviews, idf, bs, softmax_cls=True, want_scores=False):
+    """-> decoded [bs,N,attrs] (and, with want_scores on channels-last heads, score [bs,N] + arg-max label [bs,N])."""
     N, attrs = geom.off[geom.num_scales], geom.num_classes + 5
     dev = torch.device("cuda", torch.cuda.current_device())
     out = torch.empty((bs, N, attrs), device=dev, dtype=torch.float32)
-    check(lib().mi355det_yolo_decode(C.byref(geom), hviews, ptr(idf), bs, int(softmax_cls), ptr(out), stream_ptr()), "yolo_decode")
-    return out
+    score = label = None
+    if want_scores and all(hviews[k].sc == 1 for k in range(geom.num_scales)):
+        score = torch.empty((bs, N), device=dev, dtype=torch.float32)
+        label = torch.empty((bs, N), device=dev, dtype=torch.int32)
+    check(lib().mi355det_yolo_decode(C.byref(geom), hviews, ptr(idf), bs, int(softmax_cls), ptr(out), ptr(score), ptr(label), stream_ptr()),
+          "yolo_decode")
+    return (out, score, label) if want_scores else out
 
 
-def yolo_candidates(pred, conf_thr, max_cand=None):
-    """test_one_epoch.py:24-35 -> (cand [bs,max_cand,6], count [bs] i32)."""
+def yolo_candidates(pred, conf_thr, max_cand=None, score=None, label=None):
+    """test_one_epoch.py:24-35 -> (cand [bs,max_cand,6], count [bs] i32).  score/label: the fused outputs of yolo_decode."""
     pred = _f32c(pred)
     bs, n, attrs = pred.shape
     max_cand = int(max_cand or min(n, 16384))
@@ -129,8 +135,8 @@ def yolo_candidates(pred, conf_thr, max_cand=None):
     count = torch.empty(bs, device=pred.device, dtype=torch.int32)
     wsb = lib().mi355det_yolo_candidates_workspace(bs, n)
     ws = torch.empty(wsb, device=pred.device, dtype=torch.uint8)
-    check(lib().mi355det_yolo_candidates(ptr(pred), bs, n, attrs, float(conf_thr), ptr(cand), ptr(count), max_cand, ptr(ws), wsb,
-                                         stream_ptr()), "yolo_candidates")
+    check(lib().mi355det_yolo_candidates(ptr(pred), ptr(score), ptr(label), bs, n, attrs, float(conf_thr), ptr(cand), ptr(count), max_cand,
+                                         ptr(ws), wsb, stream_ptr()), "yolo_candidates")
     return cand, count
 
 

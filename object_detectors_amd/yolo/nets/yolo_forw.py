@@ -124,7 +124,10 @@ class YOLOForw(nn.Module):
         grids = [int(h.shape[2]) for h in heads]
         geom = self._geom(grids)
         hv, keep = ops.head_views(heads, len(self.anchors[0]) * self.bbox_attrs)
-        return ops.yolo_decode(geom, hv, self._idf(keep[0].device), keep[0].shape[0], softmax_cls=True)
+        out, score, label = ops.yolo_decode(geom, hv, self._idf(keep[0].device), keep[0].shape[0], softmax_cls=True, want_scores=True)
+        # conf*max(cls) / arg-max from the same pass (channels-last heads), picked up by procedures.test_one_epoch.postprocess
+        self.last_decode_scores = (out.data_ptr(), score, label) if score is not None else None
+        return out
 
     def get_target(self, targets, grids, device=None):
         """YOLOForw.get_target (yolo_forw.py:178-208) for a whole batch: (tgt, obj_mask list, noobj_mask)."""

@@ -4,13 +4,17 @@ import torch
 from ... import ops
 
 
-def postprocess(predictions, confidence=0.1, iou_threshold=0.6, num_classes=None):
+def postprocess(predictions, confidence=0.1, iou_threshold=0.6, num_classes=None, criterion=None):
     """predictions: decoded [bs,N,5+C] (YOLOForw inference output).  Returns the list of per-image
     [k,6] tensors (x1,y1,x2,y2,score,label) for images with at least one box above `confidence`, exactly
     like `pred_final` in the reference (which calls nms_majority with its default 0.6 threshold)."""
     bs, n, attrs = predictions.shape
     num_classes = num_classes or (attrs - 5)
-    cand, count = ops.yolo_candidates(predictions, confidence)
+    score = label = None
+    fused = getattr(criterion, "last_decode_scores", None) if criterion is not None else None
+    if fused is not None and fused[0] == predictions.data_ptr():
+        score, label = fused[1], fused[2]       # computed by the decode kernel: the 85-wide rows are not re-read
+    cand, count = ops.yolo_candidates(predictions, confidence, score=score, label=label)
     counts = count.tolist()                     # one host sync for the ragged python-list output
     if max(counts) > cand.shape[1]:
         raise RuntimeError(f"more than {cand.shape[1]} boxes above the confidence threshold in one image")
