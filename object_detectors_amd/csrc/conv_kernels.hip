@@ -463,6 +463,159 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
 }
 
+// Interleaved variant (2-buffer ring): all fragment reads of a k-step are issued up front (the second half's LDS
+// latency hides under the first half's MFMAs) and the next stage's LDS-DMA pieces are issued BRANCH-FREE between
+// groups of MFMAs (past the last stage the pieces carry an out-of-range offset and just zero-fill the idle buffer),
+// so a piece's ~100-cycle issue stall overlaps with this wave's own MFMAs still executing in the matrix pipe.
+template <int WM, int WN, int TM, int TN, int BK, int EPI, int SCHED>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_il_kernel(const IgemmParams p) {
+  constexpr int NT = WM * WN * 64, NW = WM * WN, NST = 2;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int ROWB = BK * 2, R = 1024 / ROWB, CPR = BK / 8, KS = BK / 32;
+  constexpr int A_INSTR = BM / R, B_INSTR = BN / R;
+  constexpr int A_PER = A_INSTR / NW, B_PER = (B_INSTR + NW - 1) / NW, PER = A_PER + B_PER;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int NMF = TN * TM * KS, G = NMF / PER;
+  static_assert(A_INSTR % NW == 0 && G >= 1, "tile must split evenly");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_toff = (int*)(smem + NST * STAGE);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid % WM, wn = wid / WM;
+  const int ntn = p.CoutPad / BN, nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = bid / ntn, nt = bid - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  if (tid == 0) {
+#pragma unroll
+    for (int t = 0; t < MAX_TAPS; ++t)
+      if (t < p.T) s_toff[t] = ((p.dy[t] * p.Win + p.dx[t]) * p.ldin + p.tap_pad) * 2;
+  }
+  const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
+  const int Ktot = p.T * p.Cin;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+  const int lrow = lane / CPR, cpos = lane % CPR;
+  int a_voff[A_PER], b_voff[B_PER], b_instr[B_PER];
+  unsigned a_valid[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int row = (wid * A_PER + i) * R + lrow;
+    const int m = m0 + row;
+    unsigned vm = 0;
+    int voff = OOB_VOFF;
+    if (m < p.M) {
+      const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+      const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+      const int iy0 = yy * p.sin, ix0 = xx * p.sin;
+      voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ swz<BK>(row)) * 8) * 2;
+#pragma unroll
+      for (int t = 0; t < MAX_TAPS; ++t) {
+        const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
+        const bool ok = t < p.T && (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
+        vm |= ok ? (1u << t) : 0u;
+      }
+    }
+    a_voff[i] = voff;
+    a_valid[i] = vm;
+  }
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int instr = (wid * B_PER + i) % B_INSTR;
+    const int row = instr * R + lrow;
+    b_instr[i] = instr;
+    b_voff[i] = (row * Ktot + (cpos ^ swz<BK>(row)) * 8) * 2;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  const int ksteps = Ktot / BK, cin_steps = p.Cin / BK;
+  int pf_t = 0, pf_c = 0;
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  // one piece q of stage s into buffer `buf`; `live` false -> out-of-range offsets (zero fill, no memory traffic)
+  auto piece = [&](int q, int s, int soff, int tap, int buf, bool live) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + BM * ROWB;
+    if (q < A_PER) {
+      const bool ok = live && ((a_valid[q] >> tap) & 1u);
+      bufld16(rsrc_x, sa + (wid * A_PER + q) * 1024, ok ? a_voff[q] : OOB_VOFF, soff);
+    } else {
+      bufld16(rsrc_w, sb + b_instr[q - A_PER] * 1024, live ? b_voff[q - A_PER] : OOB_VOFF, s * (BK * 2));
+    }
+  };
+  {
+    const int soff = __builtin_amdgcn_readfirstlane(s_toff[0]);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) piece(q, 0, soff, 0, 0, true);
+    if (++pf_c == cin_steps) {
+      pf_c = 0;
+      ++pf_t;
+    }
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int s = 0; s < ksteps; ++s) {
+    const int buf = s & 1;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const bool live = s + 1 < ksteps;
+    const int tap = live ? pf_t : 0;
+    const int soff = __builtin_amdgcn_readfirstlane(s_toff[tap]) + pf_c * (BK * 2);
+    if (++pf_c == cin_steps) {
+      pf_c = 0;
+      ++pf_t;
+    }
+    const char* sa = smem + buf * STAGE;
+    const char* sb = sa + BM * ROWB;
+    bf16x8_t wf[KS][TN], af[KS][TM];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * (TN * 16) + i * 16 + fr;
+        wf[ks][i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm * (TM * 16) + j * 16 + fr;
+        af[ks][j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+          const int cnt = (ks * TN + i) * TM + j + 1;
+          if (cnt % G == 0 && cnt / G - 1 < PER) piece(cnt / G - 1, s + 1, soff, tap, buf ^ 1, live);
+        }
+    if (SCHED == 1) {
+      // ask the scheduler for: all DS reads first, then G MFMAs / 1 LDS-DMA piece alternating
+      __builtin_amdgcn_sched_group_barrier(0x100, KS * (TN + TM), 0);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x8, G, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
+}
+
 // Warp-specialised variant: LW dedicated LOADER waves drive the LDS-DMA ring while the WM x WN CONSUMER waves only
 // read fragments and issue MFMAs.  Measured on the unified kernel above: a wave spends ~740 cycles per k-step issuing
 // its 8 LDS-DMA pieces (the CU's texture-address path is saturated meanwhile) and ~930 cycles in ds_read+MFMA, one
@@ -747,6 +900,23 @@ int launch_ws(const IgemmParams& p, hipStream_t st) {
   return check_launch("igemm_ws");
 }
 
+template <int WM, int WN, int TM, int TN, int BK, int EPI, int SCHED>
+int launch_il(const IgemmParams& p, hipStream_t st) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int lds_ring = 2 * (BM + BN) * BK * 2 + 64;
+  constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
+  constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
+  auto k = igemm_il_kernel<WM, WN, TM, TN, BK, EPI, SCHED>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
+  return check_launch("igemm_il");
+}
+
 int g_tune = 0;   // bring-up knob (mi355det_debug_set(0, v)): forces a tile configuration
 std::unordered_map<unsigned long long, int> g_igemm_tuned;   // shape key -> configuration found by mi355det_conv_autotune
 
@@ -763,6 +933,7 @@ unsigned long long igemm_key(const IgemmParams& p, int epi) {
 // tile configurations for Cout % 128 == 0 and Cin % 64 == 0 (pixels x channels x k-step, ring depth):
 //   1: 128x128x64 x2, 4 waves of 64x64, 2 workgroups/CU        2: 256x128x32 x2, 4 waves of 128x64, 48 KB
 //   3: 256x256x64 x2, 8 waves of 128x64, 1 workgroup/CU        4: 128x128x32 x3, 4 waves of 64x64, 3 workgroups/CU
+//   5: 128x128x32 x2 at 4 workgroups/CU                         6: 256x256x64 with LDS-DMA pieces interleaved between MFMAs
 template <int EPI>
 int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
   switch (cfg) {
@@ -778,10 +949,15 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 12: return launch_ws<2, 2, 8, 4, 64, 3, 2, EPI>(p, st);   // ws 256x128x64 ring 3 (144 KB), 2 loaders
     case 13: return launch_ws<2, 2, 8, 4, 64, 3, 4, EPI>(p, st);   // ws 256x128x64 ring 3, 4 loaders
     case 14: return launch_ws<2, 2, 4, 4, 32, 4, 2, EPI>(p, st);   // ws 128x128x32 ring 4 (64 KB, 2 WG/CU), 2 loaders
-    case 6: return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 3>(p, st);   // 64 KB: still 2/CU by LDS, tighter regs
+    case 6: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 0>(p, st); break;   // interleaved 256x256x64, 8 waves of 128x64
     case 21: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 1>(p, st); break;   // ablations of cfg 1
     case 22: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 2>(p, st); break;
     case 23: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 3>(p, st); break;
+    case 41: return launch_il<2, 2, 4, 4, 64, EPI, 0>(p, st);    // interleaved 128x128x64
+    case 42: return launch_il<2, 2, 4, 4, 64, EPI, 1>(p, st);    // + sched_group_barrier pattern
+    case 43: return launch_il<2, 2, 8, 4, 64, EPI, 0>(p, st);    // interleaved 256x128x64 (wave 128x64), 96 KB
+    case 44: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 0>(p, st); break;   // interleaved 256x256x64, 8 waves
+    case 45: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 1>(p, st); break;
     case 31: if (EPI == EPI_PLAIN) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, true>(p, st); break;   // interleaved issue
     case 25: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 5>(p, st); break;
     case 99: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, true>(p, st); break;   // phase-stamp diagnostic build
@@ -815,8 +991,8 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
   float best_ms = 1e30f;
-  for (int cfg = 1; cfg <= 5; ++cfg) {
-    if (cfg == 3 && p.CoutPad % 256 != 0) continue;
+  for (int cfg = 1; cfg <= 6; ++cfg) {
+    if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
     int e = run_cfg<EPI>(cfg, p, st);
     if (e) return e;
     (void)hipEventRecord(e0, st);
