@@ -232,6 +232,18 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
 size_t mi355det_dgrad_pack_elems(const mi355det_conv_shape* s);
 int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is_ohwi, void* w_fwd,
                           int32_t cout_pad, void* w_dgrad, void* stream);
+/* Batched form: all layers of a model re-packed by ONE launch per step.  The host table (entries + block table) is
+ * built once from `items`, copied to the device by the caller, and replayed with mi355det_pack_weights_batched. */
+typedef struct {
+  const float* w;      /* device fp32 master */
+  void* w_fwd;         /* device bf16 forward pack or NULL */
+  void* w_dgrad;       /* device bf16 dgrad pack or NULL */
+  mi355det_conv_shape shape;
+  int32_t cout_pad, w_is_ohwi;
+} mi355det_pack_item;
+size_t mi355det_pack_table_bytes(const mi355det_pack_item* items, int32_t n, int32_t* n_entries, int32_t* n_blocks);
+int mi355det_pack_table_build(const mi355det_pack_item* items, int32_t n, void* host_table, size_t host_bytes);
+int mi355det_pack_weights_batched(const void* dev_table, int32_t n_entries, int32_t n_blocks, void* stream);
 /* dw fp32 [cout][k][k][cin] -> torch layout [cout][cin][k][k] (param.grad) */
 int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* grad, void* stream);
 

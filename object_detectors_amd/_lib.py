@@ -36,6 +36,10 @@ class ConvShape(C.Structure):
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("in_ld", i32), ("out_ld", i32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("shape", ConvShape), ("cout_pad", i32), ("w_is_ohwi", i32)]
+
+
 P = C.POINTER
 PROTOTYPES = {
     # name: (restype, argtypes)
@@ -70,6 +74,9 @@ PROTOTYPES = {
     "mi355det_conv_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, vp, sz, vp]),
     "mi355det_dgrad_pack_elems": (sz, [P(ConvShape)]),
     "mi355det_pack_weights": (C.c_int, [P(ConvShape), vp, C.c_int, vp, i32, vp, vp]),
+    "mi355det_pack_table_bytes": (sz, [P(PackItem), i32, P(i32), P(i32)]),
+    "mi355det_pack_table_build": (C.c_int, [P(PackItem), i32, vp, sz]),
+    "mi355det_pack_weights_batched": (C.c_int, [vp, i32, i32, vp]),
     "mi355det_unpack_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp]),
     "mi355det_conv_autotune_mode": (C.c_int, [C.c_int]),
     "mi355det_conv_stats_rows": (C.c_int, [P(ConvShape), i32]),

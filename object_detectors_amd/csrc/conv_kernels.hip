@@ -1162,6 +1162,116 @@ int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is
   return check_launch("pack_weights");
 }
 
+// ---- batched packing: every layer of a model in ONE launch (a step re-packs ~75 layers; 130 tiny launches cost
+// ~1 ms of pure launch latency).  The host builds two tables once: entries (one per forward pack / dgrad class) and a
+// block table (entry, first element) so that each workgroup converts one 4096-element chunk of one entry.
+struct PackEntry {
+  const float* src;
+  bf16_t* dst;
+  long long s_co, s_ci, s_t;
+  int total, rows_valid, cin, kk, ntaps, mode, cdim, pad0;   // mode 0: fwd [rows_pad][kk][cin]; 1: dgrad [cin_pad][ntaps][cout]
+  int taps[9];
+  int pad1;
+};
+#define PACK_CHUNK 4096
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ entries, const int2* __restrict__ blocks) {
+  const int2 bt = blocks[blockIdx.x];
+  const PackEntry e = entries[bt.x];
+  const int end = min(e.total, bt.y + PACK_CHUNK);
+  for (int i = bt.y + threadIdx.x; i < end; i += 256) {
+    float v = 0.f;
+    if (e.mode == 0) {
+      const int c = i % e.cin, t = (i / e.cin) % e.kk, co = i / (e.cin * e.kk);
+      if (co < e.rows_valid) v = e.src[co * e.s_co + c * e.s_ci + t * e.s_t];
+    } else {
+      const int co = i % e.cdim, j = (i / e.cdim) % e.ntaps, ci = i / (e.cdim * e.ntaps);
+      int tap = e.taps[0];
+#pragma unroll
+      for (int q = 1; q < 9; ++q)
+        if (j == q) tap = e.taps[q];
+      if (ci < e.rows_valid) v = e.src[co * e.s_co + ci * e.s_ci + tap * e.s_t];
+    }
+    e.dst[i] = f2bf(v);
+  }
+}
+
+size_t mi355det_pack_table_bytes(const mi355det_pack_item* items, int32_t n, int32_t* n_entries, int32_t* n_blocks) {
+  int ne = 0;
+  long long nb = 0;
+  for (int i = 0; i < n; ++i) {
+    const mi355det_conv_shape* s = &items[i].shape;
+    const int kk = s->ksize * s->ksize;
+    if (items[i].w_fwd) {
+      ++ne;
+      nb += ((long long)items[i].cout_pad * kk * s->cin + PACK_CHUNK - 1) / PACK_CHUNK;
+    }
+    if (items[i].w_dgrad) {
+      const int cin_pad = (s->cin + 31) / 32 * 32;
+      const int classes = s->stride == 1 ? 1 : 4;
+      for (int c = 0; c < classes; ++c) {
+        int ft[9], dy[9], dx[9];
+        const int nt = dgrad_taps(s, c >> 1, c & 1, ft, dy, dx);
+        ++ne;
+        nb += ((long long)cin_pad * nt * s->cout + PACK_CHUNK - 1) / PACK_CHUNK;
+      }
+    }
+  }
+  if (n_entries) *n_entries = ne;
+  if (n_blocks) *n_blocks = (int)nb;
+  return (size_t)ne * sizeof(PackEntry) + (size_t)nb * sizeof(int2);
+}
+
+int mi355det_pack_table_build(const mi355det_pack_item* items, int32_t n, void* host_table, size_t host_bytes) {
+  int ne = 0, nb = 0;
+  const size_t need = mi355det_pack_table_bytes(items, n, &ne, &nb);
+  if (host_bytes < need) return fail(MI355DET_EWORKSPACE, "%s: host table too small", "pack_table_build");
+  PackEntry* E = (PackEntry*)host_table;
+  int2* B = (int2*)((char*)host_table + (size_t)ne * sizeof(PackEntry));
+  int ei = 0, bi = 0;
+  auto add_blocks = [&](int entry, long long total) {
+    for (long long o = 0; o < total; o += PACK_CHUNK) B[bi++] = make_int2(entry, (int)o);
+  };
+  for (int i = 0; i < n; ++i) {
+    const mi355det_conv_shape* s = &items[i].shape;
+    if (int e = check_shape(s, "pack_table_build")) return e;
+    const int kk = s->ksize * s->ksize;
+    const long long s_co = (long long)s->cin * kk, s_ci = items[i].w_is_ohwi ? 1 : kk, s_t = items[i].w_is_ohwi ? s->cin : 1;
+    if (items[i].w_fwd) {
+      PackEntry& e = E[ei];
+      e = PackEntry{};
+      e.src = items[i].w; e.dst = (bf16_t*)items[i].w_fwd; e.s_co = s_co; e.s_ci = s_ci; e.s_t = s_t;
+      e.total = items[i].cout_pad * kk * s->cin; e.rows_valid = s->cout; e.cin = s->cin; e.kk = kk; e.mode = 0;
+      add_blocks(ei++, e.total);
+    }
+    if (items[i].w_dgrad) {
+      const int cin_pad = (s->cin + 31) / 32 * 32;
+      bf16_t* out = (bf16_t*)items[i].w_dgrad;
+      const int classes = s->stride == 1 ? 1 : 4;
+      for (int c = 0; c < classes; ++c) {
+        int ft[9] = {0}, dy[9], dx[9];
+        const int nt = dgrad_taps(s, c >> 1, c & 1, ft, dy, dx);
+        PackEntry& e = E[ei];
+        e = PackEntry{};
+        e.src = items[i].w; e.dst = out; e.s_co = s_co; e.s_ci = s_ci; e.s_t = s_t;
+        e.total = cin_pad * nt * s->cout; e.rows_valid = s->cin; e.cin = s->cin; e.kk = kk; e.ntaps = nt; e.mode = 1; e.cdim = s->cout;
+        for (int q = 0; q < 9; ++q) e.taps[q] = ft[q];
+        add_blocks(ei++, e.total);
+        out += e.total;
+      }
+    }
+  }
+  return 0;
+}
+
+int mi355det_pack_weights_batched(const void* dev_table, int32_t n_entries, int32_t n_blocks, void* stream) {
+  if (!dev_table || n_entries <= 0 || n_blocks <= 0) return fail(MI355DET_EINVAL, "%s: bad table", "pack_weights_batched");
+  const PackEntry* E = (const PackEntry*)dev_table;
+  const int2* B = (const int2*)((const char*)dev_table + (size_t)n_entries * sizeof(PackEntry));
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(n_blocks), dim3(256), 0, S(stream), E, B);
+  return check_launch("pack_weights_batched");
+}
+
 int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* grad, void* stream) {
   if (int e = check_shape(s, "unpack_wgrad")) return e;
   const int kk = s->ksize * s->ksize;

@@ -40,12 +40,22 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.handles = []
+        self.side_stream = None
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self.use_avg = backend == "nccl"
 
     def reduce_slice(self, lo, hi):
         if self.world == 1:
             return
+        if self.side_stream is not None:
+            # weight gradients are produced on the plan's side stream (which is ordered behind the BN-parameter gradients
+            # of the same layers on the main stream): launch the collective from there
+            with torch.cuda.stream(self.side_stream):
+                self._reduce(lo, hi)
+        else:
+            self._reduce(lo, hi)
+
+    def _reduce(self, lo, hi):
         t = self.flat[lo:hi]
         if self.use_avg:
             self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
@@ -75,4 +85,5 @@ class GradSync:
         plan.bwd_base = base
         plan.bwd = calls
         plan._gradsync = self
+        self.side_stream = getattr(plan, "side_stream", None)
         self.buckets = buckets

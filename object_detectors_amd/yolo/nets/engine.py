@@ -392,15 +392,24 @@ class Plan:
         self.ops.append(dict(kind="up", x=t, cat=self.cat2, c_up=128, skip_to=feats[3]))
         branch("embedding2", self.cat2, 2)
 
-        # ---- weight packing (every step: the optimizer changes the fp32 masters)
-        for s in eng.specs:
+        # ---- weight packing (every step: the optimizer changes the fp32 masters) — one batched launch
+        items = (_lib.PackItem * len(eng.specs))()
+        for i, s in enumerate(eng.specs):
             shp = eng._wshape(s, 1, 8, 8)
             wf, wd = eng.packed[s.name]
-            cp = ops.cout_pad_of(shp.cout)
-            self.keep.append(shp)
             need_d = training and wd is not None
-            self.pack.append((L.mi355det_pack_weights, (C.byref(shp), _vp(eng.params[s.name + ".weight"]), 1, _vp(wf), cp,
-                                                        _vp(wd) if need_d else None, self.stream)))
+            items[i].w = eng.params[s.name + ".weight"].data_ptr()
+            items[i].w_fwd = wf.data_ptr()
+            items[i].w_dgrad = wd.data_ptr() if need_d else None
+            items[i].shape = shp
+            items[i].cout_pad = ops.cout_pad_of(shp.cout)
+            items[i].w_is_ohwi = 1
+        ne, nb = C.c_int32(0), C.c_int32(0)
+        nbytes = L.mi355det_pack_table_bytes(items, len(eng.specs), C.byref(ne), C.byref(nb))
+        host = torch.empty(nbytes, dtype=torch.uint8)
+        check(L.mi355det_pack_table_build(items, len(eng.specs), C.c_void_p(host.data_ptr()), nbytes), "pack_table_build")
+        self.pack_table = host.to(dev)
+        self.pack.append((L.mi355det_pack_weights_batched, (_vp(self.pack_table), ne.value, nb.value, self.stream)))
         if training:
             self._build_backward()
             self._autotune()
@@ -409,7 +418,19 @@ class Plan:
     def _build_backward(self):
         eng, L, dev = self.eng, lib(), self.eng.device
         bf = torch.bfloat16
-        self.dz = torch.zeros(self.dz_elems, device=dev, dtype=bf)
+        # two dz buffers (ping-pong) so the weight-gradient GEMM of layer L can run on a SECOND stream while the main
+        # stream already does the BN backward / dgrad of the next layers: wgrad is off the dependency chain
+        # (reduce -> apply -> dgrad), and the HBM-bound BN passes overlap with its MFMA work.
+        self.dz2 = [torch.zeros(self.dz_elems, device=dev, dtype=bf) for _ in range(2)]
+        self.dz = self.dz2[0]
+        self.side = torch.cuda.Stream(device=dev)
+        side_ptr = C.c_void_p(self.side.cuda_stream)
+        main = torch.cuda.current_stream(dev)
+        wg_done = [None, None]        # event: last wgrad that read dz2[i]
+        flip = [0]
+
+        def py(fn, *a):
+            self.bwd.append((comm_hook, (fn,) + a))
         ws_need = max(L.mi355det_conv_wgrad_workspace(C.byref(r["shp_f"] if r["kind"] == "out" else r["shp"]))
                       for r in self.ops if r["kind"] in ("cbl", "out"))
         self.wgrad_ws = torch.empty(max(ws_need, 16), device=dev, dtype=torch.uint8)
@@ -449,8 +470,11 @@ class Plan:
                 shp, shp_f, x, k, name = rec["shp"], rec["shp_f"], rec["x"], rec["k"], rec["name"]
                 _, wd = eng.packed[name]
                 dy = _vp(self.head_grads[k])
+                ev = torch.cuda.Event()
+                py(ev.record, main)                       # head gradients ready (criterion ran on the main stream)
+                py(self.side.wait_event, ev)
                 self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp_f), x.ptr, dy, _vp(eng.grads[name + ".weight"]),
-                                                         _vp(eng.grads[name + ".bias"]), ws_ptr, ws_bytes, self.stream)))
+                                                         _vp(eng.grads[name + ".bias"]), ws_ptr, ws_bytes, side_ptr)))
                 emit_dgrad(shp, dy, wd, x)
             elif rec["kind"] == "up":
                 x, cat, c_up, skip_to = rec["x"], rec["cat"], rec["c_up"], rec["skip_to"]
@@ -469,18 +493,32 @@ class Plan:
                 sum_off[0] += 2 * shp.cout
                 if res is not None:
                     res.skips.append(g)
+                di = flip[0]
+                flip[0] ^= 1
+                dzb = self.dz2[di]
                 self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
                                                                 _vp(sums), self.stream)))
+                if wg_done[di] is not None:
+                    py(main.wait_event, wg_done[di])      # the wgrad that last read this dz buffer has finished
                 self.bwd.append((L.mi355det_bn_act_bwd_apply, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), _vp(sums), None, shp.cout,
-                                                               pixels, SLOPE, _vp(self.dz), shp.cout, _vp(eng.grads[b + ".weight"]),
+                                                               pixels, SLOPE, _vp(dzb), shp.cout, _vp(eng.grads[b + ".weight"]),
                                                                _vp(eng.grads[b + ".bias"]), self.stream)))
-                self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(self.dz), _vp(eng.grads[name + ".weight"]), None,
-                                                         ws_ptr, ws_bytes, self.stream)))
+                ev_dz, ev_wg = torch.cuda.Event(), torch.cuda.Event()
+                py(ev_dz.record, main)
+                py(self.side.wait_event, ev_dz)
+                self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
+                                                         ws_ptr, ws_bytes, side_ptr)))
+                py(ev_wg.record, self.side)
+                wg_done[di] = ev_wg
                 if name != "backbone.conv1":
                     _, wd = eng.packed[name]
-                    emit_dgrad(shp, _vp(self.dz), wd, x)
+                    emit_dgrad(shp, _vp(dzb), wd, x)
             if rec["kind"] in ("out", "cbl"):
                 self.bwd_marks.append((len(self.bwd), first_off[rec["name"] + ".weight"]))
+        ev_end = torch.cuda.Event()
+        py(ev_end.record, self.side)
+        py(main.wait_event, ev_end)                       # join: backward is complete on the main stream
+        self.side_stream = self.side
 
     def _autotune(self):
         """Plan-build time only: let the library time its candidate tile configurations / split counts for every
@@ -555,6 +593,7 @@ class Plan:
     def run_backward(self):
         self.eng.flat_g.zero_()
         self.sums_all.zero_()
+        self.side.wait_stream(torch.cuda.current_stream())   # zeroed gradients / forward activations visible to the side stream
         self._run(self.bwd)
 
 

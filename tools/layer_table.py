@@ -1,0 +1,45 @@
+"""Per-shape time table (fwd / dgrad / wgrad) of the last step in a rocprofv3 kernel trace of bench.py."""
+import csv, glob, sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detectors_amd.yolo.nets.engine import arch
+path = sys.argv[1]
+rows = list(csv.DictReader(open(glob.glob(path + '/**/*kernel_trace.csv', recursive=True)[0])))
+idx = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name']]
+last = rows[idx[-1]:]
+specs = arch()
+def hw(s):
+    n = s.name
+    if n == 'backbone.conv1': return 640
+    if n.startswith('backbone.layer'): return 640 >> int(n[len('backbone.layer')])
+    if n.startswith('embedding0') or n.startswith('embedding1_cbl'): return 20
+    if n.startswith('embedding1') or n.startswith('embedding2_cbl'): return 40
+    return 80
+def dur(r): return (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+fw = [r for r in last if 'igemm' in r['Kernel_Name'] and (', 0, ' in r['Kernel_Name'].split('igemm')[1][:60] or True)]
+# forward igemm launches = first 75 igemm-family kernels of the step (before any wgrad)
+first_w = next(i for i, r in enumerate(last) if 'wgrad_kernel' in r['Kernel_Name'])
+fwd = [r for r in last[:first_w] if 'igemm' in r['Kernel_Name']][:75]
+bwd = last[first_w - 10:]
+wg = [r for r in last if 'wgrad_kernel' in r['Kernel_Name']]
+agg = collections.OrderedDict()
+for s, r in zip(specs, fwd):
+    k = (s.cin, s.cout, s.k, s.stride, hw(s)); a = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dur(r)
+    kk = 27 if s.name == 'backbone.conv1' else s.cin * s.k * s.k
+    a[4] += 2.0 * 32 * hw(s) ** 2 * s.cout * kk
+for s, r in zip(reversed(specs), wg):
+    agg[(s.cin, s.cout, s.k, s.stride, hw(s))][3] += dur(r)
+# dgrad: igemm kernels after the first wgrad, grouped per layer in backward order (stride-2 layers have 4 launches)
+dg = [r for r in last[first_w:] if 'igemm' in r['Kernel_Name']]
+it = iter(dg)
+for s in reversed(specs):
+    if s.name == 'backbone.conv1': continue
+    n = 4 if s.stride == 2 else 1
+    t = sum(dur(next(it)) for _ in range(n))
+    agg[(s.cin, s.cout, s.k, s.stride, hw(s))][2] += t
+print(f"{'cin->cout k s @hw':28s} {'n':>3s} {'fwd us':>8s} {'TF':>6s} {'dgrad':>8s} {'TF':>6s} {'wgrad':>8s} {'TF':>6s}  tot ms")
+tot = [0, 0, 0]
+for k, (n, f, d, w, fl) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2] + kv[1][3])):
+    tf = lambda t: fl / t / 1e6 if t else 0
+    print(f"{k[0]:4d}->{k[1]:4d} k{k[2]} s{k[3]} @{k[4]:3d}       {n:3d} {f / n:8.1f} {tf(f):6.0f} {d / n:8.1f} {tf(d):6.0f} {w / n:8.1f} {tf(w):6.0f}  {(f + d + w) / 1e3:6.2f}")
+    tot[0] += f; tot[1] += d; tot[2] += w
+print('totals ms: fwd %.2f dgrad %.2f wgrad %.2f' % tuple(t / 1e3 for t in tot))
