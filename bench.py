@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--px", type=int, default=640)
+    ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (pure timing run)")
     args = ap.parse_args()
@@ -104,6 +105,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.parallel import GradSync
     from object_detectors_amd.yolo.nets.engine import YoloV3Engine
     from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
@@ -112,6 +114,9 @@ def main():
     crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=args.px).to(dev)
     imgs, targets = synth_batch(args.batch, args.px, rank, dev)
     sync = GradSync(eng.flat_g) if world > 1 else None
+    # the reference's optimizer (yolo/hydra/optimizer/sgd.yaml: momentum 0.9, weight decay 5e-4) as one fused kernel over
+    # the flat buffers; the step is inside the timed region (train_one_epoch.py:96)
+    opt = FlatSGD.for_engine(eng, lr=args.lr, momentum=0.9, weight_decay=5e-4)
 
     def step():
         if sync is not None:
@@ -119,6 +124,7 @@ def main():
         out12 = eng.train_step(imgs, targets, crit)
         if sync is not None:
             sync.wait()
+        opt.step()
         return out12
 
     for _ in range(max(1, args.warmup)):
@@ -185,7 +191,7 @@ def main():
             "metric": "images/sec (fwd+bwd) YOLOv3 640px bs=32", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+bwd{'+grad all-reduce' if world > 1 else ''}), "
+            "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+loss+bwd{'+grad all-reduce' if world > 1 else ''}+SGD step), "
                                    f"synthetic COCO {args.px}px, per-GPU bs={args.batch}, 7 GT/img, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss_first": round(loss0, 4), "loss_last": round(loss1, 4),

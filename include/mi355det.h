@@ -279,6 +279,17 @@ int mi355det_upsample2x_fwd(const void* x, int32_t x_ld, int32_t n, int32_t h, i
 int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out,
                             int32_t out_ld, void* stream);
 
+/* ---- fused optimizer step on the flat fp32 buffers --------------------------------------------------
+ * Replaces torch.optim.SGD / Adam .step() (+ zero_grad) of yolo/procedures/initialize.py:38,41 and
+ * yolo/procedures/train_one_epoch.py:96: one pass over {param, grad, state}.  grad_scale = 1/loss_scale (apex amp,
+ * train_one_epoch.py:89) folded in.  first_step: momentum buffer is initialised with the gradient (torch semantics). */
+int mi355det_sgd_step(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                      float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream);
+int mi355det_adam_step(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, float grad_scale, int32_t step, int zero_grad,
+                       void* stream);
+
+
 /* layout / dtype converters at the module boundary */
 int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h,
                               int32_t w, float* out, void* stream);

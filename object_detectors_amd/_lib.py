@@ -83,6 +83,8 @@ PROTOTYPES = {
     "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "mi355det_bn_eval_scale_shift": (C.c_int, [i32, vp, vp, vp, vp, f32, vp, vp]),
+    "mi355det_sgd_step": (C.c_int, [vp, vp, vp, i64] + [C.c_float] * 5 + [C.c_int] * 3 + [vp]),
+    "mi355det_adam_step": (C.c_int, [vp, vp, vp, vp, i64] + [C.c_float] * 6 + [i32, C.c_int, vp]),
     "mi355det_add_bf16": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, i32, vp]),
     "mi355det_bn_act_fwd": (C.c_int, [vp, i32, vp, i32, i64, f32, vp, i32, vp, i32, vp]),
     "mi355det_bn_act_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, f32, vp, vp]),

@@ -325,6 +325,59 @@ inline int grid_for(long long total) { return (int)min((long long)256 * 16, (tot
 
 }  // namespace
 
+
+// ---- fused optimizer steps on the flat fp32 parameter / gradient buffers ------------------------------------------------------
+// torch.optim.SGD (yolo/procedures/initialize.py:38) and torch.optim.Adam (initialize.py:41) semantics, one pass over
+// {w, g, state}: 16-B accesses, grid-stride.  HBM bound: 20 B/param (SGD), 28 B/param (Adam).
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ mom, long long n4, long long n,
+                                                   float lr, float momentum, float dampening, float wd, float gscale, int nesterov, int first,
+                                                   int zero_grad) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 wv = ((const float4*)w)[i], gv = ((const float4*)g)[i], mv = ((const float4*)mom)[i];
+    float* wp = (float*)&wv; float* gp = (float*)&gv; float* mp = (float*)&mv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = gp[j] * gscale + wd * wp[j];
+      if (momentum != 0.f) {
+        mp[j] = first ? d : momentum * mp[j] + (1.f - dampening) * d;
+        d = nesterov ? d + momentum * mp[j] : mp[j];
+      }
+      wp[j] -= lr * d;
+    }
+    ((float4*)w)[i] = wv;
+    ((float4*)mom)[i] = mv;
+    if (zero_grad) ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // tail (n not a multiple of 4)
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float d = g[i] * gscale + wd * w[i];
+    if (momentum != 0.f) {
+      mom[i] = first ? d : momentum * mom[i] + (1.f - dampening) * d;
+      d = nesterov ? d + momentum * mom[i] : mom[i];
+    }
+    w[i] -= lr * d;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                                                    float lr, float b1, float b2, float eps, float wd, float gscale, float bc1, float bc2_sqrt,
+                                                    int zero_grad) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float wi = w[i];
+    const float d = g[i] * gscale + wd * wi;
+    const float mi = b1 * m[i] + (1.f - b1) * d;
+    const float vi = b2 * v[i] + (1.f - b2) * d * d;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w[i] = wi - (lr / bc1) * (mi / denom);
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
 extern "C" {
 
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
@@ -422,6 +475,26 @@ int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_
   else
     hipLaunchKernelGGL(nhwc_to_nchw_kernel<false>, dim3(grid_for(total)), dim3(256), 0, S(stream), x, x_ld, n, c, h * w, out);
   return check_launch("nhwc_to_nchw_f32");
+}
+
+int mi355det_sgd_step(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening, float weight_decay,
+                      float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
+  if (n <= 0) return MI355DET_OK;
+  if (((uintptr_t)w | (uintptr_t)g | (uintptr_t)momentum_buf) & 15) return fail(MI355DET_EINVAL, "%s: buffers must be 16-byte aligned", "sgd_step");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, S(stream), w, g, momentum_buf, (long long)(n / 4), (long long)n, lr, momentum,
+                     dampening, weight_decay, grad_scale, nesterov, first_step, zero_grad);
+  return check_launch("sgd_step");
+}
+
+int mi355det_adam_step(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float grad_scale, int32_t step, int zero_grad, void* stream) {
+  if (n <= 0) return MI355DET_OK;
+  if (step < 1) return fail(MI355DET_EINVAL, "%s: step counts from 1", "adam_step");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, g, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps,
+                     weight_decay, grad_scale, bc1, bc2s, zero_grad);
+  return check_launch("adam_step");
 }
 
 }  // extern "C"

@@ -228,3 +228,31 @@ def test_yolohead_module_autograd_and_fused_step():
     for k, v in m2.state_dict().items():
         assert torch.equal(v.cpu(), sd[k].cpu()), k
     assert list(sd.keys()) == [k for k, _ in net_oracle.state_keys("darknet_21")]
+
+
+@pytest.mark.gpu
+def test_flat_optimizers_match_torch():
+    """mi355det_sgd_step / adam_step vs torch.optim.SGD / Adam (initialize.py:38,41) over several steps."""
+    from object_detectors_amd.optim import FlatAdam, FlatSGD
+    torch.manual_seed(0)
+    n = 100003
+    w0 = torch.randn(n, device="cuda")
+    grads = [torch.randn(n, device="cuda") for _ in range(4)]
+    for kind in ("sgd", "sgd_nesterov", "adam"):
+        w = torch.zeros(n + 1, device="cuda")[:n]
+        w.copy_(w0)
+        g = torch.zeros_like(w)
+        ref = w0.clone().requires_grad_(True)
+        if kind == "adam":
+            mine = FlatAdam(w, g, lr=1e-2, weight_decay=5e-4)
+            theirs = torch.optim.Adam([ref], lr=1e-2, weight_decay=5e-4)
+        else:
+            mine = FlatSGD(w, g, lr=1e-2, momentum=0.9, weight_decay=5e-4, nesterov=kind.endswith("nesterov"))
+            theirs = torch.optim.SGD([ref], lr=1e-2, momentum=0.9, weight_decay=5e-4, nesterov=kind.endswith("nesterov"))
+        for gi in grads:
+            g.copy_(gi * 4.0)
+            ref.grad = gi.clone()
+            mine.step(grad_scale=0.25, zero_grad=True)
+            theirs.step()
+            assert float(g.abs().max()) == 0.0
+        torch.testing.assert_close(w, ref.detach(), rtol=2e-5, atol=2e-6)
