@@ -168,6 +168,19 @@ int mi355det_retina_cls_loss(const float* logits, const int64_t* matched, const 
                              const float* scale, int64_t rows, int32_t k, float alpha, float gamma,
                              float grad_scale, float* loss_sum, float* grad, void* stream);
 
+/* RetinaNetHead.compute_loss for a WHOLE batch in three launches (retinanet.py:56-62,107-143,196-223):
+ *   cls_logits [n_images, rows_per_image, k], bbox_regression [n_images, rows_per_image, 4] (the level-concatenated head
+ *   outputs), anchors [rows_per_image, 4] (same image size for the batch), matched [n_images, rows_per_image] int64
+ *   (Matcher output: >=0 GT index within the image, -1 background, -2 between thresholds), gt_boxes [sum M,4] /
+ *   gt_labels [sum M] packed over images with gt_offsets [n_images+1].
+ *   losses[0] = classification (focal sum / max(1,num_fg) averaged over images), losses[1] = bbox_regression (L1 on
+ *   BoxCoder(1,1,1,1) targets, same normalisation); num_fg [n_images] scratch/out; grads (nullable) = d(loss)*grad_scale. */
+int mi355det_retina_loss(const float* cls_logits, const float* bbox_regression, const float* anchors, const int64_t* matched,
+                         const float* gt_boxes, const int64_t* gt_labels, const int32_t* gt_offsets,
+                         const float* class_scale, int32_t n_images, int64_t rows_per_image, int32_t k, float alpha,
+                         float gamma, float grad_scale, float* num_fg, float* losses, float* grad_logits,
+                         float* grad_regression, void* stream);
+
 /* torchvision.ops.roi_align / MultiScaleRoIAlign (tvision/frcnn.py:208-211, roi_heads.py:818): NCHW fp32 features.
  *   feats/hs/ws/scales: HOST arrays of num_levels (1..4) device pointers / sizes / spatial scales; with several levels
  *   the LevelMapper (k = floor(4 + log2(sqrt(area)/224) + 1e-6) clamped to [k_min,k_max]) picks the level per RoI.
@@ -201,6 +214,20 @@ typedef struct {
  *   (fp32, row pitch 2*cout_pad, plain stores, deterministic) for training BatchNorm. */
 int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias,
                       void* y, int out_f32, float* stats, int32_t cout_pad, void* stream);
+/* Forward with a fused affine epilogue: y = relu?( conv(x,w) * scale[co] + shift[co] + residual ) — FrozenBatchNorm2d
+ * (+ReLU, + the Bottleneck identity add, utilities/resnet.py:116-141) or a plain bias (FPN / RetinaNet head convs,
+ * retinanet.py:86-97) without a separate elementwise pass. */
+typedef struct {
+  const float* scale;        /* [cout] or NULL (= 1) */
+  const float* shift;        /* [cout] or NULL (= 0) */
+  const void* residual;      /* bf16 [n,ho,wo,cout] with pixel pitch residual_ld, or NULL; bf16 outputs only */
+  int32_t residual_ld;
+  int32_t relu;              /* 1: ReLU after scale/shift/residual */
+  int64_t out_image_stride;  /* fp32 outputs: elements between images of y (0 = ho*wo*out_ld): heads write straight
+                                into the level-concatenated [N, sum HWA, K] tensor (retinanet.py:163-170) */
+} mi355det_conv_epilogue;
+int mi355det_conv_fwd_ex(const mi355det_conv_shape* s, const void* x, const void* w, const mi355det_conv_epilogue* e,
+                         void* y, int out_f32, int32_t cout_pad, void* stream);
 /* plan-build helper (synchronises; never part of the step): while the mode is on, mi355det_conv_fwd / _dgrad time
  * their candidate tile configurations on the caller's buffers and remember the fastest per shape. */
 int mi355det_conv_autotune_mode(int on);
@@ -278,6 +305,31 @@ int mi355det_upsample2x_fwd(const void* x, int32_t x_ld, int32_t n, int32_t h, i
                             int32_t out_ld, void* stream);
 int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out,
                             int32_t out_ld, void* stream);
+
+/* ---- ResNet-FPN / RetinaNet elementwise companions (csrc/resnet_kernels.hip) -------------------------------------------
+ * im2col_nchw: NCHW fp32 image, optional per-channel (x-mean)*inv_std (GeneralizedRCNNTransform.normalize,
+ *   tvision/transform.py:120-124) -> rows [n*ho*wo][kpad] bf16, k=(kh*ks+kw)*c+ch: the 7x7/2 stem (resnet.py:173) runs
+ *   as a 1x1 convolution with cin=kpad on the MFMA path.
+ * maxpool3x3s2: nn.MaxPool2d(3,2,1) (resnet.py:176).
+ * relu_affine_bwd: gm = (g1 [+g2]) * [a>0] (if relu), dz = gm * scale[c] (scale NULL = 1); gm / dz nullable.
+ * upsample_nearest_add: out = lateral + interpolate(x, size=(out_h,out_w), nearest) (FPN top-down); _bwd its adjoint
+ *   (out = accumulate + sum of g over the pixels that read it).
+ * cast_rows_bf16: dst[b][r][0..cols) = src[b*image_stride + r*row_stride + c] * mul, zero fill up to dst_ld. */
+int mi355det_im2col_nchw(const float* img, const float* mean, const float* inv_std, void* out, int32_t n, int32_t c,
+                         int32_t h, int32_t w, int32_t ksize, int32_t stride, int32_t pad, int32_t kpad, void* stream);
+int mi355det_maxpool3x3s2(const void* x, int32_t x_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out,
+                          int32_t out_ld, void* stream);
+int mi355det_relu_affine_bwd(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* a, int32_t a_ld,
+                             const float* scale, int32_t c, int64_t pixels, int relu, void* dz, int32_t dz_ld,
+                             void* gm, int32_t gm_ld, void* stream);
+int mi355det_upsample_nearest_add(const void* x, int32_t x_ld, int32_t n, int32_t h, int32_t w, int32_t c,
+                                  const void* lateral, int32_t lateral_ld, int32_t out_h, int32_t out_w, void* out,
+                                  int32_t out_ld, void* stream);
+int mi355det_upsample_nearest_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w, int32_t c, int32_t g_h,
+                                  int32_t g_w, const void* accumulate, int32_t accumulate_ld, void* out,
+                                  int32_t out_ld, void* stream);
+int mi355det_cast_rows_bf16(const float* src, int64_t src_image_stride, int64_t src_row_stride, int32_t n, int64_t rows,
+                            int32_t cols, float mul, void* dst, int32_t dst_ld, void* stream);
 
 /* ---- fused optimizer step on the flat fp32 buffers --------------------------------------------------
  * Replaces torch.optim.SGD / Adam .step() (+ zero_grad) of yolo/procedures/initialize.py:38,41 and

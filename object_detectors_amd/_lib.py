@@ -36,6 +36,10 @@ class ConvShape(C.Structure):
                 ("ksize", i32), ("stride", i32), ("pad", i32), ("in_ld", i32), ("out_ld", i32)]
 
 
+class ConvEpilogue(C.Structure):
+    _fields_ = [("scale", vp), ("shift", vp), ("residual", vp), ("residual_ld", i32), ("relu", i32), ("out_image_stride", i64)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("shape", ConvShape), ("cout_pad", i32), ("w_is_ohwi", i32)]
 
@@ -83,6 +87,14 @@ PROTOTYPES = {
     "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "mi355det_bn_eval_scale_shift": (C.c_int, [i32, vp, vp, vp, vp, f32, vp, vp]),
+    "mi355det_conv_fwd_ex": (C.c_int, [P(ConvShape), vp, vp, P(ConvEpilogue), vp, C.c_int, i32, vp]),
+    "mi355det_retina_loss": (C.c_int, [vp] * 8 + [i32, i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
+    "mi355det_im2col_nchw": (C.c_int, [vp, vp, vp, vp] + [i32] * 8 + [vp]),
+    "mi355det_maxpool3x3s2": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "mi355det_relu_affine_bwd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, C.c_int, vp, i32, vp, i32, vp]),
+    "mi355det_upsample_nearest_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]),
+    "mi355det_upsample_nearest_bwd": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
+    "mi355det_cast_rows_bf16": (C.c_int, [vp, i64, i64, i32, i64, i32, C.c_float, vp, i32, vp]),
     "mi355det_sgd_step": (C.c_int, [vp, vp, vp, i64] + [C.c_float] * 5 + [C.c_int] * 3 + [vp]),
     "mi355det_adam_step": (C.c_int, [vp, vp, vp, vp, i64] + [C.c_float] * 6 + [i32, C.c_int, vp]),
     "mi355det_add_bf16": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, i32, vp]),

@@ -463,7 +463,9 @@ template <int TGT_MODE>
 __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x, const float* __restrict__ t, const long long* __restrict__ matched,
                                                     const long long* __restrict__ gt_labels, const float* __restrict__ scale,
                                                     const unsigned char* __restrict__ valid, long long rows, int k, float alpha, float gamma,
-                                                    float gscale, float* __restrict__ loss_sum, float* __restrict__ grad) {
+                                                    float gscale, float* __restrict__ loss_sum, float* __restrict__ grad,
+                                                    const float* __restrict__ nfg = nullptr, long long rows_per_image = 0,
+                                                    const int* __restrict__ gt_off = nullptr, float inv_images = 1.f) {
   __shared__ float red[4];
   const long long total = rows * k;
   const bool vec = (total & 3) == 0;      // 4 consecutive elements per lane: 16-byte loads/stores of logits and gradients
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
     long long mi = 0, lab = -1;
     bool ok = true;
     bool fresh = true;
+    float wimg = 1.f;          // batched form: 1 / max(1, num_foreground of the row's image) / num_images (retinanet.py:141-143)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (e >= cnt) break;
@@ -497,7 +500,12 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
         else {
           mi = matched[r];
           ok = mi != -2;                                   // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135)
-          lab = mi >= 0 ? gt_labels[mi] : -1;
+          int b = 0;
+          if (nfg) {
+            b = (int)(r / rows_per_image);
+            wimg = inv_images / fmaxf(1.f, nfg[b]);
+          }
+          lab = mi >= 0 ? gt_labels[mi + (gt_off ? gt_off[b] : 0)] : -1;
         }
         fresh = false;
       }
@@ -507,8 +515,8 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
         const float sc = scale ? scale[c] : 1.0f;
         float l;
         sfl(sc * xv[e], tv, alpha, gamma, l, g);
-        acc += l;
-        g *= sc * gscale;
+        acc += l * wimg;
+        g *= sc * gscale * wimg;
       }
       gv[e] = g;
       if (++c == k) {
@@ -521,6 +529,55 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
       if (vec) *(float4*)(grad + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
       else grad[i0] = gv[0];
     }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- RetinaNet head losses for a whole batch (retinanet.py:56-62,107-143,196-223) ---------------------------------
+// nfg[b] = number of foreground anchors (matched >= 0) of image b
+__global__ __launch_bounds__(256) void count_fg_kernel(const long long* __restrict__ matched, long long rows_per_image, float* __restrict__ nfg) {
+  __shared__ float red[4];
+  const long long* m = matched + (long long)blockIdx.y * rows_per_image;
+  float c = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < rows_per_image; i += (long long)gridDim.x * 256) c += m[i] >= 0 ? 1.f : 0.f;
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(nfg + blockIdx.y, red[0] + red[1] + red[2] + red[3]);   // integer-valued floats: order independent
+}
+
+// L1 regression loss on the foreground anchors against BoxCoder.encode_single targets (weights 1,1,1,1; _utils.py:130-163)
+__global__ __launch_bounds__(256) void retina_reg_kernel(const float* __restrict__ pred, const float* __restrict__ anchors,
+                                                         const long long* __restrict__ matched, const float* __restrict__ gt_boxes,
+                                                         const int* __restrict__ gt_off, const float* __restrict__ nfg, int n_images,
+                                                         long long rows_per_image, float wx, float wy, float ww, float wh, float gscale,
+                                                         float* __restrict__ loss_sum, float* __restrict__ grad) {
+  __shared__ float red[4];
+  const long long total = (long long)n_images * rows_per_image;
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long mi = matched[i];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mi >= 0) {
+      const int b = (int)(i / rows_per_image);
+      const long long r = i - (long long)b * rows_per_image;
+      const float wimg = 1.f / fmaxf(1.f, nfg[b]) / (float)n_images;
+      const float4 a = *(const float4*)(anchors + r * 4);
+      const float4 q = *(const float4*)(gt_boxes + (mi + gt_off[b]) * 4);
+      const float4 pv = *(const float4*)(pred + i * 4);
+      const float ew = a.z - a.x, eh = a.w - a.y, ecx = a.x + 0.5f * ew, ecy = a.y + 0.5f * eh;
+      const float gw = q.z - q.x, gh = q.w - q.y, gcx = q.x + 0.5f * gw, gcy = q.y + 0.5f * gh;
+      const float t0 = wx * (gcx - ecx) / ew, t1 = wy * (gcy - ecy) / eh, t2 = ww * logf(gw / ew), t3 = wh * logf(gh / eh);
+      const float d0 = pv.x - t0, d1 = pv.y - t1, d2 = pv.z - t2, d3 = pv.w - t3;
+      acc += (fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3)) * wimg;
+      const float gs = gscale * wimg;
+      g = make_float4(d0 > 0.f ? gs : (d0 < 0.f ? -gs : 0.f), d1 > 0.f ? gs : (d1 < 0.f ? -gs : 0.f), d2 > 0.f ? gs : (d2 < 0.f ? -gs : 0.f),
+                      d3 > 0.f ? gs : (d3 < 0.f ? -gs : 0.f));
+    }
+    if (grad) *(float4*)(grad + i * 4) = g;
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = acc;
@@ -655,6 +712,29 @@ int mi355det_retina_cls_loss(const float* logits, const int64_t* matched, const 
                      (const long long*)gt_labels, scale, (const unsigned char*)nullptr, (long long)rows, k, alpha, gamma, grad_scale, loss_sum,
                      grad);
   return check_launch("retina_cls_loss");
+}
+
+int mi355det_retina_loss(const float* cls_logits, const float* bbox_regression, const float* anchors, const int64_t* matched,
+                         const float* gt_boxes, const int64_t* gt_labels, const int32_t* gt_offsets, const float* class_scale, int32_t n_images,
+                         int64_t rows_per_image, int32_t k, float alpha, float gamma, float grad_scale, float* num_fg, float* losses,
+                         float* grad_logits, float* grad_regression, void* stream) {
+  if (n_images <= 0 || rows_per_image <= 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "retina_loss");
+  if (!cls_logits || !bbox_regression || !anchors || !matched || !gt_boxes || !gt_labels || !gt_offsets || !num_fg || !losses)
+    return fail(MI355DET_EINVAL, "%s: null argument", "retina_loss");
+  hipStream_t st = S(stream);
+  (void)hipMemsetAsync(num_fg, 0, sizeof(float) * n_images, st);
+  (void)hipMemsetAsync(losses, 0, sizeof(float) * 2, st);
+  hipLaunchKernelGGL(count_fg_kernel, dim3((int)min((long long)64, (long long)((rows_per_image + 255) / 256)), n_images), dim3(256), 0, st,
+                     (const long long*)matched, (long long)rows_per_image, num_fg);
+  const long long rows = (long long)n_images * rows_per_image;
+  const int blocks = (int)min((long long)256 * 8, (long long)((rows * k + 255) / 256));
+  hipLaunchKernelGGL(focal_kernel<1>, dim3(blocks), dim3(256), 0, st, cls_logits, (const float*)nullptr, (const long long*)matched,
+                     (const long long*)gt_labels, class_scale, (const unsigned char*)nullptr, rows, k, alpha, gamma, grad_scale, losses, grad_logits,
+                     (const float*)num_fg, (long long)rows_per_image, (const int*)gt_offsets, 1.0f / (float)n_images);
+  hipLaunchKernelGGL(retina_reg_kernel, dim3((int)min((long long)2048, (rows + 255) / 256)), dim3(256), 0, st, bbox_regression, anchors,
+                     (const long long*)matched, gt_boxes, (const int*)gt_offsets, (const float*)num_fg, n_images, (long long)rows_per_image, 1.f, 1.f,
+                     1.f, 1.f, grad_scale, losses + 1, grad_regression);
+  return check_launch("retina_loss");
 }
 
 }  // extern "C"

@@ -44,7 +44,10 @@ struct IgemmParams {
   const bf16_t* x;       // input activations (fwd: x, dgrad: dy)
   const bf16_t* w;       // packed weights [CoutPad][T*Cin]
   void* y;               // output (bf16 or fp32)
-  const float* bias;     // EPI_F32
+  const float* bias;     // EPI_F32 / EPI_AFF: per-channel shift
+  const float* scale;    // EPI_F32 / EPI_AFF: per-channel multiplier on the accumulator or null (FrozenBatchNorm2d folded into the conv)
+  int relu;              // EPI_F32 / EPI_AFF: ReLU after (scale, shift, residual)
+  long long ynstride;    // EPI_F32: elements between images of y (heads write straight into the level-concatenated tensor)
   float* stats;          // EPI_STATS: [gridM][2][CoutPad] partial sum / sumsq
   const bf16_t* res;     // EPI_RES: residual to add
   const bf16_t* zero;    // >= 256 B of zeros
@@ -60,7 +63,7 @@ struct IgemmParams {
   unsigned long long* dbg;   // diagnostic build only (PROF): per-wave phase cycle sums
 };
 
-enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3 };
+enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4 };
 #define EPI_LDS_OFF 4096                               // epilogue staging starts behind the BN-statistics scratch
 #define EPI_LDS_BYTES(nwaves) (EPI_LDS_OFF + (nwaves) * (64 * (8 * 16 * 2 + 16) + 256))   // upper bound (TN <= 8)
 
@@ -157,15 +160,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
       const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
       if (oy >= p.Hout || ox >= p.Wout) continue;
-      const long long pix = (long long)(n * p.Hout + oy) * p.Wout + ox;
+      float* orow = (float*)p.y + (long long)n * p.ynstride + (long long)(oy * p.Wout + ox) * p.ldout;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int co = n0 + wn * (TN * 16) + i * 16 + fq * 4;
         if (co >= p.Cout) continue;
-        float* o = (float*)p.y + pix * p.ldout + co;
+        float* o = orow + co;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (co + r < p.Cout) o[r] = acc[i][j][r] + (p.bias ? p.bias[co + r] : 0.f);
+          if (co + r < p.Cout) {
+            float v = acc[i][j][r];
+            if (p.scale) v *= p.scale[co + r];
+            if (p.bias) v += p.bias[co + r];
+            if (p.relu) v = fmaxf(v, 0.f);
+            o[r] = v;
+          }
       }
     }
     return;
@@ -180,6 +189,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
   const int wid = wm + wn * WM;
   char* reg = smem + EPI_LDS_OFF + wid * (64 * PITCH + 256);
   int* rowpix = (int*)(reg + 64 * PITCH);     // pixel index (or -1) of the 64 staged rows
+  f32x4_t aff_sc[EPI == EPI_AFF ? TN : 1], aff_sh[EPI == EPI_AFF ? TN : 1];
+  if (EPI == EPI_AFF) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int cb = n0 + wn * CW + i * 16 + fq * 4;      // Cout % 4 == 0 (checked by the entry point)
+      const bool in = cb < p.Cout;
+      aff_sc[i] = (in && p.scale) ? *(const f32x4_t*)(p.scale + cb) : f32x4_t{1.f, 1.f, 1.f, 1.f};
+      aff_sh[i] = (in && p.bias) ? *(const f32x4_t*)(p.bias + cb) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 #pragma unroll
   for (int jh = 0; jh < TM / 4; ++jh) {       // 64 pixels at a time
     {
@@ -198,7 +217,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       const int j = jh * 4 + jj;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const f32x4_t v = acc[i][j];
+        f32x4_t v = acc[i][j];
+        if (EPI == EPI_AFF) v = v * aff_sc[i] + aff_sh[i];
         uint2 o;
         o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
         o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
@@ -213,14 +233,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       const int pixi = rowpix[row];
       uint4 v = *(const uint4*)(reg + row * PITCH + ch * 16);
       if (pixi >= 0 && co < p.Cout) {
-        if (EPI == EPI_RES) {
-          const uint4 rr = *(const uint4*)(p.res + (long long)pixi * p.ldres + co);
+        if (EPI == EPI_RES || (EPI == EPI_AFF && (p.res != nullptr || p.relu))) {
+          const uint4 rr = (EPI == EPI_RES || p.res != nullptr) ? *(const uint4*)(p.res + (long long)pixi * p.ldres + co) : make_uint4(0, 0, 0, 0);
+          const bool relu = EPI == EPI_AFF && p.relu;
           const unsigned vi[4] = {v.x, v.y, v.z, v.w}, ri[4] = {rr.x, rr.y, rr.z, rr.w};
           unsigned oo[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float lo = bf2f((bf16_t)(vi[q] & 0xFFFF)) + bf2f((bf16_t)(ri[q] & 0xFFFF));
-            const float hi = bf2f((bf16_t)(vi[q] >> 16)) + bf2f((bf16_t)(ri[q] >> 16));
+            float lo = bf2f((bf16_t)(vi[q] & 0xFFFF)) + bf2f((bf16_t)(ri[q] & 0xFFFF));
+            float hi = bf2f((bf16_t)(vi[q] >> 16)) + bf2f((bf16_t)(ri[q] >> 16));
+            if (relu) {
+              lo = fmaxf(lo, 0.f);
+              hi = fmaxf(hi, 0.f);
+            }
             oo[q] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
           }
           v = make_uint4(oo[0], oo[1], oo[2], oo[3]);
@@ -1012,6 +1037,26 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   return best;
 }
 
+// dx[n, 2*yy+py, 2*xx+px, :] = residual or 0 on one stride-2 parity class (16-byte pieces)
+__global__ __launch_bounds__(256) void lattice_fill_kernel(bf16_t* __restrict__ dx, int ld, const bf16_t* __restrict__ res, int ldres, int n, int h, int w,
+                                                            int mh, int mw, int py, int px, int c) {
+  const int c8 = c / 8;
+  const long long total = (long long)n * mh * mw * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % c8);
+    long long t = i / c8;
+    const int xx = (int)(t % mw);
+    t /= mw;
+    const int yy = (int)(t % mh), im = (int)(t / mh);
+    const int oy = 2 * yy + py, ox = 2 * xx + px;
+    if (oy >= h || ox >= w) continue;
+    const long long pix = ((long long)im * h + oy) * w + ox;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (res) v = *(const uint4*)(res + pix * ldres + ch * 8);
+    *(uint4*)(dx + pix * ld + ch * 8) = v;
+  }
+}
+
 bool g_autotune_mode = false;   // set by mi355det_conv_autotune around a regular entry-point call
 
 template <int EPI>
@@ -1073,8 +1118,8 @@ int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad) {
   return grid_m_rows(s, cout_pad);
 }
 
-int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias, void* y, int out_f32, float* stats,
-                      int32_t cout_pad, void* stream) {
+static int conv_fwd_impl(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias, void* y, int out_f32, float* stats,
+                         int32_t cout_pad, const mi355det_conv_epilogue* ex, void* stream) {
   if (int e = check_shape(s, "conv_fwd")) return e;
   if (int e = ensure_zero_page()) return e;
   if (cout_pad < s->cout) return fail(MI355DET_EINVAL, "%s: cout_pad < cout", "conv_fwd");
@@ -1099,9 +1144,36 @@ int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w
     }
   p.dMW = make_fastdiv((unsigned)p.MW);
   p.dMH = make_fastdiv((unsigned)p.MH);
+  p.ynstride = (long long)s->ho * s->wo * s->out_ld;
   set_tap_pad(p);
+  if (ex) {
+    p.scale = ex->scale;
+    p.bias = ex->shift;
+    p.relu = ex->relu;
+    p.res = (const bf16_t*)ex->residual;
+    p.ldres = ex->residual_ld;
+    if (ex->out_image_stride) {
+      if (!out_f32) return fail(MI355DET_EINVAL, "%s: out_image_stride needs an fp32 output", "conv_fwd_ex");
+      p.ynstride = ex->out_image_stride;
+    }
+    if (out_f32 && ex->residual) return fail(MI355DET_EINVAL, "%s: residual needs a bf16 output", "conv_fwd_ex");
+    if (!out_f32 && (s->cout % 8)) return fail(MI355DET_EINVAL, "%s: bf16 outputs need cout %% 8 == 0", "conv_fwd_ex");
+    const int r = out_f32 ? dispatch_igemm<EPI_F32>(p, S(stream)) : dispatch_igemm<EPI_AFF>(p, S(stream));
+    return r < 0 ? r : 0;
+  }
   const int r = out_f32 ? dispatch_igemm<EPI_F32>(p, S(stream)) : stats ? dispatch_igemm<EPI_STATS>(p, S(stream)) : dispatch_igemm<EPI_PLAIN>(p, S(stream));
   return r < 0 ? r : 0;
+}
+
+int mi355det_conv_fwd(const mi355det_conv_shape* s, const void* x, const void* w, const float* bias, void* y, int out_f32, float* stats,
+                      int32_t cout_pad, void* stream) {
+  return conv_fwd_impl(s, x, w, bias, y, out_f32, stats, cout_pad, nullptr, stream);
+}
+
+int mi355det_conv_fwd_ex(const mi355det_conv_shape* s, const void* x, const void* w, const mi355det_conv_epilogue* e, void* y, int out_f32,
+                         int32_t cout_pad, void* stream) {
+  if (!e) return fail(MI355DET_EINVAL, "%s: null epilogue", "conv_fwd_ex");
+  return conv_fwd_impl(s, x, w, nullptr, y, out_f32, nullptr, cout_pad, e, stream);
 }
 
 // dgrad tap lists.  stride 1: dx[y,x] = sum_{kh,kw} dy[y+p-kh, x+p-kw] * w[kh,kw]  -> tap j=(kh,kw): d = p-kh.
@@ -1154,6 +1226,7 @@ int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is
       int ft[9] = {0}, dy[9], dx[9];
       const int nt = dgrad_taps(s, c >> 1, c & 1, ft, dy, dx);
       const long long total = (long long)cin_pad * nt * s->cout;
+      if (total == 0) continue;     // 1x1 stride-2: the odd parity classes have no taps
       hipLaunchKernelGGL(pack_dgrad_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), w, out, s->cout, s->cin,
                          cin_pad, kk, nt, s_co, s_ci, s_t, ft[0], ft[1], ft[2], ft[3], ft[4], ft[5], ft[6], ft[7], ft[8]);
       out += total;
@@ -1293,6 +1366,15 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
     IgemmParams p{};
     int ft[9];
     p.T = dgrad_taps(s, c >> 1, c & 1, ft, p.dy, p.dx);
+    if (p.T == 0) {
+      // 1x1 stride-2 convolutions never read the odd input rows / columns: their data gradient is zero (+ residual)
+      const int mh = (s->h + 1) / 2, mw = (s->w + 1) / 2;
+      const long long total = (long long)s->n * mh * mw * (s->cin / 8);
+      if (s->cin % 8) return fail(MI355DET_EINVAL, "%s: cin must be a multiple of 8", "conv_dgrad");
+      hipLaunchKernelGGL(lattice_fill_kernel, dim3((int)min((long long)4096, (total + 255) / 256)), dim3(256), 0, S(stream), (bf16_t*)dx, s->in_ld,
+                         (const bf16_t*)residual, residual_ld, s->n, s->h, s->w, mh, mw, c >> 1, c & 1, s->cin);
+      continue;
+    }
     p.x = (const bf16_t*)dy;
     p.w = wp;
     p.y = dx;

@@ -332,3 +332,69 @@ def topk_rows(x, k, min_value=float("-inf")):
     cnt = torch.empty(rows, device=x.device, dtype=torch.int32)
     check(lib().mi355det_topk(ptr(x), rows, n, x.stride(0), k, float(min_value), ptr(idx), ptr(val), ptr(cnt), stream_ptr()), "topk")
     return val, idx, cnt
+
+
+# ------------------------------------------------------------------------------------ ResNet-FPN / RetinaNet companions
+def conv_fwd_ex(shape, x, w_fwd, y, scale=None, shift=None, residual=None, residual_ld=0, relu=False, out_f32=False, out_image_stride=0):
+    """y = relu?(conv(x,w)*scale + shift + residual): FrozenBatchNorm2d / bias / identity add fused into the conv epilogue."""
+    e = _lib.ConvEpilogue(ptr(scale), ptr(shift), ptr(residual), int(residual_ld), int(bool(relu)), int(out_image_stride))
+    check(lib().mi355det_conv_fwd_ex(C.byref(shape), ptr(x), ptr(w_fwd), C.byref(e), ptr(y), int(out_f32), cout_pad_of(shape.cout), stream_ptr()),
+          "conv_fwd_ex")
+
+
+def im2col_nchw(img, ksize, stride, pad, kpad, mean=None, inv_std=None):
+    n, c, h, w = img.shape
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    out = torch.empty((n, ho, wo, kpad), device=img.device, dtype=torch.bfloat16)
+    check(lib().mi355det_im2col_nchw(ptr(_f32c(img)), ptr(mean), ptr(inv_std), ptr(out), n, c, h, w, ksize, stride, pad, kpad, stream_ptr()),
+          "im2col_nchw")
+    return out
+
+
+def maxpool3x3s2(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.bfloat16)
+    check(lib().mi355det_maxpool3x3s2(ptr(x), c, n, h, w, c, ptr(out), c, stream_ptr()), "maxpool3x3s2")
+    return out
+
+
+def relu_affine_bwd(g1, a, scale=None, g2=None, relu=True, want_gm=False):
+    c = g1.shape[-1]
+    pixels = g1.numel() // c
+    dz = torch.empty_like(g1)
+    gm = torch.empty_like(g1) if want_gm else None
+    check(lib().mi355det_relu_affine_bwd(ptr(g1), c, ptr(g2), c if g2 is not None else 0, ptr(a), c, ptr(scale), c, pixels, int(relu), ptr(dz), c,
+                                         ptr(gm), c, stream_ptr()), "relu_affine_bwd")
+    return (dz, gm) if want_gm else dz
+
+
+def upsample_nearest_add(x, lateral, out_hw):
+    n, h, w, c = x.shape
+    out = torch.empty((n, out_hw[0], out_hw[1], c), device=x.device, dtype=torch.bfloat16)
+    check(lib().mi355det_upsample_nearest_add(ptr(x), c, n, h, w, c, ptr(lateral), c if lateral is not None else 0, out_hw[0], out_hw[1], ptr(out), c,
+                                              stream_ptr()), "upsample_nearest_add")
+    return out
+
+
+def upsample_nearest_bwd(g, hw, accumulate=None):
+    n, gh, gw, c = g.shape
+    out = torch.empty((n, hw[0], hw[1], c), device=g.device, dtype=torch.bfloat16)
+    check(lib().mi355det_upsample_nearest_bwd(ptr(g), c, n, hw[0], hw[1], c, gh, gw, ptr(accumulate), c if accumulate is not None else 0, ptr(out), c,
+                                              stream_ptr()), "upsample_nearest_bwd")
+    return out
+
+
+def retina_loss(cls_logits, bbox_regression, anchors, matched, gt_boxes, gt_labels, gt_offsets, k=None, class_scale=None, alpha=0.25, gamma=2.0,
+                want_grad=True, grad_scale=1.0, grad_logits=None, grad_regression=None):
+    """Batched RetinaNetHead.compute_loss.  -> (losses[2] = (classification, bbox_regression), num_fg [N], grad_logits, grad_regression)."""
+    n, rows, k = cls_logits.shape
+    dev = cls_logits.device
+    losses = torch.empty(2, device=dev)
+    nfg = torch.empty(n, device=dev)
+    if want_grad:
+        grad_logits = torch.empty_like(cls_logits) if grad_logits is None else grad_logits
+        grad_regression = torch.empty_like(bbox_regression) if grad_regression is None else grad_regression
+    check(lib().mi355det_retina_loss(ptr(cls_logits), ptr(bbox_regression), ptr(anchors), ptr(matched), ptr(gt_boxes), ptr(gt_labels), ptr(gt_offsets),
+                                     ptr(class_scale), n, rows, k, float(alpha), float(gamma), float(grad_scale), ptr(nfg), ptr(losses),
+                                     ptr(grad_logits) if want_grad else None, ptr(grad_regression) if want_grad else None, stream_ptr()), "retina_loss")
+    return losses, nfg, grad_logits, grad_regression
