@@ -486,6 +486,102 @@ def g5_7_tvision():
     np.savez_compressed(os.path.join(OUT, "g5_7_tvision.npz"), **d)
 
 
+# ----------------------------------------------------------------------------- G12 ResNet-50 body + RetinaNetHead
+class _PermissiveMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _PermissiveMeta(name, (), {})
+
+
+class _Permissive(types.ModuleType):
+    """Stub module: any attribute resolves to a placeholder class (enough for `from torchvision.ops import X` at import time)."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _PermissiveMeta(name, (), {})
+
+
+class FrozenBN(nn.Module):
+    """torchvision.ops.misc.FrozenBatchNorm2d restated (torchvision is not installed): fixed statistics and affine."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x):
+        w, b, rm, rv = (t.reshape(1, -1, 1, 1) for t in (self.weight, self.bias, self.running_mean, self.running_var))
+        scale = w * (rv + self.eps).rsqrt()
+        return x * scale + (b - rm * scale)
+
+
+def g12_retinanet():
+    from oracle import retina_oracle as ro
+    for k in [k for k in sys.modules if k == "utilities" or k.startswith("utilities.") or k == "tvision" or k.startswith("tvision.")
+              or k == "torchvision" or k.startswith("torchvision.")]:
+        del sys.modules[k]
+    sys.path.insert(0, os.path.join(REF, "torchvision_models"))
+    for name in ("torchvision", "torchvision.ops", "torchvision.ops.misc", "torchvision.ops.boxes", "torchvision.ops.feature_pyramid_network",
+                 "torchvision.ops.roi_align", "torchvision.models", "torchvision.models.utils", "torchvision.models.detection",
+                 "torchvision.models.detection.image_list"):
+        sys.modules[name] = _Permissive(name)
+    sys.modules["torchvision.ops.misc"].FrozenBatchNorm2d = FrozenBN
+    sys.modules["torchvision"].ops = sys.modules["torchvision.ops"]
+    sys.modules["torchvision.ops"].misc = sys.modules["torchvision.ops.misc"]
+    sys.modules["torchvision.ops"].boxes = sys.modules["torchvision.ops.boxes"]
+    from utilities import resnet
+    seed = 7000
+    d = {"meta": np.array([seed, 7100, 64], np.int64)}
+    # ---- the reference's ResNet class, FrozenBN, deterministic weights
+    m = resnet.resnet50(pretrained=False, norm_layer=FrozenBN)
+    msd = m.state_dict()
+    allk = ro.state_keys()
+    for i, (k, shp) in enumerate(allk):
+        if k.startswith("backbone.body."):
+            msd[k[len("backbone.body."):]].copy_(torch.from_numpy(ro.det_fill(k, shp, seed + i)))
+    m.eval()
+    x = torch.from_numpy(detrand.uniform(7100, (2, 3, 64, 64), -2.0, 2.0))
+    with torch.no_grad():
+        t = m.maxpool(m.relu(m.bn1(m.conv1(x))))
+        d["stem_sample"], d["stem_norm"] = ro.sample(t), np.float64(t.double().norm())
+        for li in range(1, 5):
+            t = getattr(m, f"layer{li}")(t)
+            d[f"c{li + 1}_shape"] = np.array(t.shape, np.int64)
+            d[f"c{li + 1}_sample"] = ro.sample(t)
+            d[f"c{li + 1}_norm"] = np.float64(t.double().norm())
+    # gradient of a fixed cotangent on C5 w.r.t. layer2.0.conv1 (first trainable conv for trainable_layers=3) and the input of layer2
+    xg = torch.from_numpy(detrand.uniform(7101, (2, 256, 16, 16), -1.0, 1.0)).requires_grad_(True)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    c5 = m.layer4(m.layer3(m.layer2(xg)))
+    cot = torch.from_numpy(detrand.uniform(7102, tuple(c5.shape), -1.0, 1.0))
+    (c5 * cot).sum().backward()
+    d["l2in_grad_sample"], d["l2in_grad_norm"] = ro.sample(xg.grad), np.float64(xg.grad.double().norm())
+    for pn in ("layer2.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.5.conv2.weight", "layer4.2.conv3.weight"):
+        g = dict(m.named_parameters())[pn].grad
+        d["grad_" + pn + "_sample"], d["grad_" + pn + "_norm"] = ro.sample(g), np.float64(g.double().norm())
+    # ---- the reference's RetinaNetHead
+    from tvision import retinanet as rn
+    head = rn.RetinaNetHead(256, 9, 91, tfidf={"num_classes": 91, "values": torch.ones(91), "mini_batch": False, "tfidf_norm": 0})
+    hsd = head.state_dict()
+    for i, (k, shp) in enumerate(allk):
+        if k.startswith("head."):
+            hsd[k[len("head."):]].copy_(torch.from_numpy(ro.det_fill(k, shp, seed + i)))
+    feats = [torch.from_numpy(detrand.uniform(7200 + l, (2, 256, hw, hw), -1.0, 1.0)) for l, hw in enumerate((8, 4, 2, 1, 1))]
+    with torch.no_grad():
+        out = head(feats)
+    for k in ("cls_logits", "bbox_regression"):
+        d["head_" + k + "_shape"] = np.array(out[k].shape, np.int64)
+        d["head_" + k + "_sample"] = ro.sample(out[k], 256)
+        d["head_" + k + "_norm"] = np.float64(out[k].double().norm())
+    np.savez_compressed(os.path.join(OUT, "g12_retinanet.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -497,6 +593,7 @@ def main():
     g11_postproc(helper, custom, yolo_forw)
     g8_network(yolohead, darknet)
     g5_7_tvision()
+    g12_retinanet()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
