@@ -207,3 +207,35 @@ def test_upsample_and_layout():
     back = torch.empty(2, 5, 4, 6, device=d)
     check(lib().mi355det_nhwc_to_nchw_f32(ptr(o), 1, 8, 2, 5, 4, 6, ptr(back), stream_ptr()))
     assert torch.equal(back.cpu(), t)
+
+
+def test_batched_pack_equals_single_pack():
+    """mi355det_pack_weights_batched (one launch, tiled transpose for the dgrad packs) == mi355det_pack_weights per layer."""
+    import ctypes as C
+    from object_detectors_amd import _lib, ops
+    from object_detectors_amd._lib import check, lib
+    cases = [(64, 128, 3, 1), (32, 64, 3, 2), (128, 64, 1, 1), (256, 512, 1, 2), (64, 32, 1, 1), (96, 256, 3, 1), (512, 1024, 3, 2)]
+    L = lib()
+    items = (_lib.PackItem * len(cases))()
+    keep, want = [], []
+    for i, (cin, cout, k, s) in enumerate(cases):
+        shp = ops.conv_shape(1, 8, 8, cin, cout, k, s)
+        w = (torch.randn((cout, k, k, cin), generator=torch.Generator().manual_seed(i)) * 0.1).to(dev())
+        wf0, wd0 = ops.pack_weights(shp, w, ohwi=True)
+        want.append((wf0, wd0))
+        wf, wd = torch.full_like(wf0, 7.0), torch.full_like(wd0, 7.0)
+        keep += [shp, w, wf, wd]
+        items[i].w, items[i].w_fwd, items[i].w_dgrad = w.data_ptr(), wf.data_ptr(), wd.data_ptr()
+        items[i].shape, items[i].cout_pad, items[i].w_is_ohwi = shp, ops.cout_pad_of(cout), 1
+    ne, nb = C.c_int32(0), C.c_int32(0)
+    nbytes = L.mi355det_pack_table_bytes(items, len(cases), C.byref(ne), C.byref(nb))
+    host = torch.empty(nbytes, dtype=torch.uint8)
+    check(L.mi355det_pack_table_build(items, len(cases), C.c_void_p(host.data_ptr()), nbytes), "pack_table_build")
+    tab = host.to(dev())
+    check(L.mi355det_pack_weights_batched(C.c_void_p(tab.data_ptr()), ne.value, nb.value, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pack")
+    torch.cuda.synchronize()
+    for i, (wf0, wd0) in enumerate(want):
+        wf, wd = keep[4 * i + 2], keep[4 * i + 3]
+        assert torch.equal(wf, wf0), cases[i]
+        n = lib().mi355det_dgrad_pack_elems(C.byref(keep[4 * i])) - 64          # the 64 trailing elements are slack
+        assert torch.equal(wd[:n], wd0[:n]), cases[i]

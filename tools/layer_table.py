@@ -5,6 +5,8 @@ from object_detectors_amd.yolo.nets.engine import arch
 path = sys.argv[1]
 rows = list(csv.DictReader(open(glob.glob(path + '/**/*kernel_trace.csv', recursive=True)[0])))
 idx = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name']]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name']]
 last = rows[idx[-1]:]
 specs = arch()
 def hw(s):
@@ -18,9 +20,9 @@ def dur(r): return (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 fw = [r for r in last if 'igemm' in r['Kernel_Name'] and (', 0, ' in r['Kernel_Name'].split('igemm')[1][:60] or True)]
 # forward igemm launches = first 75 igemm-family kernels of the step (before any wgrad)
 first_w = next(i for i, r in enumerate(last) if 'wgrad_kernel' in r['Kernel_Name'])
-fwd = [r for r in last[:first_w] if 'igemm' in r['Kernel_Name']][:75]
+fwd = sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))[:75]
 bwd = last[first_w - 10:]
-wg = [r for r in last if 'wgrad_kernel' in r['Kernel_Name']]
+wg = sorted([r for r in last if 'wgrad_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
 agg = collections.OrderedDict()
 for s, r in zip(specs, fwd):
     k = (s.cin, s.cout, s.k, s.stride, hw(s)); a = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dur(r)
@@ -29,7 +31,8 @@ for s, r in zip(specs, fwd):
 for s, r in zip(reversed(specs), wg):
     agg[(s.cin, s.cout, s.k, s.stride, hw(s))][3] += dur(r)
 # dgrad: igemm kernels after the first wgrad, grouped per layer in backward order (stride-2 layers have 4 launches)
-dg = [r for r in last[first_w:] if 'igemm' in r['Kernel_Name']]
+allig = sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
+dg = allig[75:]
 it = iter(dg)
 for s in reversed(specs):
     if s.name == 'backbone.conv1': continue
