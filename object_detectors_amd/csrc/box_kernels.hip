@@ -28,7 +28,7 @@ __host__ __device__ inline NmsWs nms_layout(int max_n) {
   w.kept = o;       o = align16(o + sizeof(int) * (size_t)max_n);
   w.remover = o;    o = align16(o + sizeof(int) * (size_t)max_n);
   w.misc = o;       o = align16(o + 64);
-  w.mask = o;       o = align16(o + sizeof(unsigned long long) * (size_t)max_n * w.words);
+  w.mask = o;       o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64 * w.words);   // [column block][row padded to 64]
   w.stride = o;
   return w;
 }
@@ -120,7 +120,8 @@ __device__ __forceinline__ float nms_iou(const float4 s, const float4 r) {   // 
   return inter / (as + ar - inter);                    // torchvision nms
 }
 
-// ---- 2. bit mask: bit (i,j) j>i set when box j is dropped by box i ------------------------------
+// ---- 2. bit mask: bit (i,j) j>i set when box j is dropped by box i; stored column-block major, word [tj][i] holds
+//         columns tj*64..tj*64+63 of row i, so the scan's per-tile gather over rows is one contiguous, coalesced read
 // MODE 0: drop = !(IoU < thr) (helper.py:368 keeps IoU<thr);  MODE 1: drop = IoU > thr
 template <int MODE>
 __global__ __launch_bounds__(WAVE) void nms_mask_kernel(char* __restrict__ ws_base, NmsWs L, float thr) {
@@ -145,103 +146,128 @@ __global__ __launch_bounds__(WAVE) void nms_mask_kernel(char* __restrict__ ws_ba
     const bool drop = MODE == 0 ? !(v < thr) : (v > thr);
     if (drop) bits |= 1ull << c;
   }
-  ((unsigned long long*)(ws + L.mask))[(size_t)i * L.words + tj] = bits;
+  ((unsigned long long*)(ws + L.mask))[(size_t)tj * (L.words * 64) + i] = bits;   // column-block major: [tj][row]
 }
 
-// ---- 3. greedy scan: one wave per image, 64-box tiles resolved in registers ----------------------
-#define SCAN_SLOTS (NMS_MAX_N / 64 / 64)   // 4 words of the removed-bitmap per lane
-__global__ __launch_bounds__(WAVE) void nms_scan_kernel(char* __restrict__ ws_base, NmsWs L, int* __restrict__ out_count) {
+// ---- 3. greedy scan: one workgroup per image ------------------------------------------------------
+// Tile t (64 sorted boxes) needs R_t = OR over all boxes kept so far of their mask word for column block t.  Those loads
+// are independent of each other, so the whole workgroup issues them at once (one memory round trip per tile instead of
+// one per kept row), ORs them with wave shuffles, and wave 0 resolves the 64x64 diagonal block in registers
+// (readlane chain).  The kept list lives in LDS.  Sequential cost: ~2 memory latencies per 64 boxes.
+#define SCAN_THREADS 256
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(char* __restrict__ ws_base, NmsWs L, int* __restrict__ out_count) {
+  extern __shared__ unsigned long long skeptbits[];     // bit r%64 of word r/64: sorted box r is kept
+  __shared__ unsigned long long s_red[SCAN_THREADS / WAVE];
+  __shared__ int s_kc;
   const int b = blockIdx.x;
   char* ws = ws_base + (size_t)b * L.stride;
   const int n = ((const int*)(ws + L.misc))[0];
   const unsigned long long* mask = (const unsigned long long*)(ws + L.mask);
+  const size_t NP = (size_t)L.words * 64;
   int* kept = (int*)(ws + L.kept);
   int* remover = (int*)(ws + L.remover);
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const int words = (n + 63) / 64;
-  unsigned long long removed[SCAN_SLOTS];
-#pragma unroll
-  for (int s = 0; s < SCAN_SLOTS; ++s) removed[s] = 0;
   int kc = 0;
   for (int t = 0; t < words; ++t) {
-    // removed word t lives in lane t%64, slot t/64
-    unsigned long long rw = 0;
-#pragma unroll
-    for (int s = 0; s < SCAN_SLOTS; ++s)
-      if (s == t / 64) rw = removed[s];
-    const unsigned rlo = __shfl((unsigned)rw, t & 63, WAVE), rhi = __shfl((unsigned)(rw >> 32), t & 63, WAVE);
-    const int cn = min(64, n - t * 64);
-    const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
-    unsigned long long alive = ~(((unsigned long long)rhi << 32) | rlo) & valid;
     const int row = t * 64 + lane;
-    const unsigned long long diag = row < n ? mask[(size_t)row * L.words + t] : 0ull;
-    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-    unsigned long long kept_bits = 0;
-    int my_remover = -1;
-    for (int j = 0; j < cn; ++j) {
-      if ((alive >> j) & 1ull) {
+    const unsigned long long* col = mask + (size_t)t * NP;
+    unsigned long long diag = 0;
+    if (wid == 0 && row < n) diag = col[row];
+    // R_t = OR over the kept rows r < 64 t of word [t][r]: contiguous in r, all loads independent
+    unsigned long long acc = 0;
+    const int rows_before = t * 64;
+    int r = tid;
+    for (; r + 3 * SCAN_THREADS < rows_before; r += 4 * SCAN_THREADS) {
+      const unsigned long long a0 = col[r], a1 = col[r + SCAN_THREADS], a2 = col[r + 2 * SCAN_THREADS], a3 = col[r + 3 * SCAN_THREADS];
+      const unsigned long long kb = skeptbits[r >> 6];      // SCAN_THREADS is a multiple of 64: the four rows share the bit index
+      const unsigned long long k1 = skeptbits[(r + SCAN_THREADS) >> 6], k2 = skeptbits[(r + 2 * SCAN_THREADS) >> 6],
+                               k3 = skeptbits[(r + 3 * SCAN_THREADS) >> 6];
+      const int bit = r & 63;
+      acc |= ((kb >> bit) & 1ull ? a0 : 0ull) | ((k1 >> bit) & 1ull ? a1 : 0ull) | ((k2 >> bit) & 1ull ? a2 : 0ull) | ((k3 >> bit) & 1ull ? a3 : 0ull);
+    }
+    for (; r < rows_before; r += SCAN_THREADS) {
+      const unsigned long long a0 = col[r];
+      if ((skeptbits[r >> 6] >> (r & 63)) & 1ull) acc |= a0;
+    }
+    unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo |= (unsigned)__shfl_xor((int)lo, o, WAVE);
+      hi |= (unsigned)__shfl_xor((int)hi, o, WAVE);
+    }
+    if (lane == 0) s_red[wid] = ((unsigned long long)hi << 32) | lo;
+    __syncthreads();
+    if (wid == 0) {
+      unsigned long long R = 0;
+#pragma unroll
+      for (int w = 0; w < SCAN_THREADS / WAVE; ++w) R |= s_red[w];
+      const int cn = min(64, n - t * 64);
+      const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+      // wave-uniform values through readfirstlane: the 64-step chain below then runs on the scalar unit
+      const unsigned long long Ru = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(R >> 32)) << 32) |
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)R);
+      unsigned long long alive = ~Ru & valid;
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      unsigned long long kept_bits = 0;
+      while (alive) {
+        const int j = __builtin_ctzll(alive);
         kept_bits |= 1ull << j;
         const unsigned long long d =
             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, j);
-        const unsigned long long newly = alive & d;
-        if ((newly >> lane) & 1ull) my_remover = t * 64 + j;
-        alive &= ~d;
+        alive &= ~d & ~(1ull << j);
+      }
+      const bool mine = (kept_bits >> lane) & 1ull;
+      if (row < n) remover[row] = mine ? -1 : -2;      // -2: removed, the remover is resolved by nms_remover_kernel
+      if (mine) kept[kc + __popcll(kept_bits & ((1ull << lane) - 1ull))] = row;
+      if (lane == 0) {
+        skeptbits[t] = kept_bits;
+        s_kc = kc + __popcll(kept_bits);
       }
     }
-    if (row < n) {   // rows already removed by an earlier tile keep the remover written by the row-OR below
-      if ((kept_bits >> lane) & 1ull) remover[row] = -1;
-      else if (my_remover >= 0) remover[row] = my_remover;
-    }
-    // kept list in order
-    if ((kept_bits >> lane) & 1ull) kept[kc + __popcll(kept_bits & ((1ull << lane) - 1ull))] = row;
-    kc += __popcll(kept_bits);
-    // OR the kept rows into the removed bitmap for words > t, assigning first removers.  The rows of up to 8 kept
-    // boxes are loaded together (independent loads in flight) and then applied in keep order.
-    unsigned long long kb = kept_bits;
-    while (kb) {
-      int rows8[8];
-      int nr = 0;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        rows8[r] = 0;
-        if (kb) {
-          const int j = __ffsll((long long)kb) - 1;
-          kb &= kb - 1;
-          rows8[r] = t * 64 + j;
-          nr = r + 1;
-        }
-      }
-      unsigned long long m8[8][SCAN_SLOTS];
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int s = 0; s < SCAN_SLOTS; ++s) {
-          const int w = lane + 64 * s;
-          m8[r][s] = (r < nr && w > t && w < words) ? mask[(size_t)rows8[r] * L.words + w] : 0ull;
-        }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if (r < nr) {
-#pragma unroll
-          for (int s = 0; s < SCAN_SLOTS; ++s) {
-            const int w = lane + 64 * s;
-            unsigned long long newly = m8[r][s] & ~removed[s];
-            removed[s] |= m8[r][s];
-            while (newly) {
-              const int bit = __ffsll((long long)newly) - 1;
-              newly &= newly - 1;
-              const int col = w * 64 + bit;
-              if (col < n) remover[col] = rows8[r];
-            }
-          }
-        }
-      }
-    }
+    __syncthreads();
+    kc = s_kc;
   }
-  if (lane == 0) {
+  if (tid == 0) {
     ((int*)(ws + L.misc))[1] = kc;
     out_count[b] = kc;
   }
+}
+
+// remover[c] = the first kept box (in keep order) whose mask row has bit c: the box that suppressed c (helper.py:355-368).
+// One thread per removed box; the 64 lanes of a wave share the mask word index, so each step is one broadcast load.
+__global__ __launch_bounds__(256) void nms_remover_kernel(char* __restrict__ ws_base, NmsWs L) {
+  const int b = blockIdx.y;
+  char* ws = ws_base + (size_t)b * L.stride;
+  const int n = ((const int*)(ws + L.misc))[0];
+  const int kc = ((const int*)(ws + L.misc))[1];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if ((c & ~63) >= n) return;          // whole wave out of range
+  const unsigned long long* mask = (const unsigned long long*)(ws + L.mask);
+  const int* kept = (const int*)(ws + L.kept);
+  int* remover = (int*)(ws + L.remover);
+  const int w = c >> 6, bit = c & 63;
+  const size_t NP = (size_t)L.words * 64;
+  bool open = c < n && remover[c] == -2;
+  int found = -1;
+  for (int k0 = 0; k0 < kc; k0 += 4) {
+    if (!__any(open)) break;
+    int r[4];
+    unsigned long long m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      r[q] = k0 + q < kc ? kept[k0 + q] : 0x7FFFFFFF;
+      m[q] = r[q] < (w + 1) * 64 ? mask[(size_t)w * NP + r[q]] : 0ull;   // rows beyond this column block cannot remove c
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (open && r[q] < c && ((m[q] >> bit) & 1ull)) {
+        found = r[q];
+        open = false;
+      }
+    if (r[3] >= (w + 1) * 64) break;     // kept rows are ascending: nothing later can precede any column of this wave
+  }
+  if (found >= 0) remover[c] = found;
 }
 
 // ---- 4. majority vote + output (helper.py:369-375) --------------------------------------------
@@ -348,31 +374,41 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_pass1_kernel(const float*
                                                                      long long n, float hi, float lo, unsigned* __restrict__ gt_best,
                                                                      long long* __restrict__ matches) {
   extern __shared__ float4 sg[];
-  for (int g = threadIdx.x; g < m; g += MATCH_THREADS) sg[g] = *(const float4*)(gt + 4 * (size_t)g);
+  // per-GT maximum over this workgroup's anchors with LDS atomics, then ONE global atomic per GT per workgroup
+  // (a global atomicMax per wave per GT = 13k same-address atomics cost 170 us at N=120k, M=7)
+  unsigned* sbest = (unsigned*)(sg + m);
+  for (int g = threadIdx.x; g < m; g += MATCH_THREADS) {
+    sg[g] = *(const float4*)(gt + 4 * (size_t)g);
+    sbest[g] = 0u;
+  }
   __syncthreads();
-  const long long i = blockIdx.x * (long long)MATCH_THREADS + threadIdx.x;
-  const bool live = i < n;
-  const float4 a = live ? *(const float4*)(anchors + 4 * i) : make_float4(0, 0, 0, 0);
-  float best = -INFINITY;
-  int arg = 0;
-  for (int g = 0; g < m; ++g) {
-    const float v = tv_iou(sg[g], a);
-    if (g == 0 || v > best) {   // first maximum, as torch.max(dim=0)
-      best = v;
-      arg = g;
-    }
-    // per-GT row maximum over anchors
-    unsigned o = live ? f2ord(v) : 0u;
+  const long long stride = (long long)gridDim.x * MATCH_THREADS;
+  const long long n_round = (n + MATCH_THREADS - 1) / MATCH_THREADS * MATCH_THREADS;
+  for (long long i = blockIdx.x * (long long)MATCH_THREADS + threadIdx.x; i < n_round; i += stride) {
+    const bool live = i < n;
+    const float4 a = live ? *(const float4*)(anchors + 4 * i) : make_float4(0, 0, 0, 0);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int g = 0; g < m; ++g) {
+      const float v = tv_iou(sg[g], a);
+      if (g == 0 || v > best) {   // first maximum, as torch.max(dim=0)
+        best = v;
+        arg = g;
+      }
+      unsigned o = live ? f2ord(v) : 0u;
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) o = max(o, (unsigned)__shfl_xor((int)o, s, WAVE));
-    if ((threadIdx.x & 63) == 0) atomicMax(gt_best + g, o);
+      for (int s = 32; s > 0; s >>= 1) o = max(o, (unsigned)__shfl_xor((int)o, s, WAVE));
+      if ((threadIdx.x & 63) == 0) atomicMax(sbest + g, o);
+    }
+    if (live) {
+      long long r = arg;
+      if (best < lo) r = -1;
+      else if (best < hi) r = -2;
+      matches[i] = r;
+    }
   }
-  if (live) {
-    long long r = arg;
-    if (best < lo) r = -1;
-    else if (best < hi) r = -2;
-    matches[i] = r;
-  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < m; g += MATCH_THREADS) atomicMax(gt_best + g, sbest[g]);
 }
 
 __global__ __launch_bounds__(MATCH_THREADS) void match_pass2_kernel(const float* __restrict__ gt, const float* __restrict__ anchors, int m,
@@ -603,7 +639,10 @@ int launch_nms_common(int mode, const float* boxes, const float* scores, const l
   const int tiles = (max_n + 63) / 64;
   if (mode == 0) hipLaunchKernelGGL(nms_mask_kernel<0>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);
   else hipLaunchKernelGGL(nms_mask_kernel<1>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(bs), dim3(WAVE), 0, st, (char*)workspace, L, out_count);
+  const size_t scan_lds = sizeof(unsigned long long) * (size_t)((max_n + 63) / 64);
+  (void)hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(bs), dim3(SCAN_THREADS), scan_lds, st, (char*)workspace, L, out_count);
+  if (mode == 0) hipLaunchKernelGGL(nms_remover_kernel, dim3((max_n + 255) / 256, bs), dim3(256), 0, st, (char*)workspace, L);
   return 0;
 }
 
@@ -659,8 +698,8 @@ int mi355det_match_anchors(const float* gt, const float* anchors, int32_t m, int
   if (m > MATCH_MAX_GT) return fail(MI355DET_EINVAL, "%s: more than %lld GT boxes per image", "match_anchors", MATCH_MAX_GT);
   if (hipMemsetAsync(gt_best, 0, sizeof(uint32_t) * (size_t)m, S(stream)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: memset failed", "match");
   const int blocks = (int)((n + MATCH_THREADS - 1) / MATCH_THREADS);
-  hipLaunchKernelGGL(match_pass1_kernel, dim3(blocks), dim3(MATCH_THREADS), sizeof(float4) * m, S(stream), gt, anchors, m, (long long)n, high_thr,
-                     low_thr, gt_best, (long long*)matches);
+  hipLaunchKernelGGL(match_pass1_kernel, dim3(min(blocks, 256)), dim3(MATCH_THREADS), (sizeof(float4) + sizeof(unsigned)) * m, S(stream), gt, anchors,
+                     m, (long long)n, high_thr, low_thr, gt_best, (long long*)matches);
   if (allow_low_quality)
     hipLaunchKernelGGL(match_pass2_kernel, dim3(blocks), dim3(MATCH_THREADS), (sizeof(float4) + sizeof(unsigned)) * m, S(stream), gt, anchors, m,
                        (long long)n, gt_best, (long long*)matches);
