@@ -71,3 +71,36 @@ class Matcher(object):
             pred = torch.where(q == best[:, None])[1]
             matches[pred] = allm[pred]
         return matches
+
+
+class BalancedPositiveNegativeSampler(object):
+    """tvision/_utils.py:9-76.  Stays in torch by design: it is RNG-dependent (`torch.randperm`), tiny
+    (<= 512 indices per image) and must consume the framework's generator to stay reproducible against the reference."""
+
+    def __init__(self, batch_size_per_image, positive_fraction):
+        self.batch_size_per_image = batch_size_per_image
+        self.positive_fraction = positive_fraction
+
+    def __call__(self, matched_idxs):
+        pos_idx, neg_idx = [], []
+        for m in matched_idxs:
+            positive = torch.where(m >= 1)[0]
+            negative = torch.where(m == 0)[0]
+            num_pos = min(positive.numel(), int(self.batch_size_per_image * self.positive_fraction))
+            num_neg = min(negative.numel(), self.batch_size_per_image - num_pos)
+            perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
+            perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+            pm = torch.zeros_like(m, dtype=torch.uint8)
+            nm = torch.zeros_like(m, dtype=torch.uint8)
+            pm[positive[perm1]] = 1
+            nm[negative[perm2]] = 1
+            pos_idx.append(pm)
+            neg_idx.append(nm)
+        return pos_idx, neg_idx
+
+
+def smooth_l1_loss(input, target, beta: float = 1. / 9, size_average: bool = True):
+    """tvision/_utils.py:347-358."""
+    n = torch.abs(input - target)
+    loss = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+    return loss.mean() if size_average else loss.sum()

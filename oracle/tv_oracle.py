@@ -251,3 +251,60 @@ def map_levels(boxes, k_min, k_max):
     s = np.sqrt((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])).astype(F32)
     k = np.floor(F32(4) + np.log2(s / F32(224)) + F32(1e-6))
     return (np.clip(k, k_min, k_max) - k_min).astype(np.int64)
+
+
+# ---- Faster R-CNN target / loss side (tvision/rpn.py:179-213,282-318; tvision/roi_heads.py:22-98,627-651) ----------------
+def rpn_assign(anchors_xyxy, gt, high=0.7, low=0.3):
+    """-> (labels float32 {1, 0, -1}, matched_gt_boxes [N,4])."""
+    if np.asarray(gt).size == 0:
+        return np.zeros(len(anchors_xyxy), F32), np.zeros((len(anchors_xyxy), 4), F32)
+    m = matcher(box_iou(gt, anchors_xyxy), high, low, True)
+    lab = (m >= 0).astype(F32)
+    lab[m == -1] = 0.0
+    lab[m == -2] = -1.0
+    return lab, np.asarray(gt, F32)[np.clip(m, 0, None)]
+
+
+def smooth_l1_sum(x, t, beta):
+    n = np.abs(x.astype(np.float64) - t.astype(np.float64))
+    return np.where(n < beta, 0.5 * n * n / beta, n - 0.5 * beta).sum()
+
+
+def rpn_loss(objectness, deltas, labels, reg_targets, pos_idx, neg_idx):
+    """compute_loss with the sampler's outcome (pos_idx / neg_idx into the concatenated anchors) given."""
+    sampled = np.concatenate([pos_idx, neg_idx])
+    box = smooth_l1_sum(deltas[pos_idx], reg_targets[pos_idx], 1.0 / 9) / sampled.size
+    x = objectness.reshape(-1)[sampled].astype(np.float64)
+    y = labels[sampled].astype(np.float64)
+    bce = (np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))).mean()
+    return F32(bce), F32(box)
+
+
+def roi_assign(proposals, gt_boxes, gt_labels, high=0.5, low=0.5):
+    m = matcher(box_iou(gt_boxes, proposals), high, low, False)
+    lab = np.asarray(gt_labels)[np.clip(m, 0, None)].astype(np.int64)
+    lab[m == -1] = 0
+    lab[m == -2] = -1
+    return np.clip(m, 0, None), lab
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, reg_targets, loss_type="ce"):
+    x = class_logits.astype(np.float64)
+    n, k = x.shape
+    if loss_type == "ce":
+        mx = x.max(1, keepdims=True)
+        lse = mx[:, 0] + np.log(np.exp(x - mx).sum(1))
+        cls = (lse - x[np.arange(n), labels]).mean()
+    else:
+        y = np.zeros_like(x)
+        y[np.arange(n), labels] = 1.0
+        y[:, 0] = 0.0
+        if loss_type == "bce":
+            cls = (np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))).sum() / n
+        else:
+            l, _ = sigmoid_focal_loss(class_logits.astype(F32), y.astype(F32))
+            cls = l.astype(np.float64).sum() / n
+    pos = np.nonzero(labels > 0)[0]
+    br = box_regression.reshape(n, -1, 4)
+    box = smooth_l1_sum(br[pos, labels[pos]], reg_targets[pos], 1.0) / labels.size
+    return F32(cls), F32(box)

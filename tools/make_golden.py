@@ -582,6 +582,67 @@ def g12_retinanet():
     np.savez_compressed(os.path.join(OUT, "g12_retinanet.npz"), **d)
 
 
+# ----------------------------------------------------------------------------- G13 Faster R-CNN targets / losses
+def g13_frcnn():
+    """RegionProposalNetwork.assign_targets_to_anchors / compute_loss and roi_heads.fastrcnn_loss / assign_targets_to_proposals of the
+    reference, called unbound on a namespace that carries the reference's own Matcher and a DETERMINISTIC stand-in sampler."""
+    import types as _t
+    from tvision import _utils, rpn, roi_heads
+    d = {}
+    rng_anchor = detrand.uniform(900, (600, 2), 0, 700)
+    anchors = np.concatenate([rng_anchor, rng_anchor + detrand.uniform(901, (600, 2), 16, 300)], 1).astype(np.float32)
+    gts = [synth_gt_xyxy(910, 5), synth_gt_xyxy(912, 3), np.zeros((0, 4), np.float32)]
+    gts[0][1] = anchors[17]
+    iou = lambda a, b: torch.from_numpy(box_iou_np(a.numpy(), b.numpy()))
+    self_rpn = _t.SimpleNamespace(box_similarity=iou, proposal_matcher=_utils.Matcher(0.7, 0.3, allow_low_quality_matches=True))
+    targets = [{"boxes": torch.from_numpy(g)} for g in gts]
+    labels, mgt = rpn.RegionProposalNetwork.assign_targets_to_anchors(self_rpn, [torch.from_numpy(anchors)] * 3, targets)
+    d["anchors"] = anchors
+    for i in range(3):
+        d[f"gt{i}"], d[f"rpn_labels{i}"], d[f"rpn_mgt{i}"] = gts[i], labels[i].numpy(), mgt[i].numpy()
+    # deterministic sampler: first 8 positives / first 24 negatives per image
+    def sampler(lbls):
+        pos, neg = [], []
+        for l in lbls:
+            p, n = torch.zeros_like(l, dtype=torch.uint8), torch.zeros_like(l, dtype=torch.uint8)
+            p[torch.where(l >= 1)[0][:8]] = 1
+            n[torch.where(l == 0)[0][:24]] = 1
+            pos.append(p)
+            neg.append(n)
+        return pos, neg
+    self_rpn.fg_bg_sampler = sampler
+    obj = torch.from_numpy(detrand.uniform(920, (3 * 600, 1), -3, 3))
+    deltas = torch.from_numpy(detrand.uniform(921, (3 * 600, 4), -1, 1))
+    coder = _utils.BoxCoder((1.0, 1.0, 1.0, 1.0))
+    reg = coder.encode(mgt, [torch.from_numpy(anchors)] * 3)
+    lo, lb = rpn.RegionProposalNetwork.compute_loss(self_rpn, obj, deltas, labels, reg)
+    d["rpn_obj"], d["rpn_deltas"], d["rpn_losses"] = obj.numpy(), deltas.numpy(), np.array([float(lo), float(lb)], np.float64)
+    # RoI heads
+    self_roi = _t.SimpleNamespace(proposal_matcher=_utils.Matcher(0.5, 0.5, allow_low_quality_matches=False))
+    sys.modules["torchvision.ops.boxes"].box_iou = iou
+    roi_heads.box_ops.box_iou = iou
+    props = [torch.from_numpy(np.concatenate([anchors[:200], gts[i]])) for i in range(2)]
+    gl = [torch.from_numpy(detrand.randint(930 + i, (len(gts[i]),), 1, 91)) for i in range(2)]
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})   # reference hard-codes device='cuda'
+    try:
+        mi, lab = roi_heads.RoIHeads.assign_targets_to_proposals(self_roi, props, [torch.from_numpy(g) for g in gts[:2]], gl)
+    finally:
+        torch.tensor = real_tensor
+    for i in range(2):
+        d[f"roi_gl{i}"], d[f"roi_mi{i}"], d[f"roi_lab{i}"] = gl[i].numpy(), mi[i].numpy(), lab[i].numpy()
+    n, k = 96, 91
+    logits = torch.from_numpy(detrand.uniform(940, (n, k), -3, 3))
+    breg = torch.from_numpy(detrand.uniform(941, (n, k * 4), -1, 1))
+    lbl = detrand.randint(942, (n,), 0, k)
+    lbl[::3] = 0
+    tgt = torch.from_numpy(detrand.uniform(943, (n, 4), -1, 1))
+    d["frcnn_logits"], d["frcnn_breg"], d["frcnn_labels"], d["frcnn_tgt"] = logits.numpy(), breg.numpy(), lbl, tgt.numpy()
+    c, b = roi_heads.fastrcnn_loss(logits, breg, [torch.from_numpy(lbl)], [tgt], loss_type="ce")
+    d["frcnn_losses_ce"] = np.array([float(c), float(b)], np.float64)
+    np.savez_compressed(os.path.join(OUT, "g13_frcnn.npz"), **d)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -594,6 +655,7 @@ def main():
     g8_network(yolohead, darknet)
     g5_7_tvision()
     g12_retinanet()
+    g13_frcnn()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
