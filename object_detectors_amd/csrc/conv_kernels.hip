@@ -104,6 +104,33 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Per-channel partial sums of one workgroup tile -> rows of the partial buffer [row][2][CoutPad].  A row always stands for
+// 128 consecutive lattice pixels (row = m / 128) whatever the tile height, so every tile configuration fills the same
+// rows (a 256-pixel tile writes two) and no row is left stale when the autotuner switches configurations.
+template <int WM, int TM, int BN>
+__device__ __forceinline__ void write_partial_rows(const IgemmParams& p, const float* sred, int tid, int nthreads, int mt, int n0) {
+  constexpr int BM = WM * TM * 16;
+  static_assert(BM % 128 == 0, "tiles are multiples of 128 pixels");
+  constexpr int G = BM / 128;            // rows per tile
+  constexpr int WPG = WM / G;            // waves (in M) per row
+  static_assert(WM % G == 0, "a 128-pixel row must be covered by whole waves");
+  const int nrows = (p.M + 127) / 128;
+  for (int i = tid; i < BN * G; i += nthreads) {
+    const int c = i % BN, g = i / BN;
+    const int row = mt * G + g;
+    if (row >= nrows) continue;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPG; ++w) {
+      s1 += sred[((g * WPG + w) * BN + c) * 2 + 0];
+      s2 += sred[((g * WPG + w) * BN + c) * 2 + 1];
+    }
+    float* dst = p.stats + (long long)row * 2 * p.CoutPad;
+    dst[n0 + c] = s1;
+    dst[p.CoutPad + n0 + c] = s2;
+  }
+}
+
 // ---- shared epilogue.  `consumer` = this wave holds accumulators (false for a dedicated loader wave, which only
 //      takes part in the barrier and the final statistics write)
 template <int WM, int WN, int TM, int TN, int EPI>
@@ -137,17 +164,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       }
     }
     __syncthreads();
-    for (int c = tid; c < BN; c += nthreads) {
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        s1 += sred[(w * BN + c) * 2 + 0];
-        s2 += sred[(w * BN + c) * 2 + 1];
-      }
-      float* dst = p.stats + (long long)mt * 2 * p.CoutPad;
-      dst[n0 + c] = s1;
-      dst[p.CoutPad + n0 + c] = s2;
-    }
+    write_partial_rows<WM, TM, BN>(p, (const float*)smem, tid, nthreads, mt, n0);
   }
   if (!consumer) return;
   if (EPI == EPI_F32) {

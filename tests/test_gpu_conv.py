@@ -239,3 +239,31 @@ def test_batched_pack_equals_single_pack():
         assert torch.equal(wf, wf0), cases[i]
         n = lib().mi355det_dgrad_pack_elems(C.byref(keep[4 * i])) - 64          # the 64 trailing elements are slack
         assert torch.equal(wd[:n], wd0[:n]), cases[i]
+
+
+def test_partial_stats_rows_identical_across_tile_configs():
+    """Every tile configuration must fill the same partial-statistics rows (one per 128 lattice pixels): the plan autotuner runs
+    all of them on one buffer, and bn_finalize sums a fixed number of rows."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout = 3, 24, 24, 128, 256           # M = 1728 = 13.5 rows of 128: the last 256-pixel tile is half empty
+    x = rnd((n, cin, h, w), 1)
+    wt = rnd((cout, cin, 3, 3), 2, (2.0 / (cin * 9)) ** 0.5)
+    shape = ops.conv_shape(n, h, w, cin, cout, 3, 1)
+    wf, _ = ops.pack_weights(shape, wt.to(dev()), want_dgrad=False)
+    xd = nhwc(x)
+    rows = ops.conv_stats_rows(shape)
+    assert rows == (n * h * w + 127) // 128
+    stats = torch.full((rows + 64, 2, ops.cout_pad_of(cout)), 123.0, device=dev())
+    y = torch.zeros((n, h, w, cout), device=dev(), dtype=torch.bfloat16)
+    try:
+        for cfg in (1, 2, 3, 4, 5, 6, 3, 1, 6):
+            lib().mi355det_debug_set(0, cfg)
+            ops.conv_fwd(shape, xd, wf, y, stats=stats)
+            torch.cuda.synchronize()
+            yf = y.float().reshape(-1, cout)
+            s1, s2 = stats[:rows, 0, :cout].sum(0), stats[:rows, 1, :cout].sum(0)
+            torch.testing.assert_close(s1, yf.sum(0), rtol=1e-3, atol=1e-2, msg=f"cfg {cfg} sum")
+            torch.testing.assert_close(s2, (yf * yf).sum(0), rtol=1e-3, atol=1e-2, msg=f"cfg {cfg} sumsq")
+    finally:
+        lib().mi355det_debug_set(0, 0)
