@@ -243,6 +243,19 @@ int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int3
 int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx,
                         const void* residual, int32_t residual_ld, void* stream);
 
+/* Data gradient that also starts the BatchNorm backward of the layer it feeds: dx is the gradient of an activation
+ * a = lrelu(bn(z)); while the dx tile is still on chip the epilogue accumulates that layer's per-channel
+ *   sum dy  and  sum dy*xhat,   dy = dx * lrelu'(z*scale+shift),  xhat = (z-mean)*invstd
+ * into `partials` [rows+64][2][cin_pad] (plain stores, deterministic; rows = mi355det_conv_dgrad_bn_rows(s), the 64
+ * spare rows are scratch), saving the separate bn_act_bwd_reduce pass its re-read of dx.  mi355det_bn_bwd_sum_partials
+ * folds them into sums[2*cin] (same layout as bn_act_bwd_reduce).  scale_shift = [4*cin] of the producing layer. */
+int mi355det_conv_dgrad_bn_rows(const mi355det_conv_shape* s);
+int mi355det_conv_dgrad_bn(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual,
+                           int32_t residual_ld, const void* z, int32_t z_ld, const float* scale_shift, float slope,
+                           float* partials, void* stream);
+int mi355det_bn_bwd_sum_partials(const float* partials, int32_t rows, int32_t c, int32_t c_pad, float* sums,
+                                 void* stream);
+
 /* Weight gradient: dw[cout][k*k*cin] fp32 += x^T dy.  Split over the pixel axis; partial 128x128 tiles go to
  * `workspace` with plain stores and are summed into dw in a fixed order (deterministic, no atomics).
  * dbias != NULL: dbias[cout] += sum_pixels dy. */

@@ -48,6 +48,10 @@ struct IgemmParams {
   const float* scale;    // EPI_F32 / EPI_AFF: per-channel multiplier on the accumulator or null (FrozenBatchNorm2d folded into the conv)
   int relu;              // EPI_F32 / EPI_AFF: ReLU after (scale, shift, residual)
   long long ynstride;    // EPI_F32: elements between images of y (heads write straight into the level-concatenated tensor)
+  const bf16_t* z;       // EPI_BNRED: pre-BN output of the layer whose activation gradient this dgrad writes
+  const float* ss;       // EPI_BNRED: that layer's [4*Cout] scale, shift, mean, invstd
+  int ldz;
+  float slope;
   float* stats;          // EPI_STATS: [gridM][2][CoutPad] partial sum / sumsq
   const bf16_t* res;     // EPI_RES: residual to add
   const bf16_t* zero;    // >= 256 B of zeros
@@ -63,7 +67,7 @@ struct IgemmParams {
   unsigned long long* dbg;   // diagnostic build only (PROF): per-wave phase cycle sums
 };
 
-enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4 };
+enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4, EPI_BNRED = 5 };
 #define EPI_LDS_OFF 4096                               // epilogue staging starts behind the BN-statistics scratch
 #define EPI_LDS_BYTES(nwaves) (EPI_LDS_OFF + (nwaves) * (64 * (8 * 16 * 2 + 16) + 256))   // upper bound (TN <= 8)
 
@@ -206,6 +210,22 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
   const int wid = wm + wn * WM;
   char* reg = smem + EPI_LDS_OFF + wid * (64 * PITCH + 256);
   int* rowpix = (int*)(reg + 64 * PITCH);     // pixel index (or -1) of the 64 staged rows
+  // EPI_BNRED: BatchNorm-backward partial sums of the gradient tile being written (this lane's 8 channels)
+  float bn_sc[EPI == EPI_BNRED ? 8 : 1], bn_sh[EPI == EPI_BNRED ? 8 : 1], bn_mu[EPI == EPI_BNRED ? 8 : 1], bn_is[EPI == EPI_BNRED ? 8 : 1];
+  float bn_a1[EPI == EPI_BNRED ? 8 : 1], bn_a2[EPI == EPI_BNRED ? 8 : 1];
+  if (EPI == EPI_BNRED) {
+    const int cb = n0 + wn * CW + (lane % CH16) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool in = cb + k < p.Cout;
+      bn_sc[k] = in ? p.ss[cb + k] : 0.f;
+      bn_sh[k] = in ? p.ss[p.Cout + cb + k] : 0.f;
+      bn_mu[k] = in ? p.ss[2 * p.Cout + cb + k] : 0.f;
+      bn_is[k] = in ? p.ss[3 * p.Cout + cb + k] : 0.f;
+      bn_a1[k] = 0.f;
+      bn_a2[k] = 0.f;
+    }
+  }
   f32x4_t aff_sc[EPI == EPI_AFF ? TN : 1], aff_sh[EPI == EPI_AFF ? TN : 1];
   if (EPI == EPI_AFF) {
 #pragma unroll
@@ -216,9 +236,33 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       aff_sh[i] = (in && p.bias) ? *(const f32x4_t*)(p.bias + cb) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
   }
+  const int ch = lane % CH16, rsub = lane / CH16;
+  const int co = n0 + wn * CW + ch * 8;
+  constexpr int NPASS = 64 / RPP;
+  constexpr bool kReadsSide = EPI == EPI_RES || EPI == EPI_AFF || EPI == EPI_BNRED;    // residual and / or z tiles are read back
 #pragma unroll
   for (int jh = 0; jh < TM / 4; ++jh) {       // 64 pixels at a time
-    {
+    // Side tiles (skip-connection residual, pre-BN z) come from HBM: issue every load of this 64-pixel block FIRST, so
+    // their latency runs under the LDS staging below instead of once per pass.
+    int pixp[kReadsSide ? NPASS : 1];
+    uint4 rpre[kReadsSide ? NPASS : 1], zpre[EPI == EPI_BNRED ? NPASS : 1];
+    if (kReadsSide) {
+      const bool want_res = EPI == EPI_RES || p.res != nullptr;
+#pragma unroll
+      for (int pass = 0; pass < NPASS; ++pass) {
+        const int m = m0 + wm * (TM * 16) + jh * 64 + pass * RPP + rsub;
+        int pixi = -1;
+        if (m < p.M && co < p.Cout) {
+          const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+          const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+          const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+          if (oy < p.Hout && ox < p.Wout) pixi = (n * p.Hout + oy) * p.Wout + ox;
+        }
+        pixp[pass] = pixi;
+        rpre[pass] = (want_res && pixi >= 0) ? *(const uint4*)(p.res + (long long)pixi * p.ldres + co) : make_uint4(0, 0, 0, 0);
+        if (EPI == EPI_BNRED) zpre[pass] = pixi >= 0 ? *(const uint4*)(p.z + (long long)pixi * p.ldz + co) : make_uint4(0, 0, 0, 0);
+      }
+    } else {
       const int m = m0 + wm * (TM * 16) + jh * 64 + lane;
       int pixi = -1;
       if (m < p.M) {
@@ -242,16 +286,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
         *(uint2*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fq * 4) * 2) = o;
       }
     }
-    const int ch = lane % CH16, rsub = lane / CH16;
-    const int co = n0 + wn * CW + ch * 8;
 #pragma unroll
-    for (int pass = 0; pass < 64 / RPP; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       const int row = pass * RPP + rsub;
-      const int pixi = rowpix[row];
+      const int pixi = kReadsSide ? pixp[pass] : rowpix[row];
       uint4 v = *(const uint4*)(reg + row * PITCH + ch * 16);
       if (pixi >= 0 && co < p.Cout) {
-        if (EPI == EPI_RES || (EPI == EPI_AFF && (p.res != nullptr || p.relu))) {
-          const uint4 rr = (EPI == EPI_RES || p.res != nullptr) ? *(const uint4*)(p.res + (long long)pixi * p.ldres + co) : make_uint4(0, 0, 0, 0);
+        if (EPI == EPI_RES || ((EPI == EPI_AFF || EPI == EPI_BNRED) && (p.res != nullptr || p.relu))) {
+          const uint4 rr = rpre[kReadsSide ? pass : 0];
           const bool relu = EPI == EPI_AFF && p.relu;
           const unsigned vi[4] = {v.x, v.y, v.z, v.w}, ri[4] = {rr.x, rr.y, rr.z, rr.w};
           unsigned oo[4];
@@ -268,8 +310,49 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
           v = make_uint4(oo[0], oo[1], oo[2], oo[3]);
         }
         *(uint4*)((bf16_t*)p.y + (long long)pixi * p.ldout + co) = v;
+        if (EPI == EPI_BNRED) {
+          // sums over the STORED (bf16) gradient, as the separate reduce kernel would read it back
+          const uint4 zz = zpre[EPI == EPI_BNRED ? pass : 0];
+          const unsigned gi[4] = {v.x, v.y, v.z, v.w}, zi[4] = {zz.x, zz.y, zz.z, zz.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int hsel = 0; hsel < 2; ++hsel) {
+              const int k = q * 2 + hsel;
+              const float gv = bf2f((bf16_t)(hsel ? gi[q] >> 16 : gi[q] & 0xFFFF));
+              const float zv = bf2f((bf16_t)(hsel ? zi[q] >> 16 : zi[q] & 0xFFFF));
+              const float yv = zv * bn_sc[k] + bn_sh[k];
+              const float dy = yv > 0.f ? gv : gv * p.slope;
+              bn_a1[k] += dy;
+              bn_a2[k] += dy * ((zv - bn_mu[k]) * bn_is[k]);
+            }
+          }
+        }
       }
     }
+  }
+  if (EPI == EPI_BNRED) {
+    // lanes that share a channel chunk (same lane % CH16) hold partial sums of different rows: fold them, then one lane per
+    // chunk publishes the wave's sums; waves stacked in M are combined per 128-pixel row by write_partial_rows
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int o = CH16; o < 64; o <<= 1) {
+        bn_a1[k] += __shfl_xor(bn_a1[k], o, 64);
+        bn_a2[k] += __shfl_xor(bn_a2[k], o, 64);
+      }
+    }
+    float* sred = (float*)smem;   // [WM][BN][2]
+    if (lane < CH16) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = wn * CW + lane * 8 + k;
+        sred[(wm * BN + c) * 2 + 0] = bn_a1[k];
+        sred[(wm * BN + c) * 2 + 1] = bn_a2[k];
+      }
+    }
+    __syncthreads();
+    write_partial_rows<WM, TM, BN>(p, sred, tid, nthreads, mt, n0);
   }
 }
 
@@ -1395,8 +1478,8 @@ int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* 
   return check_launch("unpack_wgrad");
 }
 
-int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
-                        void* stream) {
+static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                           const void* z, int32_t z_ld, const float* scale_shift, float slope, float* partials, void* stream) {
   if (int e = check_shape(s, "conv_dgrad")) return e;
   if (int e = ensure_zero_page()) return e;
   if (s->cout % 32 != 0) return fail(MI355DET_EINVAL, "%s: Cout (the dgrad reduction dim) must be a multiple of 32 (got %lld)", "conv_dgrad", s->cout);
@@ -1407,6 +1490,7 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
     IgemmParams p{};
     int ft[9];
     p.T = dgrad_taps(s, c >> 1, c & 1, ft, p.dy, p.dx);
+    if (p.T == 0 && partials) return fail(MI355DET_EINVAL, "%s: 1x1 stride-2 layers are not supported by the fused BN reduction", "conv_dgrad_bn");
     if (p.T == 0) {
       // 1x1 stride-2 convolutions never read the odd input rows / columns: their data gradient is zero (+ residual)
       const int mh = (s->h + 1) / 2, mw = (s->w + 1) / 2;
@@ -1434,11 +1518,40 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
     p.dMW = make_fastdiv((unsigned)p.MW);
     p.dMH = make_fastdiv((unsigned)p.MH);
     set_tap_pad(p);
-    int e = residual ? dispatch_igemm<EPI_RES>(p, S(stream)) : dispatch_igemm<EPI_PLAIN>(p, S(stream));
+    int e;
+    if (partials) {
+      p.z = (const bf16_t*)z;
+      p.ldz = z_ld;
+      p.ss = scale_shift;
+      p.slope = slope;
+      p.stats = partials + (long long)c * ((p.M + 127) / 128) * 2 * cin_pad;    // each parity class fills its own rows
+      e = dispatch_igemm<EPI_BNRED>(p, S(stream));
+    } else {
+      e = residual ? dispatch_igemm<EPI_RES>(p, S(stream)) : dispatch_igemm<EPI_PLAIN>(p, S(stream));
+    }
     if (e < 0) return e;
     wp += (long long)cin_pad * p.T * s->cout;
   }
   return 0;
+}
+
+int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                        void* stream) {
+  return conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, nullptr, 0, nullptr, 0.f, nullptr, stream);
+}
+
+int mi355det_conv_dgrad_bn_rows(const mi355det_conv_shape* s) {
+  if (!s) return 0;
+  if (s->stride == 1) return (int)(((long long)s->n * s->h * s->w + 127) / 128);
+  const long long mc = (long long)s->n * ((s->h + 1) / 2) * ((s->w + 1) / 2);
+  return (int)(4 * ((mc + 127) / 128));
+}
+
+int mi355det_conv_dgrad_bn(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                           const void* z, int32_t z_ld, const float* scale_shift, float slope, float* partials, void* stream) {
+  if (!z || !scale_shift || !partials) return fail(MI355DET_EINVAL, "%s: null argument", "conv_dgrad_bn");
+  if (s && s->cin % 8 != 0) return fail(MI355DET_EINVAL, "%s: cin must be a multiple of 8", "conv_dgrad_bn");
+  return conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, z, z_ld, scale_shift, slope, partials, stream);
 }
 
 int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int32_t w, void* stream) {

@@ -101,6 +101,30 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
+// final stage of the fused BN-backward reduction: [rows<=256][2][c_pad] -> sums[2*c] (sum dy | sum dy*xhat)
+__global__ __launch_bounds__(256) void bn_bwd_sum_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, float* __restrict__ sums) {
+  __shared__ float sh[8][32][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (ch < c)
+    for (int r = rl; r < rows; r += 8) {
+      s1 += partial[(size_t)r * 2 * c_pad + ch];
+      s2 += partial[(size_t)r * 2 * c_pad + c_pad + ch];
+    }
+  sh[rl][cl][0] = s1;
+  sh[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    for (int r = 1; r < 8; ++r) {
+      s1 += sh[r][cl][0];
+      s2 += sh[r][cl][1];
+    }
+    sums[ch] = s1;
+    sums[c + ch] = s2;
+  }
+}
+
 // eval-mode scale/shift from running stats
 __global__ void bn_eval_kernel(int c, const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
                                const float* __restrict__ rvar, float eps, float* __restrict__ ss) {
@@ -394,6 +418,19 @@ int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale_shift);
   return check_launch("bn_finalize");
+}
+
+int mi355det_bn_bwd_sum_partials(const float* partials, int32_t rows, int32_t c, int32_t c_pad, float* sums, void* stream) {
+  if (c <= 0 || rows <= 0 || c_pad < c) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_bwd_sum_partials");
+  if (rows > 256) {
+    const int chunks = 64, chunk = (rows + chunks - 1) / chunks;
+    float* scratch = const_cast<float*>(partials) + (size_t)rows * 2 * c_pad;     // the 64 spare rows behind the partials
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((c_pad + 31) / 32, chunks), dim3(256), 0, S(stream), partials, rows, c_pad, chunk, scratch);
+    partials = scratch;
+    rows = chunks;
+  }
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32), dim3(256), 0, S(stream), partials, rows, c, c_pad, sums);
+  return check_launch("bn_bwd_sum_partials");
 }
 
 int mi355det_bn_eval_scale_shift(int32_t c, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,

@@ -398,3 +398,16 @@ def retina_loss(cls_logits, bbox_regression, anchors, matched, gt_boxes, gt_labe
                                      ptr(class_scale), n, rows, k, float(alpha), float(gamma), float(grad_scale), ptr(nfg), ptr(losses),
                                      ptr(grad_logits) if want_grad else None, ptr(grad_regression) if want_grad else None, stream_ptr()), "retina_loss")
     return losses, nfg, grad_logits, grad_regression
+
+
+def conv_dgrad_bn(shape, dy, w_dgrad, dx, z, scale_shift, slope, residual=None, residual_ld=0):
+    """dgrad + fused BN-backward partial sums of the layer that produced dx's activation -> sums [2*cin]."""
+    L = lib()
+    rows = L.mi355det_conv_dgrad_bn_rows(C.byref(shape))
+    cin_pad = pad_to(shape.cin, 32)
+    partials = torch.empty((rows + 64, 2, cin_pad), device=dx.device, dtype=torch.float32)
+    check(L.mi355det_conv_dgrad_bn(C.byref(shape), ptr(dy), ptr(w_dgrad), ptr(dx), ptr(residual), int(residual_ld), ptr(z), shape.in_ld,
+                                   ptr(scale_shift), float(slope), ptr(partials), stream_ptr()), "conv_dgrad_bn")
+    sums = torch.empty(2 * shape.cin, device=dx.device, dtype=torch.float32)
+    check(L.mi355det_bn_bwd_sum_partials(ptr(partials), rows, shape.cin, cin_pad, ptr(sums), stream_ptr()), "bn_bwd_sum_partials")
+    return sums

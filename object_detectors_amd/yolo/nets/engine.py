@@ -13,6 +13,7 @@ Mirrors the forward graph of the reference's `DarkNet` (yolo/nets/backbone/darkn
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -36,6 +37,7 @@ class Act:
         self.grad = None
         self.grad_written = False
         self.skips = []
+        self.conv_consumers = 0      # convolutions reading this activation (their dgrads all add into its gradient)
 
     @property
     def ptr(self):
@@ -314,6 +316,7 @@ class Plan:
         def conv_bn(name, x, out=None, res=None):
             s = eng.by_name[name]
             shp = eng._wshape(s, x.n, x.h, x.w, in_ld=x.ld)
+            x.conv_consumers += 1
             a = out if out is not None else new_act(x.n, shp.ho, shp.wo, shp.cout)
             shp.out_ld = shp.cout   # z pitch
             z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
@@ -339,12 +342,14 @@ class Plan:
                                                      res.ld if res else 0, a.ptr, a.ld, self.stream)))
             self.dz_elems = max(self.dz_elems, pixels * shp.cout)
             rec = dict(kind="cbl", name=name, spec=s, shp=shp, x=x, a=a, res=res, z=z, ss=ss, pixels=pixels)
+            a.producer = rec
             self.ops.append(rec)
             self.layers[name] = rec
             return a
 
         def conv_out(name, x, k):
             s = eng.by_name[name]
+            x.conv_consumers += 1
             shp = eng._wshape(s, x.n, x.h, x.w, in_ld=x.ld, out_ld=eng.head_ld)
             shp_f = ops.conv_shape(x.n, x.h, x.w, s.cin, s.cout, 1, 1, x.ld, eng.head_ld)   # true cout: masks the pad channel
             wf, wd = eng.packed[name]
@@ -423,6 +428,10 @@ class Plan:
         # (reduce -> apply -> dgrad), and the HBM-bound BN passes overlap with its MFMA work.
         self.dz2 = [torch.zeros(self.dz_elems, device=dev, dtype=bf) for _ in range(2)]
         self.dz = self.dz2[0]
+        # BN-backward reduction fused into the producing dgrad's epilogue (mi355det_conv_dgrad_bn): correct and tested, but measured
+        # SLOWER end to end in round 1 (849 vs 871 img/s): the z tile is read at the tile's end where nothing hides the HBM latency.
+        # Opt-in until the prefetch is moved into the last k-steps.
+        self.fuse_bn_reduce = os.environ.get("MI355DET_BN_FUSION", "0") == "1"
         self.side = torch.cuda.Stream(device=dev)
         side_ptr = C.c_void_p(self.side.cuda_stream)
         main = torch.cuda.current_stream(dev)
@@ -452,8 +461,19 @@ class Plan:
                 self.keep.append(shp)
             if not x.grad_written:
                 r = x.skips.pop(0) if x.skips else None
-                self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, r.ptr if r else None, r.ld if r else 0,
-                                                         self.stream)))
+                prod = getattr(x, "producer", None)
+                # this dgrad writes the COMPLETE gradient of a BN+LeakyReLU activation (single conv consumer, at most one skip,
+                # fused as the epilogue residual): start that layer's BatchNorm backward here, while the tile is on chip
+                if prod is not None and x.conv_consumers == 1 and not x.skips and self.fuse_bn_reduce:
+                    rows = L.mi355det_conv_dgrad_bn_rows(C.byref(shp))
+                    cpad = ops.pad_to(x.c, 32)
+                    part = torch.zeros((rows + 64, 2, cpad), device=dev, dtype=torch.float32)
+                    prod["bn_partials"] = (part, rows, cpad)
+                    self.bwd.append((L.mi355det_conv_dgrad_bn, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, r.ptr if r else None, r.ld if r else 0,
+                                                                _vp(prod["z"]), x.c, _vp(prod["ss"]), SLOPE, _vp(part), self.stream)))
+                else:
+                    self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, r.ptr if r else None, r.ld if r else 0,
+                                                             self.stream)))
                 x.grad_written = True
             else:
                 self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, g.ptr, g.ld, self.stream)))
@@ -496,8 +516,12 @@ class Plan:
                 di = flip[0]
                 flip[0] ^= 1
                 dzb = self.dz2[di]
-                self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
-                                                                _vp(sums), self.stream)))
+                if "bn_partials" in rec:      # the dgrad that produced g already accumulated the per-channel partial sums
+                    part, prows, cpad = rec["bn_partials"]
+                    self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), prows, shp.cout, cpad, _vp(sums), self.stream)))
+                else:
+                    self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
+                                                                    _vp(sums), self.stream)))
                 if wg_done[di] is not None:
                     py(main.wait_event, wg_done[di])      # the wgrad that last read this dz buffer has finished
                 self.bwd.append((L.mi355det_bn_act_bwd_apply, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), _vp(sums), None, shp.cout,

@@ -267,3 +267,37 @@ def test_partial_stats_rows_identical_across_tile_configs():
             torch.testing.assert_close(s2, (yf * yf).sum(0), rtol=1e-3, atol=1e-2, msg=f"cfg {cfg} sumsq")
     finally:
         lib().mi355det_debug_set(0, 0)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 128, 256, 3, 1), (2, 16, 16, 64, 128, 3, 2), (3, 13, 13, 256, 128, 1, 1), (2, 26, 26, 32, 64, 3, 2),
+                                  (1, 40, 40, 256, 512, 3, 1)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_dgrad_with_fused_bn_backward_sums(case, with_res):
+    """mi355det_conv_dgrad_bn: dx identical to the plain dgrad, and its per-channel sums equal bn_act_bwd_reduce on that dx."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    n, h, w, cin, cout, k, s = case
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s)
+    wt = rnd((cout, cin, k, k), 2, (2.0 / (cin * k * k)) ** 0.5)
+    _, wd = ops.pack_weights(shape, wt.to(dev()))
+    dy = nhwc(rnd((n, cout, shape.ho, shape.wo), 3))
+    z = nhwc(rnd((n, cin, h, w), 4))                      # pre-BN output of the layer that produced this conv's input
+    res = nhwc(rnd((n, cin, h, w), 5)) if with_res else None
+    g = torch.Generator().manual_seed(6)
+    ss = torch.cat([torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3, torch.randn(cin, generator=g) * 0.2,
+                    torch.rand(cin, generator=g) + 0.5]).to(dev())
+    dx0 = torch.zeros((n, h, w, cin), device=dev(), dtype=torch.bfloat16)
+    ops.conv_dgrad(shape, dy, wd, dx0, residual=res, residual_ld=cin)
+    want = torch.zeros(2 * cin, device=dev())
+    check(lib().mi355det_bn_act_bwd_reduce(ptr(dx0), cin, None, 0, ptr(z), cin, ptr(ss), cin, n * h * w, 0.1, ptr(want), stream_ptr()), "reduce")
+    for cfg in (0, 1, 3, 6):
+        lib().mi355det_debug_set(0, cfg)
+        try:
+            dx = torch.full_like(dx0, 9.0)
+            sums = ops.conv_dgrad_bn(shape, dy, wd, dx, z, ss, 0.1, residual=res, residual_ld=cin)
+            torch.cuda.synchronize()
+        finally:
+            lib().mi355det_debug_set(0, 0)
+        assert torch.equal(dx, dx0), cfg
+        scale = float(want.abs().max())
+        assert float((sums - want).abs().max()) <= 2e-3 * scale + 1e-3, (cfg, float((sums - want).abs().max()), scale)
