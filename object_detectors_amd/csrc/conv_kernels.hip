@@ -588,6 +588,192 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
 }
 
+// ---- 3x3 stride-1 form with shared pixel tiles ("dx reuse") ----------------------------------------------------------
+// The implicit GEMM above stages one pixel tile per tap: nine per channel chunk, although the three taps of one kernel
+// row read the SAME pixels shifted by one.  Measured (tools/micro/l2_lds_bw.hip): a CU stages ~73-89 GB/s from L2, and at
+// 64 FLOP per staged byte that rate, not the MFMA pipe, bounds the 128x128 tile.  Here the loop is ordered
+// (channel chunk, kernel row, dx): per kernel row ONE extended pixel tile (rows m0-8 .. m0+BM+7 of the linear lattice,
+// shifted by dy*W) is staged and the three dx taps read it at row offsets dx; lanes whose pixel sits on the image's left /
+// right edge get a zero fragment for dx = -1 / +1 (the neighbour in memory is the previous / next image row).  Pixel bytes
+// per chunk drop 3x (staged bytes -31 % at 128x128).  Weights keep their own 2-deep ring (one tile per tap).
+// vmcnt bookkeeping: per step the wave issues B(s+1) first, then its share (2,2,1 pieces) of the next group's pixel tile,
+// so "all but the pieces issued after B(s)" is a compile-time count at each of the three unrolled positions.
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 ? 1 : 2)) void igemm_dx_kernel(const IgemmParams p) {
+  constexpr int BK = 64, NT = WM * WN * 64, NW = WM * WN;
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, ROWB = 128, R = 8, CPR = 8;
+  constexpr int A_INSTR = BM / R + 2;                    // 8 halo rows each side (one LDS-DMA piece = 8 rows)
+  constexpr int A_PER = (A_INSTR + NW - 1) / NW;         // pieces per wave per group (the surplus ones are dummies)
+  constexpr int A_ROWS = A_PER * NW * R;
+  constexpr int B_INSTR = BN / R, B_PER = B_INSTR / NW;
+  static_assert(B_INSTR % NW == 0, "weight tile must split evenly over the waves");
+  constexpr int AC0 = (A_PER + 2) / 3, AC1 = (A_PER + 1) / 3, AC2 = A_PER / 3;   // pieces issued at dx position 0, 1, 2
+  constexpr int ABYTES = A_ROWS * ROWB, BBYTES = BN * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const abuf0 = smem;
+  char* const bbuf0 = smem + 2 * ABYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid % WM, wn = wid / WM;
+  const int ntn = p.CoutPad / BN, nblk = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int mt = bid / ntn, nt = bid - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int n_first = (int)fdiv(fdiv((unsigned)max(m0 - 8, 0), p.dMW), p.dMH);
+  const int Ktot = 9 * p.Cin;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+
+  // scalar tap geometry: kernel row g uses taps 3g..3g+2 (same dy); dx of position i is the same for every row
+  int dyg[3], dxi[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    dyg[g] = (int)((p.dy_pack >> (12 * g)) & 0xF) - 2;
+    dxi[g] = (int)((p.dx_pack >> (4 * g)) & 0xF) - 2;
+  }
+
+  // ---- pixel-tile rows this lane stages: extended row e <-> lattice pixel m0 - 8 + e
+  const int lrow = lane >> 3, cpos = lane & 7;
+  int a_voff[A_PER];
+  unsigned a_valid[A_PER];      // bit g: source row y + dy_g inside the image
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int instr = wid * A_PER + i;
+    const int e = instr * R + lrow;
+    const int m = m0 - 8 + e;
+    unsigned vm = 0;
+    int voff = OOB_VOFF;
+    if (instr < A_INSTR && m >= 0 && m < p.M) {
+      const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+      const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+      voff = ((((n - n_first) * p.Hin + yy) * p.Win + xx) * p.ldin + (cpos ^ swz<BK>(e)) * 8) * 2;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) vm |= ((unsigned)(yy + dyg[g]) < (unsigned)p.Hin) ? (1u << g) : 0u;
+    }
+    a_voff[i] = voff;
+    a_valid[i] = vm;
+  }
+  int b_voff[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int row = (wid * B_PER + i) * R + lrow;
+    b_voff[i] = (row * Ktot + (cpos ^ swz<BK>(row)) * 8) * 2;
+  }
+
+  // ---- fragment read offsets: pixel fragments per dx position (row shift + its own swizzle phase) and edge masks
+  const int fr = lane & 15, fq = lane >> 4;
+  int afrag[3][TM];
+  unsigned edge[3];             // bit j: this lane's pixel of group j has no neighbour in direction dx_i
+#pragma unroll
+  for (int i = 0; i < 3; ++i) edge[i] = 0;
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int r = wm * (TM * 16) + j * 16 + fr;
+    const int m = m0 + r;
+    const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = r + 8 + dxi[i];
+      afrag[i][j] = e * ROWB + ((fq ^ swz<BK>(e)) << 4);
+      const bool off = (dxi[i] < 0 && xx == 0) || (dxi[i] > 0 && xx == p.MW - 1);
+      edge[i] |= off ? (1u << j) : 0u;
+    }
+  }
+  int wfrag[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * (TN * 16) + i * 16 + fr;
+    wfrag[i] = row * ROWB + ((fq ^ swz<BK>(row)) << 4);
+  }
+
+  f32x4_t acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  const int cin_steps = p.Cin / BK;
+  const int NQ = 3 * cin_steps;             // groups: channel chunk outer, kernel row inner
+  const int rowpitch2 = p.Win * p.ldin * 2; // bytes per image row
+
+  // group q = (chunk c, kernel row g): scalar byte offset of its pixel tile; step (q, i): scalar offset of its weight tile
+  auto a_soff = [&](int c, int g) { return (dyg[g] * p.Win * p.ldin + p.tap_pad) * 2 + c * (BK * 2); };
+  auto issue_a = [&](int lo, int hi, int c, int g, char* ab) {
+    const int soff = a_soff(c, g);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i)
+      if (i >= lo && i < hi) bufld16(rsrc_x, ab + (wid * A_PER + i) * 1024, ((a_valid[i] >> g) & 1u) ? a_voff[i] : OOB_VOFF, soff);
+  };
+  auto issue_b = [&](int c, int g, int i, char* bb) {
+    const int koff = ((3 * g + i) * p.Cin + c * BK) * 2;
+#pragma unroll
+    for (int q = 0; q < B_PER; ++q) bufld16(rsrc_w, bb + (wid * B_PER + q) * 1024, b_voff[q], koff);
+  };
+  (void)rowpitch2;
+
+  issue_a(0, A_PER, 0, 0, abuf0);
+  issue_b(0, 0, 0, bbuf0);
+
+  int c = 0, g = 0;           // current group
+  int sb = 0;                 // weight buffer of the current step
+  for (int q = 0; q < NQ; ++q) {
+    const bool has_next = q + 1 < NQ;
+    int cn = c, gn = g + 1;   // next group
+    if (gn == 3) {
+      gn = 0;
+      ++cn;
+    }
+    char* const ab = abuf0 + (q & 1) * ABYTES;
+    char* const abn = abuf0 + ((q + 1) & 1) * ABYTES;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      // B(s) was issued one step ago, followed by that step's share of the next pixel tile: those may stay in flight
+      if (i == 0 || !has_next) wait_vmcnt<0>();
+      else if (i == 1) wait_vmcnt<AC0>();
+      else wait_vmcnt<AC1>();
+      __builtin_amdgcn_s_barrier();
+      char* const bb = bbuf0 + sb * BBYTES;
+      char* const bbn = bbuf0 + (sb ^ 1) * BBYTES;
+      if (i < 2) issue_b(c, g, i + 1, bbn);
+      else if (has_next) issue_b(cn, gn, 0, bbn);
+      if (has_next) {
+        if (i == 0) issue_a(0, AC0, cn, gn, abn);
+        else if (i == 1) issue_a(AC0, AC0 + AC1, cn, gn, abn);
+        else issue_a(AC0 + AC1, A_PER, cn, gn, abn);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t wf[TN], af[TM];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8_t*)(bb + (wfrag[t] ^ (ks << 6)));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          af[j] = *(const bf16x8_t*)(ab + (afrag[i][j] ^ (ks << 6)));
+          if ((edge[i] >> j) & 1u) af[j] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af[j], acc[t][j], 0, 0, 0);
+      }
+      sb ^= 1;
+    }
+    c = cn;
+    g = gn;
+  }
+  (void)AC2;
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
+  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
+}
+
 // Interleaved variant (2-buffer ring): all fragment reads of a k-step are issued up front (the second half's LDS
 // latency hides under the first half's MFMAs) and the next stage's LDS-DMA pieces are issued BRANCH-FREE between
 // groups of MFMAs (past the last stage the pieces carry an out-of-range offset and just zero-fill the idle buffer),
@@ -1055,6 +1241,39 @@ unsigned long long igemm_key(const IgemmParams& p, int epi) {
   return k;
 }
 
+// applicability of the dx-reuse kernel: 3x3, unit strides on both sides, taps in three rows of equal dy with dx stepping by +-1
+static bool dx_applicable(const IgemmParams& p) {
+  if (p.T != 9 || p.so != 1 || p.sin != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
+  if (p.Hin != p.Hout || p.Win != p.Wout || p.MH != p.Hin || p.MW != p.Win) return false;
+  if (p.Cin % 64 != 0 || p.CoutPad % 128 != 0) return false;
+  for (int g = 0; g < 3; ++g) {
+    if (p.dy[3 * g] != p.dy[3 * g + 1] || p.dy[3 * g] != p.dy[3 * g + 2]) return false;
+    for (int i = 0; i < 3; ++i)
+      if (p.dx[3 * g + i] != p.dx[i] || p.dx[i] < -1 || p.dx[i] > 1) return false;
+    if (p.dy[3 * g] < -1 || p.dy[3 * g] > 1) return false;
+  }
+  return p.dx[0] != p.dx[1] && p.dx[1] != p.dx[2] && p.dx[0] != p.dx[2];
+}
+
+template <int WM, int WN, int TM, int TN, int EPI>
+int launch_dx(const IgemmParams& p, hipStream_t st) {
+  if (!dx_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
+  constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int A_PER = (BM / 8 + 2 + NW - 1) / NW;
+  constexpr int lds_ring = 2 * A_PER * NW * 8 * 128 + 2 * BN * 128;
+  constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
+  constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
+  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
+  return check_launch("igemm_dx");
+}
+
 // tile configurations for Cout % 128 == 0 and Cin % 64 == 0 (pixels x channels x k-step, ring depth):
 //   1: 128x128x64 x2, 4 waves of 64x64, 2 workgroups/CU        2: 256x128x32 x2, 4 waves of 128x64, 48 KB
 //   3: 256x256x64 x2, 8 waves of 128x64, 1 workgroup/CU        4: 128x128x32 x3, 4 waves of 64x64, 3 workgroups/CU
@@ -1075,6 +1294,11 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 13: return launch_ws<2, 2, 8, 4, 64, 3, 4, EPI>(p, st);   // ws 256x128x64 ring 3, 4 loaders
     case 14: return launch_ws<2, 2, 4, 4, 32, 4, 2, EPI>(p, st);   // ws 128x128x32 ring 4 (64 KB, 2 WG/CU), 2 loaders
     case 6: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 0>(p, st); break;   // interleaved 256x256x64, 8 waves of 128x64
+    case 15: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI>(p, st); break;             // 3x3 s1: shared pixel tiles (dx reuse), 128x128
+    case 16: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI>(p, st); break;             // dx reuse 256x128, 8 waves, 1 workgroup/CU
+    case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves
+    case 18: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 8, 4, EPI>(p, st); break;   // dx reuse 256x256, 8 waves of 128x64
+    case 19: if (dx_applicable(p)) return launch_dx<2, 2, 8, 4, EPI>(p, st); break;                           // dx reuse 256x128, 4 waves of 128x64
     case 21: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 1>(p, st); break;   // ablations of cfg 1
     case 22: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 2>(p, st); break;
     case 23: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 3>(p, st); break;
@@ -1116,8 +1340,10 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
   float best_ms = 1e30f;
-  for (int cfg = 1; cfg <= 6; ++cfg) {
+  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19};
+  for (int cfg : cands) {
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
+    if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18) && p.CoutPad % 256 != 0))) continue;
     int e = run_cfg<EPI>(cfg, p, st);
     if (e) return e;
     (void)hipEventRecord(e0, st);

@@ -301,3 +301,51 @@ def test_dgrad_with_fused_bn_backward_sums(case, with_res):
         assert torch.equal(dx, dx0), cfg
         scale = float(want.abs().max())
         assert float((sums - want).abs().max()) <= 2e-3 * scale + 1e-3, (cfg, float((sums - want).abs().max()), scale)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (2, 9, 11, 128, 256), (3, 13, 13, 64, 128), (1, 20, 20, 512, 1024), (2, 40, 40, 256, 512),
+                                  (1, 5, 3, 192, 128)])
+def test_dx_reuse_kernel_matches_default(case):
+    """Tile configuration 15 (3x3 stride-1 kernel with shared pixel tiles) against PyTorch fp32 and the default configuration:
+    forward (+ BN partial statistics) and data gradient (+ residual), image edges and tile tails included."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout = case
+    x = rnd((n, cin, h, w), 1)
+    wt = rnd((cout, cin, 3, 3), 2, (2.0 / (cin * 9)) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), wt.clone()
+    y_ref = F.conv2d(xr, wr, padding=1)
+    gy = rnd(tuple(y_ref.shape), 3)
+    y_ref.backward(gy)
+    shape = ops.conv_shape(n, h, w, cin, cout, 3, 1)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    xd, gyd = nhwc(x), nhwc(gy)
+    res = nhwc(rnd((n, cin, h, w), 4))
+    rows = ops.conv_stats_rows(shape)
+    outs = {}
+    try:
+        for cfg in (1, 15, 16, 17, 18, 19):
+            lib().mi355det_debug_set(0, cfg)
+            y = torch.full((n, h, w, cout), 5.0, device=dev(), dtype=torch.bfloat16)
+            stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())
+            ops.conv_fwd(shape, xd, wf, y, stats=stats)
+            dx = torch.full((n, h, w, cin), 5.0, device=dev(), dtype=torch.bfloat16)
+            ops.conv_dgrad(shape, gyd, wd, dx)
+            dxr = torch.full((n, h, w, cin), 5.0, device=dev(), dtype=torch.bfloat16)
+            ops.conv_dgrad(shape, gyd, wd, dxr, residual=res, residual_ld=cin)
+            torch.cuda.synchronize()
+            outs[cfg] = (y.float().cpu(), stats[:rows].sum(0).cpu(), dx.float().cpu(), dxr.float().cpu())
+    finally:
+        lib().mi355det_debug_set(0, 0)
+    yr = y_ref.detach().permute(0, 2, 3, 1)
+    gr = xr.grad.permute(0, 2, 3, 1)
+    y1, st1, dx1, dxr1 = outs[1]
+    for cfg in (15, 16, 17, 18, 19):          # 17 / 18 (256-wide) fall back to the default tile when cout % 256 != 0
+        y15, st15, dx15, dxr15 = outs[cfg]
+        assert float((y15 - yr).abs().max()) <= 2e-2 * float(yr.abs().max()), cfg
+        assert float((dx15 - gr).abs().max()) <= 2e-2 * float(gr.abs().max()), cfg
+        # against the default tile configuration: same products, different summation order only
+        assert float((y15 - y1).abs().max()) <= 1e-2 * float(y1.abs().max()), cfg
+        assert float((dx15 - dx1).abs().max()) <= 1e-2 * float(dx1.abs().max()), cfg
+        assert float((dxr15 - dxr1).abs().max()) <= 1e-2 * float(dxr1.abs().max()), cfg
+        torch.testing.assert_close(st15, st1, rtol=2e-2, atol=2e-2 * float(st1.abs().max()))

@@ -25,9 +25,11 @@ def family(name):
     m = re.match(r"(igemm\w*)<([^>]*)>", name)
     if m:
         a = [x.strip() for x in m.group(2).split(",")]
-        epi = {"0": "stats(fwd+BN partials)", "1": "f32 head", "2": "residual(dgrad+skip)", "3": "plain(dgrad)", "4": "affine"}
+        epi = {"0": "stats(fwd+BN partials)", "1": "f32 head", "2": "residual(dgrad+skip)", "3": "plain(dgrad)", "4": "affine", "5": "dgrad+BN partial sums"}
         if m.group(1) == "igemm_kernel":
             return f"igemm {int(a[0]) * int(a[2]) * 16}x{int(a[1]) * int(a[3]) * 16}x{a[4]} ring{a[5]} epi={epi.get(a[6], a[6])}"
+        if m.group(1) == "igemm_dx_kernel":
+            return f"igemm_dx {int(a[0]) * int(a[2]) * 16}x{int(a[1]) * int(a[3]) * 16}x64 (shared pixel tiles) epi={epi.get(a[4], a[4])}"
         return f"igemm_il {int(a[0]) * int(a[2]) * 16}x{int(a[1]) * int(a[3]) * 16}x{a[4]} epi={epi.get(a[5], a[5])}"
     return name.split("(")[0][:70]
 
