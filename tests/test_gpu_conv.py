@@ -304,7 +304,8 @@ def test_dgrad_with_fused_bn_backward_sums(case, with_res):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (2, 9, 11, 128, 256), (3, 13, 13, 64, 128), (1, 20, 20, 512, 1024), (2, 40, 40, 256, 512),
-                                  (1, 5, 3, 192, 128)])
+                                  (1, 5, 3, 192, 128), (2, 1, 1, 256, 256), (2, 2, 2, 256, 128), (16, 1, 1, 256, 256), (3, 2, 1, 64, 128),
+                                  (5, 1, 2, 128, 128)])
 def test_dx_reuse_kernel_matches_default(case):
     """Tile configuration 15 (3x3 stride-1 kernel with shared pixel tiles) against PyTorch fp32 and the default configuration:
     forward (+ BN partial statistics) and data gradient (+ residual), image edges and tile tails included."""
