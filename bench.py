@@ -114,12 +114,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # MI355DET_BENCH_ONE_GPU=1: rehearsal of the multi-process path on a one-GPU box (every rank on cuda:0, gloo instead of RCCL,
+    # which refuses two ranks on one device); never used for reported numbers
+    rehearsal = os.environ.get("MI355DET_BENCH_ONE_GPU", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.parallel import GradSync
@@ -189,6 +197,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss1 = float(out12[0])
+    in_sync = None
+    if world > 1:
+        # data-parallel invariant: identical initial weights + averaged gradients => identical weights on every rank
+        chk = eng.flat_w.double().abs().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(float(hi - lo) <= 1e-9 * float(hi))
 
     if rank == 0:
         ms = 1000.0 * elapsed / args.steps
@@ -211,7 +227,7 @@ def main():
             "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+loss+bwd{'+grad all-reduce' if world > 1 else ''}+SGD step), "
                                    f"synthetic COCO {args.px}px, per-GPU bs={args.batch}, 7 GT/img, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-            "loss_first": round(loss0, 4), "loss_last": round(loss1, 4),
+            "loss_first": round(loss0, 4), "loss_last": round(loss1, 4), "weights_in_sync_across_ranks": in_sync,
             "roofline": roof,
             "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.px),
         }

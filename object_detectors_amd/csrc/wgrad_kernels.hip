@@ -285,6 +285,50 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   if (pl == 0 && ch < c) atomicAdd(out + ch, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// vector form: 16-byte loads (8 channels per lane), rows spread over the lanes that do not fit a channel group
+__global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__ x, int ld, int c, long long pixels, float* __restrict__ out) {
+  __shared__ float red[256 * 8];
+  const int groups = (c + 7) >> 3;
+  const int npl = 256 / groups;                        // pixel lanes per workgroup (groups <= 256 checked on the host)
+  const int gl = threadIdx.x % groups, pl = threadIdx.x / groups;
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = 0.f;
+  if (pl < npl) {
+    const long long stride = (long long)gridDim.x * npl;
+    long long m = (long long)blockIdx.x * npl + pl;
+    for (; m + stride < pixels; m += 2 * stride) {      // two independent 16-byte loads in flight
+      const uint4 u = *(const uint4*)(x + m * ld + gl * 8), v = *(const uint4*)(x + (m + stride) * ld + gl * 8);
+      const unsigned uu[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[2 * q] += bf2f((bf16_t)(uu[q] & 0xFFFF)) + bf2f((bf16_t)(vv[q] & 0xFFFF));
+        a[2 * q + 1] += bf2f((bf16_t)(uu[q] >> 16)) + bf2f((bf16_t)(vv[q] >> 16));
+      }
+    }
+    for (; m < pixels; m += stride) {
+      const uint4 u = *(const uint4*)(x + m * ld + gl * 8);
+      const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[2 * q] += bf2f((bf16_t)(uu[q] & 0xFFFF));
+        a[2 * q + 1] += bf2f((bf16_t)(uu[q] >> 16));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = a[k];
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t = 0.f;
+      for (int r = 0; r < npl; ++r) t += red[(r * groups + gl) * 8 + k];
+      if (gl * 8 + k < c) atomicAdd(out + gl * 8 + k, t);
+    }
+  }
+}
+
 // Split count over the pixel axis from a small cost model (us): whole rounds of 512 resident workgroups, ~0.85 us per
 // 64-pixel k-step at 2 workgroups/CU, plus the slab round trip (~3 TB/s) and one extra launch when splitting.
 int choose_splits(int tiles, int M, double out_bytes) {
@@ -434,7 +478,12 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     const int gy = splits > 8 && gx < 512 ? min((splits + 7) / 8, max(1, 1024 / gx)) : 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, S(stream), p.slab, dw, p.Cout, p.NP, p.co_tiles, p.np_tiles, splits);
   }
-  if (dbias) {
+  if (dbias && s->out_ld % 8 == 0 && (s->cout + 7) / 8 <= 256 && ((s->cout + 7) / 8) * 8 <= s->out_ld && (((uintptr_t)dy) & 15) == 0) {
+    const int groups = (s->cout + 7) / 8, npl = 256 / groups;
+    // few workgroups: every one ends with c same-address atomics (1024 of them cost more than the reads)
+    const int gx = (int)max(1ll, min((long long)128, ((long long)p.M + (long long)npl * 16 - 1) / ((long long)npl * 16)));
+    hipLaunchKernelGGL(colsum8_kernel, dim3(gx), dim3(256), 0, S(stream), (const bf16_t*)dy, s->out_ld, s->cout, (long long)p.M, dbias);
+  } else if (dbias) {
     const int gy = (int)min((long long)256, ((long long)p.M + 255) / 256);
     hipLaunchKernelGGL(colsum_kernel, dim3((p.Cout + 63) / 64, gy), dim3(256), 0, S(stream), (const bf16_t*)dy, s->out_ld, s->cout, (long long)p.M, dbias);
   }

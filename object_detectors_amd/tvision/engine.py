@@ -23,6 +23,7 @@ from ..yolo.nets.engine import Act, comm_hook, _vp
 from .anchor_utils import AnchorGenerator
 
 LAYERS = [3, 4, 6, 3]
+BODY_LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3], "resnet152": [3, 8, 36, 3]}     # utilities/resnet.py:305-341
 PLANES = [64, 128, 256, 512]
 STEM_K = 160        # 7*7*3 = 147 im2col columns padded to a multiple of 32
 IMAGE_MEAN = (0.485, 0.456, 0.406)
@@ -38,7 +39,7 @@ class Conv:
         self.cout_store = ops.pad_to(cout, 32) if head else cout      # dgrad reduces over cout: multiple of 32
 
 
-def arch(num_classes=91, num_anchors=9, trainable_layers=3):
+def arch(num_classes=91, num_anchors=9, trainable_layers=3, body="resnet50"):
     """Ordered conv specs (reference state_dict order).  Frozen: everything in the body below the last
     `trainable_layers` of [layer4, layer3, layer2, layer1, conv1] (backbone_utils.py:100-104); BN is always frozen."""
     if not 0 <= trainable_layers <= 4:
@@ -47,7 +48,7 @@ def arch(num_classes=91, num_anchors=9, trainable_layers=3):
     B = "backbone.body."
     specs = [Conv(B + "conv1", STEM_K, 64, 1, 1, bn=B + "bn1", relu=True, trainable=False)]
     inpl = 64
-    for li, (planes, nb) in enumerate(zip(PLANES, LAYERS), 1):
+    for li, (planes, nb) in enumerate(zip(PLANES, BODY_LAYERS[body]), 1):
         tr = f"layer{li}" in train
         for b in range(nb):
             q = f"{B}layer{li}.{b}"
@@ -73,13 +74,14 @@ def arch(num_classes=91, num_anchors=9, trainable_layers=3):
 
 
 class RetinaNetEngine:
-    def __init__(self, num_classes=91, num_anchors=9, trainable_layers=3, device=None, seed=0, bn_eps=1e-5, normalize=True):
+    def __init__(self, num_classes=91, num_anchors=9, trainable_layers=3, device=None, seed=0, bn_eps=1e-5, normalize=True, body="resnet50"):
         lib()   # fail loudly if the HIP library is missing
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.nc, self.na = num_classes, num_anchors
         self.bn_eps = bn_eps
         self.normalize = normalize
-        self.specs = arch(num_classes, num_anchors, trainable_layers)
+        self.body_name = body
+        self.specs = arch(num_classes, num_anchors, trainable_layers, body)
         self.by_name = {s.name: s for s in self.specs}
         self._layout_params()
         self.reset_parameters(seed)
@@ -364,7 +366,7 @@ class RetinaPlan:
         x = new_act(n, down(h2, 1), down(w2, 1), 64, False)
         self.fwd.append((L.mi355det_maxpool3x3s2, (c1.ptr, c1.ld, n, c1.h, c1.w, 64, x.ptr, x.ld, self.stream)))
         feats = []
-        for li, nb in enumerate(LAYERS, 1):
+        for li, nb in enumerate(BODY_LAYERS[eng.body_name], 1):
             for b in range(nb):
                 q = f"backbone.body.layer{li}.{b}"
                 idn = conv(q + ".downsample.0", x) if b == 0 else x

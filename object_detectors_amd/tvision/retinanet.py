@@ -18,9 +18,9 @@ from .postprocess import retinanet_postprocess_detections
 
 class RetinaNet(nn.Module):
     def __init__(self, num_classes=91, trainable_backbone_layers=3, score_thresh=0.05, nms_thresh=0.5, detections_per_img=300,
-                 topk_candidates=1000, tfidf=None, device=None, seed=0):
+                 topk_candidates=1000, tfidf=None, device=None, seed=0, body="resnet50"):
         super().__init__()
-        self.engine = RetinaNetEngine(num_classes, 9, trainable_backbone_layers, device=device, seed=seed)
+        self.engine = RetinaNetEngine(num_classes, 9, trainable_backbone_layers, device=device, seed=seed, body=body)
         self.score_thresh, self.nms_thresh = score_thresh, nms_thresh
         self.detections_per_img, self.topk_candidates = detections_per_img, topk_candidates
         self.tfidf = None if tfidf is None else tfidf["values"].to(self.engine.device).float()
@@ -72,3 +72,9 @@ def retinanet_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pret
     if trainable_backbone_layers is None:
         trainable_backbone_layers = 3           # _validate_trainable_layers default (backbone_utils.py:127-139)
     return RetinaNet(num_classes, trainable_backbone_layers, tfidf=tfidf, **kwargs)
+
+
+def retinanet_resnet101_fpn(num_classes=1204, trainable_backbone_layers=3, tfidf=None, **kwargs):
+    """BASELINE config 5 (RetinaNet ResNet-101-FPN on LVIS, 1203 classes + background): `resnet_fpn_backbone('resnet101', ...)`
+    (backbone_utils.py:67-110) under the same RetinaNet head."""
+    return RetinaNet(num_classes, trainable_backbone_layers, tfidf=tfidf, body="resnet101", **kwargs)

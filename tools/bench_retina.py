@@ -18,11 +18,13 @@ def main():
     ap.add_argument("--px", type=int, default=800)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--body", default="resnet50")
+    ap.add_argument("--classes", type=int, default=91)
     args = ap.parse_args()
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.tvision.engine import RetinaNetEngine
     dev = torch.device("cuda:0")
-    eng = RetinaNetEngine(91, 9, 3, device=dev, seed=0)
+    eng = RetinaNetEngine(args.classes, 9, 3, device=dev, seed=0, body=args.body)
     opt = FlatSGD.for_engine(eng, lr=1e-4, momentum=0.9, weight_decay=1e-4)
     g = torch.Generator().manual_seed(0)
     imgs = torch.rand((args.batch, 3, args.px, args.px), generator=g).to(dev)
@@ -30,7 +32,7 @@ def main():
     for _ in range(args.batch):
         tl = torch.rand((7, 2), generator=g) * args.px * 0.6
         wh = torch.rand((7, 2), generator=g) * args.px * 0.3 + 16
-        targets.append({"boxes": torch.cat([tl, tl + wh], 1).to(dev), "labels": torch.randint(1, 91, (7,), generator=g).to(dev)})
+        targets.append({"boxes": torch.cat([tl, tl + wh], 1).to(dev), "labels": torch.randint(1, args.classes, (7,), generator=g).to(dev)})
 
     def step():
         losses = eng.train_step(imgs, targets)
@@ -52,7 +54,7 @@ def main():
         eng.forward(imgs, training=True)
     torch.cuda.synchronize()
     df = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"bench": "retinanet_r50_fpn_train_step", "batch": args.batch, "px": args.px, "images_per_s": round(args.batch / dt, 2),
+    print(json.dumps({"bench": f"retinanet_{args.body}_fpn_train_step_{args.classes}cls", "batch": args.batch, "px": args.px, "images_per_s": round(args.batch / dt, 2),
                       "ms_per_step": round(dt * 1e3, 3), "fwd_ms": round(df * 1e3, 3), "plan_build_s": round(t_build, 1),
                       "loss_first": [round(float(v), 4) for v in l0], "loss_last": [round(float(v), 4) for v in l1],
                       "trainable_params": int(eng.flat_w.numel()), "anchors_per_image": int(eng._last_plan.rows)}))
