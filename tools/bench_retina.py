@@ -25,7 +25,13 @@ def main():
     from object_detectors_amd.tvision.engine import RetinaNetEngine
     dev = torch.device("cuda:0")
     eng = RetinaNetEngine(args.classes, 9, 3, device=dev, seed=0, body=args.body)
-    opt = FlatSGD.for_engine(eng, lr=1e-4, momentum=0.9, weight_decay=1e-4)
+    # random-init residual stacks with FROZEN BatchNorm have no normalisation at all: damp the last BN of every bottleneck
+    # (as zero-init-residual / pretrained weights do) so that 33 blocks of ResNet-101 stay finite in bf16
+    for sp in eng.specs:
+        if sp.bn and sp.bn.endswith(".bn3"):
+            eng.buffers[sp.bn + ".weight"].fill_(0.2)
+    eng.refresh_frozen()
+    opt = FlatSGD.for_engine(eng, lr=1e-2, momentum=0.9, weight_decay=1e-4)      # detection/train.py default lr 0.02 at 8 GPUs x 2 images
     g = torch.Generator().manual_seed(0)
     imgs = torch.rand((args.batch, 3, args.px, args.px), generator=g).to(dev)
     targets = []
