@@ -39,7 +39,7 @@ class Conv:
         self.cout_store = ops.pad_to(cout, 32) if head else cout      # dgrad reduces over cout: multiple of 32
 
 
-def arch(num_classes=91, num_anchors=9, trainable_layers=3, body="resnet50"):
+def arch(num_classes=91, num_anchors=9, trainable_layers=3, body="resnet50", model="retinanet"):
     """Ordered conv specs (reference state_dict order).  Frozen: everything in the body below the last
     `trainable_layers` of [layer4, layer3, layer2, layer1, conv1] (backbone_utils.py:100-104); BN is always frozen."""
     if not 0 <= trainable_layers <= 4:
@@ -60,6 +60,16 @@ def arch(num_classes=91, num_anchors=9, trainable_layers=3, body="resnet50"):
                 specs.append(Conv(q + ".downsample.0", inpl, planes * 4, 1, s, bn=q + ".downsample.1", trainable=tr))
             inpl = planes * 4
     Fp = "backbone.fpn."
+    if model == "fasterrcnn":
+        # resnet_fpn_backbone(returned_layers=[1,2,3,4], extra_blocks=LastLevelMaxPool) (backbone_utils.py:106-122) + RPNHead (rpn.py:17-58)
+        for i, cin in enumerate((256, 512, 1024, 2048)):
+            specs.append(Conv(f"{Fp}inner_blocks.{i}", cin, 256, 1, 1, bias=True))
+        for i in range(4):
+            specs.append(Conv(f"{Fp}layer_blocks.{i}", 256, 256, 3, 1, bias=True))
+        specs.append(Conv("rpn.head.conv", 256, 256, 3, 1, bias=True, relu=True))
+        specs.append(Conv("rpn.head.cls_logits", 256, num_anchors * num_classes, 1, 1, bias=True, head="cls_logits"))
+        specs.append(Conv("rpn.head.bbox_pred", 256, num_anchors * 4, 1, 1, bias=True, head="bbox_reg"))
+        return specs
     for i, cin in enumerate((512, 1024, 2048)):
         specs.append(Conv(f"{Fp}inner_blocks.{i}", cin, 256, 1, 1, bias=True))
     for i in range(3):
@@ -74,6 +84,8 @@ def arch(num_classes=91, num_anchors=9, trainable_layers=3, body="resnet50"):
 
 
 class RetinaNetEngine:
+    MODEL = "retinanet"
+
     def __init__(self, num_classes=91, num_anchors=9, trainable_layers=3, device=None, seed=0, bn_eps=1e-5, normalize=True, body="resnet50"):
         lib()   # fail loudly if the HIP library is missing
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -81,13 +93,17 @@ class RetinaNetEngine:
         self.bn_eps = bn_eps
         self.normalize = normalize
         self.body_name = body
-        self.specs = arch(num_classes, num_anchors, trainable_layers, body)
+        self.model = self.MODEL
+        self.specs = arch(num_classes, num_anchors, trainable_layers, body, self.MODEL)
         self.by_name = {s.name: s for s in self.specs}
         self._layout_params()
         self.reset_parameters(seed)
         self.plans = {}
         self.training = True
-        self.anchor_generator = AnchorGenerator(ANCHOR_SIZES, ASPECT_RATIOS)
+        if self.model == "fasterrcnn":
+            self.anchor_generator = AnchorGenerator(((32,), (64,), (128,), (256,), (512,)), ((0.5, 1.0, 2.0),) * 5)     # frcnn.py:187-190
+        else:
+            self.anchor_generator = AnchorGenerator(ANCHOR_SIZES, ASPECT_RATIOS)
         self.mean = torch.tensor(IMAGE_MEAN, device=self.device)
         self.inv_std = 1.0 / torch.tensor(IMAGE_STD, device=self.device)
 
@@ -149,7 +165,7 @@ class RetinaNetEngine:
             self._set_weight_oihw(s, t)
             if s.bias:
                 self.params[s.name + ".bias"].zero_()
-                if s.head == "cls_logits":
+                if s.name == "head.classification_head.cls_logits":
                     self.params[s.name + ".bias"][:s.cout].fill_(-math.log((1 - 0.01) / 0.01))
         self.refresh_frozen()
 
@@ -286,6 +302,47 @@ class RetinaNetEngine:
         p.run_backward()
 
 
+class FasterRCNNEngine(RetinaNetEngine):
+    """ResNet-FPN backbone (C2..C5 -> P2..P5 + max-pool level) + RPNHead of `fasterrcnn_resnet50_fpn` (tvision/frcnn.py:150-236,
+    backbone_utils.py:67-122, rpn.py:17-58).  The RPN outputs are the level-concatenated objectness [N, sum HWA, 1] and deltas
+    [N, sum HWA, 4] (the layout rpn.py:concat_box_prediction_layers builds); P2..P5 are handed to the RoI heads as NCHW fp32
+    tensors and their gradients come back through `backward(..., feature_grads)`."""
+    MODEL = "fasterrcnn"
+
+    def __init__(self, trainable_layers=3, device=None, seed=0, bn_eps=1e-5, normalize=True, body="resnet50"):
+        super().__init__(num_classes=1, num_anchors=3, trainable_layers=trainable_layers, device=device, seed=seed, bn_eps=bn_eps,
+                         normalize=normalize, body=body)
+
+    def train_step(self, *a, **k):
+        raise NotImplementedError("use tvision.frcnn.FasterRCNN: the step has a data-dependent middle (proposals, sampling)")
+
+    def feature_maps_nchw(self, levels=4):
+        """P2.. as NCHW fp32 tensors (the layout mi355det_roi_align reads)."""
+        p = self._last_plan
+        outs = []
+        for f in p.features[:levels]:
+            o = torch.empty((f.n, f.c, f.h, f.w), device=self.device, dtype=torch.float32)
+            check(lib().mi355det_nhwc_to_nchw_f32(f.ptr, 1, f.ld, f.n, f.c, f.h, f.w, _vp(o), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                  "nhwc_to_nchw_f32")
+            outs.append(o)
+        return outs
+
+    def backward(self, grad_objectness, grad_deltas, feature_grads=None):
+        p = self._last_plan
+        p.glogits.copy_(grad_objectness.reshape(p.glogits.shape))
+        p.gbbox.copy_(grad_deltas.reshape(p.gbbox.shape))
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for l, rg in enumerate(p.roi_grads):
+            g = None if feature_grads is None or l >= len(feature_grads) else feature_grads[l]
+            if g is None:
+                rg.buf.zero_()
+            else:
+                g = g.float().contiguous()
+                check(lib().mi355det_nchw_f32_to_nhwc(_vp(g), rg.n, rg.c, rg.h, rg.w, rg.ptr, 1, rg.ld, st), "nchw_f32_to_nhwc")
+        p.load_head_grads()
+        p.run_backward()
+
+
 class RetinaPlan:
     """Buffers + prepared call lists for one (batch, H, W, mode)."""
 
@@ -310,7 +367,8 @@ class RetinaPlan:
             for _ in range(times):
                 v = (v - 1) // 2 + 1
             return v
-        sizes = [(down(H, t), down(W, t)) for t in (3, 4, 5, 6, 7)]
+        frcnn = eng.model == "fasterrcnn"
+        sizes = [(down(H, t), down(W, t)) for t in ((2, 3, 4, 5, 6) if frcnn else (3, 4, 5, 6, 7))]
         self.level_sizes = sizes
         self.level_rows = [h * w * A for h, w in sizes]
         self.rows = sum(self.level_rows)
@@ -375,35 +433,58 @@ class RetinaPlan:
                 x = conv(q + ".conv3", y, res=idn)
             feats.append(x)
         self.body = feats
-        # ---- FPN (top-down) + P6/P7
+        # ---- FPN (top-down) + extra levels
         Fp = "backbone.fpn."
-        last = conv(Fp + "inner_blocks.2", feats[3])
-        outs = [conv(Fp + "layer_blocks.2", last)]
-        for i in (1, 0):
-            lat = conv(f"{Fp}inner_blocks.{i}", feats[i + 1])
+        c_feats = feats if frcnn else feats[1:]          # Faster R-CNN returns C2..C5, RetinaNet C3..C5
+        top = len(c_feats) - 1
+        last = conv(f"{Fp}inner_blocks.{top}", c_feats[top])
+        outs = [conv(f"{Fp}layer_blocks.{top}", last)]
+        for i in range(top - 1, -1, -1):
+            lat = conv(f"{Fp}inner_blocks.{i}", c_feats[i])
             merged = new_act(n, lat.h, lat.w, 256, True)
             self.fwd.append((L.mi355det_upsample_nearest_add, (last.ptr, last.ld, n, last.h, last.w, 256, lat.ptr, lat.ld, lat.h, lat.w,
                                                                merged.ptr, merged.ld, self.stream)))
             self.ops.append(dict(kind="up_add", top=last, lat=lat, a=merged))
             last = merged
             outs.insert(0, conv(f"{Fp}layer_blocks.{i}", last))
-        p6 = conv(Fp + "extra_blocks.p6", outs[-1])
-        r6 = new_act(n, p6.h, p6.w, 256, True)
-        # F.relu(p6) (LastLevelP6P7.forward) on a tiny map: the BN+activation kernel with unit scale, zero shift, slope 0
-        self.unit_ss = torch.zeros(4 * 256, device=dev)
-        self.unit_ss[:256] = 1.0
-        self.fwd.append((L.mi355det_bn_act_fwd, (p6.ptr, p6.ld, _vp(self.unit_ss), 256, p6.pixels, 0.0, None, 0, r6.ptr, r6.ld, self.stream)))
-        self.ops.append(dict(kind="relu", x=p6, a=r6))
-        p7 = conv(Fp + "extra_blocks.p7", r6)
-        self.features = outs + [p6, p7]
+        if frcnn:
+            # LastLevelMaxPool: F.max_pool2d(P5, 1, 2, 0) = every other pixel (torchvision feature_pyramid_network); the RPN reads it,
+            # the RoI heads do not.  A strided torch copy inside the call list (tiny map).
+            p5 = outs[-1]
+            pool = new_act(n, down(p5.h, 1), down(p5.w, 1), 256, True)
+            self.fwd.append((comm_hook, (lambda: pool.buf.copy_(p5.buf[:, ::2, ::2]),)))
+            self.ops.append(dict(kind="pool", x=p5, a=pool))
+            self.features = outs + [pool]
+        else:
+            p6 = conv(Fp + "extra_blocks.p6", outs[-1])
+            r6 = new_act(n, p6.h, p6.w, 256, True)
+            # F.relu(p6) (LastLevelP6P7.forward) on a tiny map: the BN+activation kernel with unit scale, zero shift, slope 0
+            self.unit_ss = torch.zeros(4 * 256, device=dev)
+            self.unit_ss[:256] = 1.0
+            self.fwd.append((L.mi355det_bn_act_fwd, (p6.ptr, p6.ld, _vp(self.unit_ss), 256, p6.pixels, 0.0, None, 0, r6.ptr, r6.ld, self.stream)))
+            self.ops.append(dict(kind="relu", x=p6, a=r6))
+            p7 = conv(Fp + "extra_blocks.p7", r6)
+            self.features = outs + [p6, p7]
         assert [(f.h, f.w) for f in self.features] == sizes, ([(f.h, f.w) for f in self.features], sizes)
-        # ---- heads, weights shared over the five levels (retinanet.py:150-170,228-246)
-        for hname, last_name in (("classification_head", "cls_logits"), ("regression_head", "bbox_reg")):
+        if frcnn:
+            # gradients arriving from the RoI heads (RoIAlign backward on P2..P5) enter the backward pass as extra contributions
+            self.roi_grads = []
+            for f in self.features[:4]:
+                gbuf = new_act(n, f.h, f.w, 256, False)
+                self.roi_grads.append(gbuf)
+            # ---- RPN head shared over the five levels (rpn.py:17-58)
             for lvl, f in enumerate(self.features):
-                t = f
-                for i in (0, 2, 4, 6):
-                    t = conv(f"head.{hname}.conv.{i}", t)
-                conv(f"head.{hname}.{last_name}", t, level=lvl)
+                t = conv("rpn.head.conv", f)
+                conv("rpn.head.cls_logits", t, level=lvl)
+                conv("rpn.head.bbox_pred", t, level=lvl)
+        else:
+            # ---- heads, weights shared over the five levels (retinanet.py:150-170,228-246)
+            for hname, last_name in (("classification_head", "cls_logits"), ("regression_head", "bbox_reg")):
+                for lvl, f in enumerate(self.features):
+                    t = f
+                    for i in (0, 2, 4, 6):
+                        t = conv(f"head.{hname}.conv.{i}", t)
+                    conv(f"head.{hname}.{last_name}", t, level=lvl)
 
         # ---- weight packing of the trainable convolutions (every step: the optimizer changes the fp32 masters)
         tr = [s for s in eng.specs if s.trainable]
@@ -493,8 +574,19 @@ class RetinaPlan:
 
         self.bwd_marks = []
         first_off = {name: o for name, o, _n, _s in eng.param_order}
+        for f, rg in zip(self.features, getattr(self, "roi_grads", [])):
+            f.parts.append(rg)                 # Faster R-CNN: gradient of P2..P5 coming back through RoIAlign
         for rec in reversed(self.ops):
             kind = rec["kind"]
+            if kind == "pool":
+                g = finalize(rec["a"])
+                if g is None:
+                    continue
+                x = rec["x"]
+                d = dense(x)                   # zeros except the sampled pixels
+                self.bwd.append((comm_hook, ((lambda d=d, g=g: d.buf[:, ::2, ::2].copy_(g.buf)),)))
+                add_tensor(x, d)
+                continue
             if kind == "up_add":
                 g = finalize(rec["a"])
                 if g is None:

@@ -1,0 +1,167 @@
+"""Mirror of the reference `FasterRCNN` / `fasterrcnn_resnet50_fpn` (tvision/frcnn.py:21-236,328-400, generalized_rcnn.py) over the
+MI355X kernels (BASELINE config 4).
+
+    model = fasterrcnn_resnet50_fpn(num_classes=91)
+    losses = model(images, targets)     # {'loss_classifier','loss_box_reg','loss_objectness','loss_rpn_box_reg'}, backward already done
+    detections = model(images)          # eval: [{'boxes','labels','scores'}]
+
+Where the work runs:
+  * ResNet-FPN body, FPN and the RPN head: `tvision/engine.py:FasterRCNNEngine` (MFMA convolutions, fused FrozenBN/ReLU/identity);
+  * anchors, proposal decoding, per-level top-k, clipping, small-box filter, NMS: HIP kernels (`postprocess.rpn_filter_proposals`);
+  * RPN / RoI target assignment: fused IoU+Matcher kernels (`tvision/rpn.py`, `tvision/roi_heads.py`); the samplers stay in torch
+    (SURVEY 8 row a19);
+  * MultiScaleRoIAlign forward/backward: `mi355det_roi_align`;
+  * TwoMLPHead / FastRCNNPredictor (frcnn.py:238-290) are plain dense GEMMs on [512*N, 12544]: `torch.nn.Linear` (rocBLAS/hipBLASLt,
+    the library path the MI355X rules reserve for plain GEMMs); their parameters are ordinary torch parameters, the backbone's live in
+    `model.engine.flat_w` (optimise with `optim.FlatSGD.for_engine(model.engine)` + a torch optimizer over `model.head_parameters()`).
+Images must already be resized / batched to one [N,3,H,W] tensor with H, W multiples of 32 (see tvision/retinanet.py).
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .. import ops
+from ._utils import BoxCoder
+from .engine import FasterRCNNEngine
+from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals
+from .roi_align import MultiScaleRoIAlign
+from .roi_heads import RoIHeadTargets, fastrcnn_loss
+from .rpn import RPNTargets
+
+
+class TwoMLPHead(nn.Module):
+    """frcnn.py:238-262."""
+
+    def __init__(self, in_channels, representation_size):
+        super().__init__()
+        self.fc6 = nn.Linear(in_channels, representation_size)
+        self.fc7 = nn.Linear(representation_size, representation_size)
+
+    def forward(self, x):
+        x = x.flatten(start_dim=1)
+        return torch.relu(self.fc7(torch.relu(self.fc6(x))))
+
+
+class FastRCNNPredictor(nn.Module):
+    """frcnn.py:265-290."""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__()
+        self.cls_score = nn.Linear(in_channels, num_classes)
+        self.bbox_pred = nn.Linear(in_channels, num_classes * 4)
+
+    def forward(self, x):
+        if x.dim() == 4:
+            assert list(x.shape[2:]) == [1, 1]
+        x = x.flatten(start_dim=1)
+        return self.cls_score(x), self.bbox_pred(x)
+
+
+class FasterRCNN(nn.Module):
+    def __init__(self, num_classes=91, trainable_backbone_layers=3, tfidf=None,
+                 rpn_pre_nms_top_n_train=2000, rpn_pre_nms_top_n_test=1000, rpn_post_nms_top_n_train=2000, rpn_post_nms_top_n_test=1000,
+                 rpn_nms_thresh=0.7, rpn_fg_iou_thresh=0.7, rpn_bg_iou_thresh=0.3, rpn_batch_size_per_image=256, rpn_positive_fraction=0.5,
+                 rpn_score_thresh=0.0, box_score_thresh=0.05, box_nms_thresh=0.5, box_detections_per_img=100, box_fg_iou_thresh=0.5,
+                 box_bg_iou_thresh=0.5, box_batch_size_per_image=512, box_positive_fraction=0.25, bbox_reg_weights=None, loss_type="ce",
+                 device=None, seed=0, body="resnet50"):
+        super().__init__()
+        self.engine = FasterRCNNEngine(trainable_backbone_layers, device=device, seed=seed, body=body)
+        dev = self.engine.device
+        self.rpn_targets = RPNTargets(rpn_fg_iou_thresh, rpn_bg_iou_thresh, rpn_batch_size_per_image, rpn_positive_fraction)
+        self.rpn_pre = dict(training=rpn_pre_nms_top_n_train, testing=rpn_pre_nms_top_n_test)
+        self.rpn_post = dict(training=rpn_post_nms_top_n_train, testing=rpn_post_nms_top_n_test)
+        self.rpn_nms_thresh, self.rpn_score_thresh = rpn_nms_thresh, rpn_score_thresh
+        weights = bbox_reg_weights or (10., 10., 5., 5.)
+        self.roi_targets = RoIHeadTargets(box_fg_iou_thresh, box_bg_iou_thresh, box_batch_size_per_image, box_positive_fraction, weights)
+        self.box_roi_pool = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+        self.box_head = TwoMLPHead(256 * 7 * 7, 1024).to(dev)
+        self.box_predictor = FastRCNNPredictor(1024, num_classes).to(dev)
+        self.box_score_thresh, self.box_nms_thresh, self.box_detections_per_img = box_score_thresh, box_nms_thresh, box_detections_per_img
+        self.bbox_reg_weights = weights
+        self.loss_type = loss_type
+        self.tfidf_post = 1.0 if tfidf is None else tfidf["values"].to(dev).float()
+        self.rpn_coder = BoxCoder((1.0, 1.0, 1.0, 1.0))
+
+    def head_parameters(self):
+        return list(self.box_head.parameters()) + list(self.box_predictor.parameters())
+
+    def state_dict(self, *a, **k):
+        sd = self.engine.reference_state_dict()
+        for k2, v in self.box_head.state_dict().items():
+            sd["roi_heads.box_head." + k2] = v
+        for k2, v in self.box_predictor.state_dict().items():
+            sd["roi_heads.box_predictor." + k2] = v
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        self.engine.load_reference_state_dict(sd)
+        self.box_head.load_state_dict({k[len("roi_heads.box_head."):]: v for k, v in sd.items() if k.startswith("roi_heads.box_head.")})
+        self.box_predictor.load_state_dict({k[len("roi_heads.box_predictor."):]: v for k, v in sd.items()
+                                            if k.startswith("roi_heads.box_predictor.")})
+
+    # ------------------------------------------------------------------
+    def _proposals(self, out, plan, image_shapes):
+        """rpn.py:336-351: decode every anchor with the (detached) deltas, then filter_proposals."""
+        n = out["cls_logits"].shape[0]
+        deltas = out["bbox_regression"].detach().reshape(-1, 4)
+        anchors = plan.anchors.repeat(n, 1)
+        proposals = ops.box_decode(deltas, anchors, (1.0, 1.0, 1.0, 1.0), self.rpn_coder.bbox_xform_clip).reshape(n, -1, 4)
+        mode = "training" if self.training else "testing"
+        return rpn_filter_proposals(proposals, out["cls_logits"].detach().reshape(n, -1), image_shapes, plan.level_rows, self.rpn_pre[mode],
+                                    self.rpn_post[mode], self.rpn_nms_thresh, self.rpn_score_thresh)
+
+    def forward(self, images, targets=None):
+        if isinstance(images, (list, tuple)):
+            if len({tuple(i.shape) for i in images}) != 1:
+                raise NotImplementedError("images of different sizes: resize/pad them to one size first")
+            images = torch.stack(list(images))
+        if self.training and targets is None:
+            raise ValueError("In training mode, targets should be passed")          # generalized_rcnn.py:60-61
+        if self.training:
+            for t in targets:
+                b = t["boxes"]
+                if b.dim() != 2 or b.shape[-1] != 4:
+                    raise ValueError("Expected target boxes to be a tensor of shape [N, 4], got {:}.".format(b.shape))
+                if b.numel() and bool((b[:, 2:] <= b[:, :2]).any()):
+                    raise ValueError("All bounding boxes should have positive height and width.")
+        n = images.shape[0]
+        image_shapes = [(images.shape[-2], images.shape[-1])] * n
+        out = self.engine.forward(images, training=self.training)
+        plan = self.engine._last_plan
+        boxes, _scores = self._proposals(out, plan, image_shapes)
+        feats = self.engine.feature_maps_nchw(4)
+        if not self.training:
+            with torch.no_grad():
+                x = self.box_roi_pool(OrderedDict((str(i), f) for i, f in enumerate(feats)), boxes, image_shapes)
+                cls, reg = self.box_predictor(self.box_head(x))
+                b, s, l = roi_heads_postprocess_detections(cls, reg, boxes, image_shapes, self.tfidf_post, self.box_score_thresh,
+                                                           self.box_nms_thresh, self.box_detections_per_img, self.bbox_reg_weights)
+            return [{"boxes": bb, "labels": ll, "scores": ss} for bb, ll, ss in zip(b, l, s)]
+        # ---- training: RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient)
+        obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
+        dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
+        rpn_losses = self.rpn_targets.losses(obj, dl, [plan.anchors] * n, targets)
+        # ---- RoI heads (roi_heads.py:783-848): sample, pool, two FC layers, predictor, Fast R-CNN loss
+        for f in feats:
+            f.requires_grad_(True)
+        proposals, _mi, labels, reg_targets = self.roi_targets.select_training_samples([b.detach() for b in boxes], targets)
+        x = self.box_roi_pool(OrderedDict((str(i), f) for i, f in enumerate(feats)), proposals, image_shapes)
+        cls, reg = self.box_predictor(self.box_head(x))
+        loss_cls, loss_box = fastrcnn_loss(cls, reg, labels, reg_targets, loss_type=self.loss_type)
+        losses = {"loss_classifier": loss_cls, "loss_box_reg": loss_box}
+        losses.update(rpn_losses)
+        sum(losses.values()).backward()
+        self.engine.backward(obj.grad, dl.grad, [f.grad for f in feats])
+        return {k: v.detach() for k, v in losses.items()}
+
+
+def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=False, trainable_backbone_layers=None, tfidf=None,
+                            **kwargs):
+    """frcnn.py:328-400.  No network here: `pretrained*` must be False; load weights with `load_state_dict`."""
+    if pretrained or pretrained_backbone:
+        raise NotImplementedError("no network access: load a reference state_dict with model.load_state_dict(...)")
+    if trainable_backbone_layers is None:
+        trainable_backbone_layers = 3
+    return FasterRCNN(num_classes, trainable_backbone_layers, tfidf=tfidf, **kwargs)

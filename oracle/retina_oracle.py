@@ -196,3 +196,46 @@ def sample(t, count=64):
     f = t.detach().reshape(-1)
     step = max(1, f.numel() // count)
     return f[::step][:count].numpy().copy()
+
+
+# ---- Faster R-CNN backbone side: FPN over C2..C5 + LastLevelMaxPool, RPNHead (tvision/rpn.py:17-58; torchvision FPN: unpinned) ----
+def frcnn_state_keys():
+    out = body_keys()
+    P = "backbone.fpn."
+    for name, chans in (("inner_blocks", [(256, 1), (512, 1), (1024, 1), (2048, 1)]), ("layer_blocks", [(256, 3)] * 4)):
+        for i, (cin, k) in enumerate(chans):
+            out.append((f"{P}{name}.{i}.weight", (256, cin, k, k)))
+            out.append((f"{P}{name}.{i}.bias", (256,)))
+    out += [("rpn.head.conv.weight", (256, 256, 3, 3)), ("rpn.head.conv.bias", (256,)), ("rpn.head.cls_logits.weight", (3, 256, 1, 1)),
+            ("rpn.head.cls_logits.bias", (3,)), ("rpn.head.bbox_pred.weight", (12, 256, 1, 1)), ("rpn.head.bbox_pred.bias", (12,))]
+    return out
+
+
+def frcnn_forward(sd, images, do_normalize=True):
+    """-> {'features': [P2, P3, P4, P5, pool], 'objectness': [N, sum HWA, 1], 'deltas': [N, sum HWA, 4]} in the layout of
+    rpn.py:concat_box_prediction_layers."""
+    x = normalize(images) if do_normalize else images
+    body = body_forward(sd, x)
+    P = "backbone.fpn."
+
+    def inner(i, t):
+        return F.conv2d(t, sd[f"{P}inner_blocks.{i}.weight"], sd[f"{P}inner_blocks.{i}.bias"])
+
+    def layer(i, t):
+        return F.conv2d(t, sd[f"{P}layer_blocks.{i}.weight"], sd[f"{P}layer_blocks.{i}.bias"], padding=1)
+    last = inner(3, body[3])
+    outs = [layer(3, last)]
+    for i in (2, 1, 0):
+        lat = inner(i, body[i])
+        last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+        outs.insert(0, layer(i, last))
+    feats = outs + [F.max_pool2d(outs[-1], 1, 2, 0)]
+    obj, dl = [], []
+    for f in feats:
+        t = F.relu(F.conv2d(f, sd["rpn.head.conv.weight"], sd["rpn.head.conv.bias"], padding=1))
+        o = F.conv2d(t, sd["rpn.head.cls_logits.weight"], sd["rpn.head.cls_logits.bias"])
+        d = F.conv2d(t, sd["rpn.head.bbox_pred.weight"], sd["rpn.head.bbox_pred.bias"])
+        n, _, h, w = o.shape
+        obj.append(o.view(n, -1, 1, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 1))
+        dl.append(d.view(n, -1, 4, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 4))
+    return {"body": body, "features": feats, "objectness": torch.cat(obj, 1), "deltas": torch.cat(dl, 1)}

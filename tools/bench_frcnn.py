@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 (one GPU's share): Faster R-CNN ResNet-50-FPN training step, synthetic COCO 800 px.
+    python tools/bench_frcnn.py --batch 4 --steps 10"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--px", type=int, default=800)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    from object_detectors_amd.optim import FlatSGD
+    from object_detectors_amd.tvision.frcnn import fasterrcnn_resnet50_fpn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = fasterrcnn_resnet50_fpn(num_classes=91, device=dev)
+    eng = model.engine
+    for sp in eng.specs:          # stable random-init residual stack (see tools/bench_retina.py)
+        if sp.bn and sp.bn.endswith(".bn3"):
+            eng.buffers[sp.bn + ".weight"].fill_(0.2)
+    eng.refresh_frozen()
+    opt = FlatSGD.for_engine(eng, lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    opt_head = torch.optim.SGD(model.head_parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.rand((args.batch, 3, args.px, args.px), generator=g).to(dev)
+    targets = []
+    for _ in range(args.batch):
+        tl = torch.rand((7, 2), generator=g) * args.px * 0.6
+        wh = torch.rand((7, 2), generator=g) * args.px * 0.3 + 16
+        targets.append({"boxes": torch.cat([tl, tl + wh], 1).to(dev), "labels": torch.randint(1, 91, (7,), generator=g).to(dev)})
+    model.train()
+
+    def step():
+        opt_head.zero_grad(set_to_none=True)
+        losses = model(imgs, targets)
+        opt.step()
+        opt_head.step()
+        return losses
+    for _ in range(args.warmup):
+        l0 = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        l1 = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    model.eval()
+    with torch.no_grad():
+        model(imgs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            det = model(imgs)
+        torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"bench": "fasterrcnn_resnet50_fpn", "batch": args.batch, "px": args.px, "train_images_per_s": round(args.batch / dt, 2),
+                      "train_ms_per_step": round(dt * 1e3, 2), "eval_images_per_s": round(args.batch / de, 2), "eval_ms_per_batch": round(de * 1e3, 2),
+                      "losses_first": {k: round(float(v), 4) for k, v in l0.items()}, "losses_last": {k: round(float(v), 4) for k, v in l1.items()},
+                      "detections_img0": int(det[0]["boxes"].shape[0])}))
+
+
+if __name__ == "__main__":
+    main()
