@@ -191,6 +191,16 @@ int mi355det_roi_align(const float* const* feats, const int32_t* hs, const int32
                        int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio, int aligned, int32_t k_min,
                        int32_t k_max, float* out, const float* grad_out, float* const* grad_feats, void* stream);
 
+/* Channels-last form of the same op for the engines' native layout: feats = bf16 NHWC [n,h,w,C] with pixel pitch lds[q]
+ * (NULL = C); out / grad_out stay [K,C,ph,pw] fp32 (the order box_head.fc6 consumes, frcnn.py:248-262); grad_feats = dense
+ * fp32 NHWC [n,h,w,C] buffers, zeroed by the caller.  Lanes run over channels, so the backward's atomics are contiguous
+ * 256-byte runs instead of 64 scattered rows. */
+int mi355det_roi_align_nhwc(const void* const* feats, const int32_t* hs, const int32_t* ws, const int32_t* lds,
+                            const float* scales, int32_t num_levels, const float* rois, int32_t num_rois,
+                            int32_t channels, int32_t pooled_h, int32_t pooled_w, int32_t sampling_ratio, int aligned,
+                            int32_t k_min, int32_t k_max, float* out, const float* grad_out, float* const* grad_feats,
+                            void* stream);
+
 /* Tensor.topk(k, dim=1) on [rows, n] (tvision/rpn.py:215-228, retinanet.py:437-445): indices (and values) of the k
  * largest entries per row in descending order, ties -> lower index; entries <= min_value are never selected
  * (the "> score_thresh" filter).  idx_out/val_out [rows,k], count_out [rows] = number selected; k <= 16384. */

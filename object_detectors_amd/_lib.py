@@ -69,6 +69,7 @@ PROTOTYPES = {
     "mi355det_anchor_grid": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "mi355det_sigmoid_focal_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
     "mi355det_retina_cls_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
+    "mi355det_roi_align_nhwc": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, C.c_int, i32, i32, vp, vp, vp, vp]),
     "mi355det_roi_align": (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, C.c_int, i32, i32, vp, vp, vp, vp]),
     "mi355det_topk": (C.c_int, [vp, i32, i64, i64, i32, f32, vp, vp, vp, vp]),
     "mi355det_conv_fwd": (C.c_int, [P(ConvShape), vp, vp, vp, vp, C.c_int, vp, i32, vp]),

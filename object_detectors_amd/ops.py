@@ -411,3 +411,31 @@ def conv_dgrad_bn(shape, dy, w_dgrad, dx, z, scale_shift, slope, residual=None, 
     sums = torch.empty(2 * shape.cin, device=dx.device, dtype=torch.float32)
     check(L.mi355det_bn_bwd_sum_partials(ptr(partials), rows, shape.cin, cin_pad, ptr(sums), stream_ptr()), "bn_bwd_sum_partials")
     return sums
+
+
+def roi_align_nhwc(feats, rois, output_size, scales, sampling_ratio=2, aligned=False, k_min=2, k_max=5, grad_out=None):
+    """Channels-last RoIAlign: feats = list of bf16 NHWC maps [n,h,w,C] (1..4 levels, pixel pitch = stride(2)); rois [K,5].
+    Forward -> fp32 [K,C,ph,pw]; with grad_out -> list of fp32 NHWC feature gradients."""
+    for f in feats:
+        if f.dtype != torch.bfloat16 or f.dim() != 4 or f.stride(3) != 1:
+            raise ValueError("roi_align_nhwc expects bf16 [n,h,w,C] tensors with contiguous channels")
+    rois = _f32c(rois)
+    nl = len(feats)
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    K, Cc = rois.shape[0], feats[0].shape[3]
+    P = (C.c_void_p * nl)(*[f.data_ptr() for f in feats])
+    hs = (C.c_int32 * nl)(*[f.shape[1] for f in feats])
+    ws = (C.c_int32 * nl)(*[f.shape[2] for f in feats])
+    lds = (C.c_int32 * nl)(*[f.stride(2) for f in feats])
+    sc = (C.c_float * nl)(*[float(s) for s in scales])
+    if grad_out is None:
+        out = torch.empty((K, Cc, ph, pw), device=rois.device, dtype=torch.float32)
+        check(lib().mi355det_roi_align_nhwc(P, hs, ws, lds, sc, nl, ptr(rois), K, Cc, ph, pw, int(sampling_ratio), int(aligned), k_min, k_max,
+                                            ptr(out), None, None, stream_ptr()), "roi_align_nhwc")
+        return out
+    g = _f32c(grad_out)
+    dfs = [torch.zeros((f.shape[0], f.shape[1], f.shape[2], Cc), device=f.device, dtype=torch.float32) for f in feats]
+    G = (C.c_void_p * nl)(*[d.data_ptr() for d in dfs])
+    check(lib().mi355det_roi_align_nhwc(P, hs, ws, lds, sc, nl, ptr(rois), K, Cc, ph, pw, int(sampling_ratio), int(aligned), k_min, k_max,
+                                        None, ptr(g), G, stream_ptr()), "roi_align_nhwc_bwd")
+    return dfs

@@ -327,7 +327,12 @@ class FasterRCNNEngine(RetinaNetEngine):
             outs.append(o)
         return outs
 
+    def feature_maps_nhwc(self, levels=4):
+        """P2.. as the engine's own bf16 NHWC buffers (no copy): leaf tensors for `MultiScaleRoIAlign.forward_nhwc`."""
+        return [f.buf.detach().requires_grad_(self.training) for f in self._last_plan.features[:levels]]
+
     def backward(self, grad_objectness, grad_deltas, feature_grads=None):
+        """feature_grads: per level None | NCHW fp32 [n,C,h,w] | NHWC [n,h,w,C] (bf16 or fp32), e.g. the .grad of feature_maps_*()."""
         p = self._last_plan
         p.glogits.copy_(grad_objectness.reshape(p.glogits.shape))
         p.gbbox.copy_(grad_deltas.reshape(p.gbbox.shape))
@@ -336,6 +341,8 @@ class FasterRCNNEngine(RetinaNetEngine):
             g = None if feature_grads is None or l >= len(feature_grads) else feature_grads[l]
             if g is None:
                 rg.buf.zero_()
+            elif g.shape[-1] == rg.c and g.shape[1] == rg.h:          # channels-last
+                rg.buf.copy_(g)
             else:
                 g = g.float().contiguous()
                 check(lib().mi355det_nchw_f32_to_nhwc(_vp(g), rg.n, rg.c, rg.h, rg.w, rg.ptr, 1, rg.ld, st), "nchw_f32_to_nhwc")

@@ -16,8 +16,6 @@ Where the work runs:
     `model.engine.flat_w` (optimise with `optim.FlatSGD.for_engine(model.engine)` + a torch optimizer over `model.head_parameters()`).
 Images must already be resized / batched to one [N,3,H,W] tensor with H, W multiples of 32 (see tvision/retinanet.py).
 """
-from collections import OrderedDict
-
 import torch
 from torch import nn
 
@@ -131,10 +129,10 @@ class FasterRCNN(nn.Module):
         out = self.engine.forward(images, training=self.training)
         plan = self.engine._last_plan
         boxes, _scores = self._proposals(out, plan, image_shapes)
-        feats = self.engine.feature_maps_nchw(4)
+        feats = self.engine.feature_maps_nhwc(4)       # the engine's bf16 NHWC buffers themselves
         if not self.training:
             with torch.no_grad():
-                x = self.box_roi_pool(OrderedDict((str(i), f) for i, f in enumerate(feats)), boxes, image_shapes)
+                x = self.box_roi_pool.forward_nhwc(feats, boxes, image_shapes)
                 cls, reg = self.box_predictor(self.box_head(x))
                 b, s, l = roi_heads_postprocess_detections(cls, reg, boxes, image_shapes, self.tfidf_post, self.box_score_thresh,
                                                            self.box_nms_thresh, self.box_detections_per_img, self.bbox_reg_weights)
@@ -144,10 +142,8 @@ class FasterRCNN(nn.Module):
         dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
         rpn_losses = self.rpn_targets.losses(obj, dl, [plan.anchors] * n, targets)
         # ---- RoI heads (roi_heads.py:783-848): sample, pool, two FC layers, predictor, Fast R-CNN loss
-        for f in feats:
-            f.requires_grad_(True)
         proposals, _mi, labels, reg_targets = self.roi_targets.select_training_samples([b.detach() for b in boxes], targets)
-        x = self.box_roi_pool(OrderedDict((str(i), f) for i, f in enumerate(feats)), proposals, image_shapes)
+        x = self.box_roi_pool.forward_nhwc(feats, proposals, image_shapes)
         cls, reg = self.box_predictor(self.box_head(x))
         loss_cls, loss_box = fastrcnn_loss(cls, reg, labels, reg_targets, loss_type=self.loss_type)
         losses = {"loss_classifier": loss_cls, "loss_box_reg": loss_box}

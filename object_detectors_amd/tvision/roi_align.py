@@ -23,6 +23,23 @@ class _RoIAlignFn(torch.autograd.Function):
         return (None,) * 7 + tuple(dfs)
 
 
+class _RoIAlignNHWCFn(torch.autograd.Function):
+    """bf16 NHWC features (the engines' layout) -> fp32 [K,C,ph,pw]; feature gradients come back as bf16 NHWC."""
+
+    @staticmethod
+    def forward(ctx, rois, output_size, scales, sampling_ratio, aligned, k_min, k_max, *feats):
+        ctx.args = (output_size, scales, sampling_ratio, aligned, k_min, k_max)
+        ctx.save_for_backward(rois, *feats)
+        return ops.roi_align_nhwc(list(feats), rois, output_size, scales, sampling_ratio, aligned, k_min, k_max)
+
+    @staticmethod
+    def backward(ctx, g):
+        rois, *feats = ctx.saved_tensors
+        output_size, scales, sampling_ratio, aligned, k_min, k_max = ctx.args
+        dfs = ops.roi_align_nhwc(list(feats), rois, output_size, scales, sampling_ratio, aligned, k_min, k_max, grad_out=g)
+        return (None,) * 7 + tuple(d.to(torch.bfloat16) for d in dfs)
+
+
 def _rois_tensor(boxes):
     if isinstance(boxes, torch.Tensor):
         return boxes
@@ -57,3 +74,18 @@ class MultiScaleRoIAlign(nn.Module):
             scales.append(sh)
         k_min, k_max = int(-math.log2(scales[0])), int(-math.log2(scales[-1]))
         return _RoIAlignFn.apply(_rois_tensor(boxes), self.output_size, scales, self.sampling_ratio, False, k_min, k_max, *feats)
+
+    def forward_nhwc(self, feats, boxes, image_shapes):
+        """Same pooling on bf16 NHWC feature maps [n,h,w,C] (list, finest first): no layout conversion, coalesced backward."""
+        if len(feats) > 4:
+            raise ValueError("at most 4 pyramid levels")
+        max_h = max(s[0] for s in image_shapes)
+        max_w = max(s[1] for s in image_shapes)
+        scales = []
+        for f in feats:
+            sh = 2.0 ** round(math.log2(f.shape[1] / max_h))
+            sw = 2.0 ** round(math.log2(f.shape[2] / max_w))
+            assert sh == sw
+            scales.append(sh)
+        k_min, k_max = int(-math.log2(scales[0])), int(-math.log2(scales[-1]))
+        return _RoIAlignNHWCFn.apply(_rois_tensor(boxes), self.output_size, scales, self.sampling_ratio, False, k_min, k_max, *feats)

@@ -146,3 +146,36 @@ def test_retinanet_postprocess_vs_oracle():
         np.testing.assert_allclose(det[i]["boxes"].cpu().numpy(), b[keep], rtol=1e-5, atol=1e-3)
         np.testing.assert_allclose(det[i]["scores"].cpu().numpy(), s[keep], rtol=1e-5, atol=1e-6)
         assert np.array_equal(det[i]["labels"].cpu().numpy(), l[keep])
+
+
+def test_roi_align_channels_last_matches_nchw():
+    """mi355det_roi_align_nhwc (bf16 NHWC features, lanes over channels) == the NCHW kernel on the same bf16-rounded features,
+    forward and backward, multi-level."""
+    from object_detectors_amd import ops
+    from object_detectors_amd.tvision.roi_align import MultiScaleRoIAlign
+    torch.manual_seed(0)
+    n, c = 2, 64
+    sizes = [(64, 48), (32, 24), (16, 12), (8, 6)]
+    img = (256, 192)
+    feats_nchw = [torch.randn(n, c, h, w, device="cuda").bfloat16().float() for h, w in sizes]
+    feats_cl = [f.permute(0, 2, 3, 1).contiguous().bfloat16() for f in feats_nchw]
+    boxes = []
+    for i in range(n):
+        tl = torch.rand(40, 2, device="cuda") * torch.tensor([150.0, 100.0], device="cuda")
+        wh = torch.rand(40, 2, device="cuda") * 120 + 4
+        boxes.append(torch.cat([tl, tl + wh], 1))
+    pool = MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    fa = [f.clone().requires_grad_(True) for f in feats_nchw]
+    fb = [f.clone().requires_grad_(True) for f in feats_cl]
+    from collections import OrderedDict
+    ya = pool(OrderedDict((str(i), f) for i, f in enumerate(fa)), boxes, [img] * n)
+    yb = pool.forward_nhwc(fb, boxes, [img] * n)
+    assert ya.shape == yb.shape == (80, c, 7, 7)
+    torch.testing.assert_close(yb, ya, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    for a, b in zip(fa, fb):
+        want = a.grad.permute(0, 2, 3, 1)
+        assert b.grad.dtype == torch.bfloat16
+        assert float((b.grad.float() - want).abs().max()) <= 1e-2 * float(want.abs().max()) + 1e-6
