@@ -232,9 +232,11 @@ typedef struct {
   const float* shift;        /* [cout] or NULL (= 0) */
   const void* residual;      /* bf16 [n,ho,wo,cout] with pixel pitch residual_ld, or NULL; bf16 outputs only */
   int32_t residual_ld;
-  int32_t relu;              /* 1: ReLU after scale/shift/residual */
+  int32_t relu;              /* 0: none; 1: ReLU after scale/shift/residual (ResNet); 2: LeakyReLU(slope) after scale/shift and
+                                BEFORE the residual (Darknet residual block, darknet.py:23-35) */
   int64_t out_image_stride;  /* fp32 outputs: elements between images of y (0 = ho*wo*out_ld): heads write straight
                                 into the level-concatenated [N, sum HWA, K] tensor (retinanet.py:163-170) */
+  float slope;               /* relu == 2: negative slope */
 } mi355det_conv_epilogue;
 int mi355det_conv_fwd_ex(const mi355det_conv_shape* s, const void* x, const void* w, const mi355det_conv_epilogue* e,
                          void* y, int out_f32, int32_t cout_pad, void* stream);

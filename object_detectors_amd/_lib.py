@@ -37,7 +37,8 @@ class ConvShape(C.Structure):
 
 
 class ConvEpilogue(C.Structure):
-    _fields_ = [("scale", vp), ("shift", vp), ("residual", vp), ("residual_ld", i32), ("relu", i32), ("out_image_stride", i64)]
+    _fields_ = [("scale", vp), ("shift", vp), ("residual", vp), ("residual_ld", i32), ("relu", i32), ("out_image_stride", i64),
+                ("slope", C.c_float)]
 
 
 class PackItem(C.Structure):

@@ -46,7 +46,7 @@ struct IgemmParams {
   void* y;               // output (bf16 or fp32)
   const float* bias;     // EPI_F32 / EPI_AFF: per-channel shift
   const float* scale;    // EPI_F32 / EPI_AFF: per-channel multiplier on the accumulator or null (FrozenBatchNorm2d folded into the conv)
-  int relu;              // EPI_F32 / EPI_AFF: ReLU after (scale, shift, residual)
+  int relu;              // EPI_F32 / EPI_AFF: 1 = ReLU after (scale, shift, residual); 2 = LeakyReLU(slope) BEFORE the residual (Darknet)
   long long ynstride;    // EPI_F32: elements between images of y (heads write straight into the level-concatenated tensor)
   const bf16_t* z;       // EPI_BNRED: pre-BN output of the layer whose activation gradient this dgrad writes
   const float* ss;       // EPI_BNRED: that layer's [4*Cout] scale, shift, mean, invstd
@@ -193,7 +193,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
             float v = acc[i][j][r];
             if (p.scale) v *= p.scale[co + r];
             if (p.bias) v += p.bias[co + r];
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.relu == 1) v = fmaxf(v, 0.f);
+            else if (p.relu == 2) v = v > 0.f ? v : v * p.slope;
             o[r] = v;
           }
       }
@@ -279,7 +280,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         f32x4_t v = acc[i][j];
-        if (EPI == EPI_AFF) v = v * aff_sc[i] + aff_sh[i];
+        if (EPI == EPI_AFF) {
+          v = v * aff_sc[i] + aff_sh[i];
+          if (p.relu == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * p.slope;
+          }
+        }
         uint2 o;
         o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
         o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
@@ -292,9 +299,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       const int pixi = kReadsSide ? pixp[pass] : rowpix[row];
       uint4 v = *(const uint4*)(reg + row * PITCH + ch * 16);
       if (pixi >= 0 && co < p.Cout) {
-        if (EPI == EPI_RES || ((EPI == EPI_AFF || EPI == EPI_BNRED) && (p.res != nullptr || p.relu))) {
+        if (EPI == EPI_RES || ((EPI == EPI_AFF || EPI == EPI_BNRED) && (p.res != nullptr || p.relu == 1))) {
           const uint4 rr = rpre[kReadsSide ? pass : 0];
-          const bool relu = EPI == EPI_AFF && p.relu;
+          const bool relu = EPI == EPI_AFF && p.relu == 1;
           const unsigned vi[4] = {v.x, v.y, v.z, v.w}, ri[4] = {rr.x, rr.y, rr.z, rr.w};
           unsigned oo[4];
 #pragma unroll
@@ -1476,6 +1483,7 @@ static int conv_fwd_impl(const mi355det_conv_shape* s, const void* x, const void
     p.scale = ex->scale;
     p.bias = ex->shift;
     p.relu = ex->relu;
+    p.slope = ex->slope;
     p.res = (const bf16_t*)ex->residual;
     p.ldres = ex->residual_ld;
     if (ex->out_image_stride) {

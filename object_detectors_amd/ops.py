@@ -335,9 +335,12 @@ def topk_rows(x, k, min_value=float("-inf")):
 
 
 # ------------------------------------------------------------------------------------ ResNet-FPN / RetinaNet companions
-def conv_fwd_ex(shape, x, w_fwd, y, scale=None, shift=None, residual=None, residual_ld=0, relu=False, out_f32=False, out_image_stride=0):
-    """y = relu?(conv(x,w)*scale + shift + residual): FrozenBatchNorm2d / bias / identity add fused into the conv epilogue."""
-    e = _lib.ConvEpilogue(ptr(scale), ptr(shift), ptr(residual), int(residual_ld), int(bool(relu)), int(out_image_stride))
+def conv_fwd_ex(shape, x, w_fwd, y, scale=None, shift=None, residual=None, residual_ld=0, relu=False, out_f32=False, out_image_stride=0,
+                leaky_slope=None):
+    """y = relu?(conv(x,w)*scale + shift + residual): FrozenBatchNorm2d / bias / identity add fused into the conv epilogue.
+    leaky_slope: Darknet form y = lrelu(conv*scale + shift) + residual."""
+    mode = 2 if leaky_slope is not None else int(bool(relu))
+    e = _lib.ConvEpilogue(ptr(scale), ptr(shift), ptr(residual), int(residual_ld), mode, int(out_image_stride), float(leaky_slope or 0.0))
     check(lib().mi355det_conv_fwd_ex(C.byref(shape), ptr(x), ptr(w_fwd), C.byref(e), ptr(y), int(out_f32), cout_pad_of(shape.cout), stream_ptr()),
           "conv_fwd_ex")
 

@@ -318,26 +318,37 @@ class Plan:
             shp = eng._wshape(s, x.n, x.h, x.w, in_ld=x.ld)
             x.conv_consumers += 1
             a = out if out is not None else new_act(x.n, shp.ho, shp.wo, shp.cout)
-            shp.out_ld = shp.cout   # z pitch
-            z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
-            rows = ops.conv_stats_rows(shp)
-            cp = ops.cout_pad_of(shp.cout)
-            stats = torch.zeros((rows + 64, 2, cp), device=dev, dtype=torch.float32) if training else None
-            ss = torch.zeros(4 * shp.cout, device=dev, dtype=torch.float32)
             wf, wd = eng.packed[name]
             b = bn_name(name)
             pixels = x.n * shp.ho * shp.wo
-            self.keep += [shp, z, stats, ss]
-            self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp), x.ptr, _vp(wf), None, _vp(z), 0, _vp(stats), cp, self.stream)))
-            if training:
-                self.fwd.append((L.mi355det_bn_finalize, (_vp(stats), rows, shp.cout, cp, pixels, _vp(eng.params[b + ".weight"]),
-                                                          _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
-                                                          _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
-                                                          _vp(ss), self.stream)))
-            else:
+            cp = ops.cout_pad_of(shp.cout)
+            ss = torch.zeros(4 * shp.cout, device=dev, dtype=torch.float32)
+            if not training:
+                # inference: BatchNorm uses the running statistics, so scale/shift are known BEFORE the convolution and the whole
+                # BN + LeakyReLU (+ residual) runs in the MFMA epilogue; the pre-BN tensor z never exists (model.eval(),
+                # test_one_epoch.py:10)
+                shp.out_ld = a.ld
+                e = _lib.ConvEpilogue(_vp(ss), _vp(ss, 4 * shp.cout), res.ptr if res else None, res.ld if res else 0, 2, 0, SLOPE)
+                self.keep += [shp, ss, e]
                 self.fwd.append((L.mi355det_bn_eval_scale_shift, (shp.cout, _vp(eng.params[b + ".weight"]), _vp(eng.params[b + ".bias"]),
                                                                   _vp(eng.buffers[b + ".running_mean"]),
                                                                   _vp(eng.buffers[b + ".running_var"]), BN_EPS, _vp(ss), self.stream)))
+                self.fwd.append((L.mi355det_conv_fwd_ex, (C.byref(shp), x.ptr, _vp(wf), C.byref(e), a.ptr, 0, cp, self.stream)))
+                rec = dict(kind="cbl", name=name, spec=s, shp=shp, x=x, a=a, res=res, z=None, ss=ss, pixels=pixels)
+                a.producer = rec
+                self.ops.append(rec)
+                self.layers[name] = rec
+                return a
+            shp.out_ld = shp.cout   # z pitch
+            z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
+            rows = ops.conv_stats_rows(shp)
+            stats = torch.zeros((rows + 64, 2, cp), device=dev, dtype=torch.float32)
+            self.keep += [shp, z, stats, ss]
+            self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp), x.ptr, _vp(wf), None, _vp(z), 0, _vp(stats), cp, self.stream)))
+            self.fwd.append((L.mi355det_bn_finalize, (_vp(stats), rows, shp.cout, cp, pixels, _vp(eng.params[b + ".weight"]),
+                                                      _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
+                                                      _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
+                                                      _vp(ss), self.stream)))
             self.fwd.append((L.mi355det_bn_act_fwd, (_vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE, res.ptr if res else None,
                                                      res.ld if res else 0, a.ptr, a.ld, self.stream)))
             self.dz_elems = max(self.dz_elems, pixels * shp.cout)

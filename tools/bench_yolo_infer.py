@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""YOLOv3 inference path (yolo/test.py + procedures/test_one_epoch.py): eval-mode network forward, decode, score filter + majority NMS.
+    python tools/bench_yolo_infer.py --batch 32 --px 640"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def timed(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--px", type=int, default=640)
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    from object_detectors_amd.yolo.nets.engine import YoloV3Engine
+    from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
+    from object_detectors_amd.yolo.procedures.test_one_epoch import postprocess
+    dev = torch.device("cuda:0")
+    eng = YoloV3Engine("darknet_53", 3, 80, device=dev, seed=0)
+    crit = YOLOForw(anchors=bench.ANCHORS, num_classes=80, img_size=args.px).to(dev)
+    imgs, _ = bench.synth_batch(args.batch, args.px, 0, dev)
+    eng.training = False
+    t_net, heads = timed(lambda: eng.forward(imgs, training=False), args.iters)
+    t_dec, pred = timed(lambda: crit(eng.forward(imgs, training=False)), args.iters)
+    t_all, dets = timed(lambda: postprocess(crit(eng.forward(imgs, training=False)), 0.5, criterion=crit), args.iters)
+    print(json.dumps({"bench": "yolov3_darknet53_inference", "batch": args.batch, "px": args.px,
+                      "network_images_per_s": round(args.batch / t_net, 1), "network_ms": round(t_net * 1e3, 3),
+                      "network_decode_images_per_s": round(args.batch / t_dec, 1), "decode_ms": round((t_dec - t_net) * 1e3, 3),
+                      "end_to_end_images_per_s": round(args.batch / t_all, 1), "postprocess_ms": round((t_all - t_dec) * 1e3, 3),
+                      "network_TFLOPs": round(args.batch * 155.9e9 / t_net / 1e12, 1)}))
+
+
+if __name__ == "__main__":
+    main()
