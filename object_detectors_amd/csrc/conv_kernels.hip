@@ -605,9 +605,11 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
 // per chunk drop 3x (staged bytes -31 % at 128x128).  Weights keep their own 2-deep ring (one tile per tap).
 // vmcnt bookkeeping: per step the wave issues B(s+1) first, then its share (2,2,1 pieces) of the next group's pixel tile,
 // so "all but the pieces issued after B(s)" is a compile-time count at each of the three unrolled positions.
-template <int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 ? 1 : 2)) void igemm_dx_kernel(const IgemmParams p) {
+template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ? 1 : 2)) void igemm_dx_kernel(const IgemmParams p) {
   constexpr int BK = 64, NT = WM * WN * 64, NW = WM * WN;
+  constexpr int D = NSTB - 1;                            // weight tiles in flight ahead of the one being consumed
+  static_assert(NSTB == 2 || NSTB == 3, "weight ring depth 2 or 3");
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, ROWB = 128, R = 8, CPR = 8;
   constexpr int A_INSTR = BM / R + 2;                    // 8 halo rows each side (one LDS-DMA piece = 8 rows)
   constexpr int A_PER = (A_INSTR + NW - 1) / NW;         // pieces per wave per group (the surplus ones are dummies)
@@ -725,8 +727,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 ? 1 : 2)) voi
   };
   (void)rowpitch2;
 
+  // step index -> (chunk, kernel row, dx position) of the weight tile D steps ahead, kept incrementally
+  const int NS = 3 * NQ;
   issue_a(0, A_PER, 0, 0, abuf0);
-  issue_b(0, 0, 0, bbuf0);
+  int pc = 0, pg = 0, pi = 0, ps = 0;      // next weight tile to prefetch
+  auto issue_next_b = [&]() {
+    char* bb = bbuf0 + (ps % NSTB) * BBYTES;
+    if (ps < NS) {
+      issue_b(pc, pg, pi, bb);
+    } else {                                 // past the end: keep the vmcnt bookkeeping uniform (zero fill of a free slot)
+#pragma unroll
+      for (int q = 0; q < B_PER; ++q) bufld16(rsrc_w, bb + (wid * B_PER + q) * 1024, OOB_VOFF, 0);
+    }
+    ++ps;
+    if (++pi == 3) {
+      pi = 0;
+      if (++pg == 3) {
+        pg = 0;
+        ++pc;
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_next_b();
 
   int c = 0, g = 0;           // current group
   int sb = 0;                 // weight buffer of the current step
@@ -741,20 +764,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 ? 1 : 2)) voi
     char* const abn = abuf0 + ((q + 1) & 1) * ABYTES;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      // B(s) was issued one step ago, followed by that step's share of the next pixel tile: those may stay in flight
-      if (i == 0 || !has_next) wait_vmcnt<0>();
-      else if (i == 1) wait_vmcnt<AC0>();
-      else wait_vmcnt<AC1>();
+      if (NSTB == 2) {
+        // order per step: B(s+1), then this step's share of the next pixel tile -> those pieces may stay in flight
+        if (i == 0 || !has_next) wait_vmcnt<0>();
+        else if (i == 1) wait_vmcnt<AC0>();
+        else wait_vmcnt<AC1>();
+      } else {
+        // order per step: share of the next pixel tile FIRST, then B(s+2): the youngest weight tile (and the pixel pieces issued
+        // one step ago) may stay in flight; at i == 0 the whole pixel tile of this group must have landed
+        if (i == 0) wait_vmcnt<B_PER>();
+        else if (i == 1) { if (has_next) wait_vmcnt<B_PER + AC0>(); else wait_vmcnt<B_PER>(); }
+        else { if (has_next) wait_vmcnt<B_PER + AC1>(); else wait_vmcnt<B_PER>(); }
+      }
       __builtin_amdgcn_s_barrier();
       char* const bb = bbuf0 + sb * BBYTES;
-      char* const bbn = bbuf0 + (sb ^ 1) * BBYTES;
-      if (i < 2) issue_b(c, g, i + 1, bbn);
-      else if (has_next) issue_b(cn, gn, 0, bbn);
+      if (NSTB == 2) issue_next_b();
       if (has_next) {
         if (i == 0) issue_a(0, AC0, cn, gn, abn);
         else if (i == 1) issue_a(AC0, AC0 + AC1, cn, gn, abn);
         else issue_a(AC0 + AC1, A_PER, cn, gn, abn);
       }
+      if (NSTB != 2) issue_next_b();
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8_t wf[TN], af[TM];
@@ -770,11 +800,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 ? 1 : 2)) voi
 #pragma unroll
           for (int j = 0; j < TM; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af[j], acc[t][j], 0, 0, 0);
       }
-      sb ^= 1;
+      sb = sb + 1 == NSTB ? 0 : sb + 1;
     }
     c = cn;
     g = gn;
   }
+  wait_vmcnt<0>();            // the uniform-count dummy pieces of the last steps
   (void)AC2;
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
@@ -1262,16 +1293,16 @@ static bool dx_applicable(const IgemmParams& p) {
   return p.dx[0] != p.dx[1] && p.dx[1] != p.dx[2] && p.dx[0] != p.dx[2];
 }
 
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2>
 int launch_dx(const IgemmParams& p, hipStream_t st) {
   if (!dx_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int A_PER = (BM / 8 + 2 + NW - 1) / NW;
-  constexpr int lds_ring = 2 * A_PER * NW * 8 * 128 + 2 * BN * 128;
+  constexpr int lds_ring = 2 * A_PER * NW * 8 * 128 + NSTB * BN * 128;
   constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
   constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
-  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI>;
+  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1306,6 +1337,9 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves
     case 18: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 8, 4, EPI>(p, st); break;   // dx reuse 256x256, 8 waves of 128x64
     case 19: if (dx_applicable(p)) return launch_dx<2, 2, 8, 4, EPI>(p, st); break;                           // dx reuse 256x128, 4 waves of 128x64
+    case 26: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI, 3>(p, st); break;                        // dx reuse 256x128, 8 waves, weight ring 3
+    case 27: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI, 3>(p, st); break;                        // dx reuse 128x128, weight ring 3 (1 WG/CU)
+    case 28: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI, 3>(p, st); break; // dx reuse 128x256, 8 waves, ring 3
     case 21: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 1>(p, st); break;   // ablations of cfg 1
     case 22: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 2>(p, st); break;
     case 23: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 3>(p, st); break;
@@ -1347,10 +1381,10 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
   float best_ms = 1e30f;
-  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19};
+  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28};
   for (int cfg : cands) {
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
-    if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18) && p.CoutPad % 256 != 0))) continue;
+    if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18 || cfg == 28) && p.CoutPad % 256 != 0))) continue;
     int e = run_cfg<EPI>(cfg, p, st);
     if (e) return e;
     (void)hipEventRecord(e0, st);

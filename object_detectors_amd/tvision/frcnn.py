@@ -135,7 +135,7 @@ class FasterRCNN(nn.Module):
                 x = self.box_roi_pool.forward_nhwc(feats, boxes, image_shapes)
                 cls, reg = self.box_predictor(self.box_head(x))
                 b, s, l = roi_heads_postprocess_detections(cls, reg, boxes, image_shapes, self.tfidf_post, self.box_score_thresh,
-                                                           self.box_nms_thresh, self.box_detections_per_img, self.bbox_reg_weights)
+                                                           self.box_nms_thresh, self.box_detections_per_img, self.bbox_reg_weights, self.loss_type)
             return [{"boxes": bb, "labels": ll, "scores": ss} for bb, ll, ss in zip(b, l, s)]
         # ---- training: RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient)
         obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)

@@ -72,13 +72,19 @@ def retinanet_postprocess_detections(cls_logits_per_level, bbox_reg_per_level, a
 
 
 def roi_heads_postprocess_detections(class_logits, box_regression, proposals, image_shapes, tfidf_post=1.0, score_thresh=0.05,
-                                     nms_thresh=0.5, detections_per_img=100, weights=(10.0, 10.0, 5.0, 5.0)):
-    """RoIHeads.postprocess_detections, 'ce' scores (softmax), per-class batched NMS."""
+                                     nms_thresh=0.5, detections_per_img=100, weights=(10.0, 10.0, 5.0, 5.0), loss_type="ce"):
+    """RoIHeads.postprocess_detections (roi_heads.py:715-781): scores by the training loss ('ce' softmax, 'gombit*' double-exponential,
+    otherwise sigmoid; :724-729), per-class batched NMS."""
     coder = BoxCoder(weights)
     num_classes = class_logits.shape[-1]
     per_img = [len(p) for p in proposals]
     pred_boxes = coder.decode(box_regression, proposals)
-    pred_scores = torch.softmax(tfidf_post * class_logits, -1)
+    if loss_type == "ce":
+        pred_scores = torch.softmax(tfidf_post * class_logits, -1)
+    elif loss_type.startswith("gombit"):
+        pred_scores = 1 / (torch.exp(torch.exp(-tfidf_post * (class_logits - 1.96))))
+    else:
+        pred_scores = torch.sigmoid(tfidf_post * class_logits)
     out_b, out_s, out_l = [], [], []
     for boxes, scores, shape in zip(pred_boxes.split(per_img, 0), pred_scores.split(per_img, 0), image_shapes):
         boxes = box_ops.clip_boxes_to_image(boxes, shape)
