@@ -62,14 +62,15 @@ def pmc_traffic(batch, px):
     PMC counters cannot be read from inside the process, so the figure is the one measured for bs=32 / 640 px."""
     path = os.path.join(ROOT, "profiles", "r01c_pmc_summary.json")
     if batch != 32 or px != 640 or not os.path.exists(path):
-        return None, None
+        return None, None, None
     d = json.load(open(path))
     n = b = 0.0
     for fam in ("igemm fwd (BN partial stats)", "igemm fwd (fp32 head)"):
         if fam in d and d[fam]["read_MB_per_launch"] is not None and d[fam]["write_MB_per_launch"] is not None:
             n += d[fam]["launches_per_step"]
             b += d[fam]["launches_per_step"] * (d[fam]["read_MB_per_launch"] + d[fam]["write_MB_per_launch"]) * 1e6
-    return (round(b / n) if n else None), "profiles/r01c_pmc_summary.md"
+    mu = d.get("igemm fwd (BN partial stats)", {}).get("mfma_util_pct")
+    return (round(b / n) if n else None), "profiles/r01c_pmc_summary.md", (round(mu, 1) if mu is not None else None)
 
 
 def cpu_baseline(px, sample_bs=2, iters=2):
@@ -214,9 +215,10 @@ def main():
             tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _f in events)
             tot_fl = sum(f for _a, _b, f in events)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic(args.batch, args.px)
+            traffic, tsrc, mfma_util = pmc_traffic(args.batch, args.px)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": tsrc,
+                    "mfma_util_counter_pct": mfma_util,
                     "kernel": "igemm_kernel (conv forward, all 75 launches/step)",
                     "launches": len(events), "avg_launch_us": round(1000.0 * tot_ms / len(events), 2),
                     "gflop_per_launch": round(tot_fl / len(events) / 1e9, 3)}
