@@ -68,6 +68,10 @@ __device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
   return __builtin_bit_cast(bf16x4_t, v);
 }
 
+// CI x CJ = 16-wide fragments per wave along cout / n': 4 x 4 is the full 128x128 tile; layers whose Cout or k*k*Cin is 32 / 64 (the
+// first Darknet layers) use 1 or 2 so that the four waves split the REAL channels instead of multiplying zero fragments
+// (50-94 % of the MFMA issue with the full tile).  Staging and the slab layout are unchanged.
+template <int CI, int CJ>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int STAGE = 2 * WG_BKP * WG_ROWB;   // dy tile + x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,11 +158,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[CI][CJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < CI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < CJ; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
 
   const int ksteps = (mB - mA + WG_BKP - 1) / WG_BKP;
   stage(mA, 0);
@@ -175,14 +179,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const char* sx = sd + WG_BKP * WG_ROWB;
 #pragma unroll
     for (int ks = 0; ks < WG_BKP / 32; ++ks) {
-      bf16x8_t af[4], bfr[4];
+      bf16x8_t af[CI], bfr[CJ];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = ks * 32 + 8 * g + 4 * h + q;
         const int f = rowf(row);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int blk = (wr * 64 + i * 16) >> 4;   // 32-byte block index of this 16-channel group
+        for (int i = 0; i < CI; ++i) {
+          const int blk = wr * CI + i;   // 32-byte block index of this 16-channel group
           const bf16x4_t v = lds_tr(sd + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
           af[i][4 * h + 0] = v[0];
           af[i][4 * h + 1] = v[1];
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
           af[i][4 * h + 3] = v[3];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int blk = (wc * 64 + j * 16) >> 4;
+        for (int j = 0; j < CJ; ++j) {
+          const int blk = wc * CJ + j;
           const bf16x4_t v = lds_tr(sx + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
           bfr[j][4 * h + 0] = v[0];
           bfr[j][4 * h + 1] = v[1];
@@ -200,9 +204,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < CI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < CJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -215,23 +219,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     // wgrad_reduce_kernel adds the slabs into dW in a fixed order (deterministic)
     float* dst = p.slab + ((size_t)split * tiles + tile) * (WG_TILE * WG_TILE);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          dst[(wr * 64 + i * 16 + fq * 4 + r) * WG_TILE + wc * 64 + j * 16 + fr] = acc[i][j][r];
+        for (int j = 0; j < CJ; ++j)
+          dst[((wr * CI + i) * 16 + fq * 4 + r) * WG_TILE + (wc * CJ + j) * 16 + fr] = acc[i][j][r];
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < CI; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int co = co0 + wr * 64 + i * 16 + fq * 4 + r;
+      const int co = co0 + (wr * CI + i) * 16 + fq * 4 + r;
       if (co >= p.Cout) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int np = np0 + wc * 64 + j * 16 + fr;
+      for (int j = 0; j < CJ; ++j) {
+        const int np = np0 + (wc * CJ + j) * 16 + fr;
         if (np < p.NP) p.dw[(long long)co * p.NP + np] += acc[i][j][r];   // single split: this block owns the tile
       }
     }
@@ -466,12 +470,23 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   p.dHo = make_fastdiv((unsigned)p.Ho);
   p.dCin = make_fastdiv((unsigned)p.Cin);
   const int lds = 2 * 2 * WG_BKP * WG_ROWB;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
+  // per-wave fragment counts: the four waves (2 x 2) split min(Cout,128) x min(NP,128) real channels
+  const int ci = p.Cout <= 32 ? 1 : (p.Cout <= 64 ? 2 : 4), cj = p.NP <= 32 ? 1 : (p.NP <= 64 ? 2 : 4);
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, S(stream), p);
+  };
+  switch (ci * 8 + cj) {
+    case 1 * 8 + 1: go(wgrad_kernel<1, 1>); break;
+    case 1 * 8 + 2: go(wgrad_kernel<1, 2>); break;
+    case 1 * 8 + 4: go(wgrad_kernel<1, 4>); break;
+    case 2 * 8 + 1: go(wgrad_kernel<2, 1>); break;
+    case 2 * 8 + 2: go(wgrad_kernel<2, 2>); break;
+    case 2 * 8 + 4: go(wgrad_kernel<2, 4>); break;
+    case 4 * 8 + 1: go(wgrad_kernel<4, 1>); break;
+    case 4 * 8 + 2: go(wgrad_kernel<4, 2>); break;
+    default: go(wgrad_kernel<4, 4>); break;
   }
-  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles * splits), dim3(256), lds, S(stream), p);
   if (p.slab) {
     const long long total = (long long)p.Cout * (p.NP / 4);
     const int gx = (int)min((long long)2048, (total + 255) / 256);
