@@ -1280,10 +1280,10 @@ unsigned long long igemm_key(const IgemmParams& p, int epi) {
 }
 
 // applicability of the dx-reuse kernel: 3x3, unit strides on both sides, taps in three rows of equal dy with dx stepping by +-1
-static bool dx_applicable(const IgemmParams& p) {
+static bool dx_applicable(const IgemmParams& p, int bn = 128) {
   if (p.T != 9 || p.so != 1 || p.sin != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
   if (p.Hin != p.Hout || p.Win != p.Wout || p.MH != p.Hin || p.MW != p.Win) return false;
-  if (p.Cin % 64 != 0 || p.CoutPad % 128 != 0) return false;
+  if (p.Cin % 64 != 0 || p.CoutPad % bn != 0) return false;
   for (int g = 0; g < 3; ++g) {
     if (p.dy[3 * g] != p.dy[3 * g + 1] || p.dy[3 * g] != p.dy[3 * g + 2]) return false;
     for (int i = 0; i < 3; ++i)
@@ -1295,7 +1295,7 @@ static bool dx_applicable(const IgemmParams& p) {
 
 template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2>
 int launch_dx(const IgemmParams& p, hipStream_t st) {
-  if (!dx_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
+  if (!dx_applicable(p, WN * TN * 16)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int A_PER = (BM / 8 + 2 + NW - 1) / NW;
   constexpr int lds_ring = 2 * A_PER * NW * 8 * 128 + NSTB * BN * 128;
@@ -1368,14 +1368,55 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     return run_cfg<EPI>(cfg, p, st);
   }
   if (p.CoutPad % 128 == 0) return launch_cfg<2, 2, 4, 4, 32, 3, EPI>(p, st);
-  if (p.CoutPad % 64 == 0) return k64 ? launch_cfg<4, 1, 4, 4, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 4, 32, 3, EPI>(p, st);
-  if (p.CoutPad % 32 == 0) return k64 ? launch_cfg<4, 1, 4, 2, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 2, 32, 4, EPI>(p, st);
+  // narrow outputs (32 / 64 channels: the first layers and their data gradients): one plain tile shape each, or the
+  // shared-pixel-tile kernel at 256 x 64 / 256 x 32 when the autotuner found it faster
+  int narrow = 0;
+  {
+    auto it = g_igemm_tuned.find(igemm_key(p, EPI));
+    if (it != g_igemm_tuned.end()) narrow = it->second;
+    if (g_tune == 29 || g_tune == 30) narrow = g_tune;
+  }
+  if (p.CoutPad % 64 == 0) {
+    if (narrow == 30 && dx_applicable(p, 64)) return launch_dx<4, 1, 4, 4, EPI>(p, st);
+    return k64 ? launch_cfg<4, 1, 4, 4, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 4, 32, 3, EPI>(p, st);
+  }
+  if (p.CoutPad % 32 == 0) {
+    if (narrow == 29 && dx_applicable(p, 32)) return launch_dx<4, 1, 4, 2, EPI>(p, st);
+    return k64 ? launch_cfg<4, 1, 4, 2, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 2, 32, 4, EPI>(p, st);
+  }
   return fail(MI355DET_EINVAL, "%s: padded Cout must be a multiple of 32 (got %lld)", "conv", p.CoutPad);
 }
 
 // plan-build helper: time the candidate configurations of one launch and remember the fastest
 template <int EPI>
 int autotune_igemm(const IgemmParams& p, hipStream_t st) {
+  if (p.CoutPad % 128 != 0 && p.Cin % 64 == 0 && (p.CoutPad % 64 == 0 ? dx_applicable(p, 64) : dx_applicable(p, 32))) {
+    // narrow output: plain tile (id 0) against the shared-pixel-tile kernel (id 30 / 29)
+    const int alt = p.CoutPad % 64 == 0 ? 30 : 29;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
+    float best_ms = 1e30f;
+    int best = 0;
+    for (int cfg : {0, alt}) {
+      g_igemm_tuned[igemm_key(p, EPI)] = cfg;
+      int e = launch_igemm<EPI>(p, st);
+      if (e) return e;
+      (void)hipEventRecord(e0, st);
+      for (int r = 0; r < 3; ++r) (void)launch_igemm<EPI>(p, st);
+      (void)hipEventRecord(e1, st);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best_ms) {
+        best_ms = ms;
+        best = cfg;
+      }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    g_igemm_tuned[igemm_key(p, EPI)] = best;
+    return best;
+  }
   if (!(p.CoutPad % 128 == 0 && p.Cin % 64 == 0)) return 0;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");

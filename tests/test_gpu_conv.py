@@ -350,3 +350,43 @@ def test_dx_reuse_kernel_matches_default(case):
         assert float((dx15 - dx1).abs().max()) <= 1e-2 * float(dx1.abs().max()), cfg
         assert float((dxr15 - dxr1).abs().max()) <= 1e-2 * float(dxr1.abs().max()), cfg
         torch.testing.assert_close(st15, st1, rtol=2e-2, atol=2e-2 * float(st1.abs().max()))
+
+
+@pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (2, 16, 20, 64, 32), (2, 12, 12, 32, 64), (1, 9, 7, 64, 64)])
+def test_narrow_output_shared_pixel_tile_kernels(case):
+    """256x64 / 256x32 shared-pixel-tile kernels (ids 30 / 29: the first Darknet layers and their data gradients) against the plain
+    narrow tiles: forward + statistics where cout is 32/64, data gradient where cin is 32/64."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout = case
+    x = rnd((n, cin, h, w), 1)
+    wt = rnd((cout, cin, 3, 3), 2, (2.0 / (cin * 9)) ** 0.5)
+    gy = rnd((n, cout, h, w), 3)
+    shape = ops.conv_shape(n, h, w, cin, cout, 3, 1)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    xd, gyd = nhwc(x), nhwc(gy)
+    rows = ops.conv_stats_rows(shape)
+    outs = {}
+    try:
+        for cfg in (0, 29, 30):
+            lib().mi355det_debug_set(0, cfg)
+            y = torch.full((n, h, w, cout), 5.0, device=dev(), dtype=torch.bfloat16)
+            stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())
+            dx = torch.full((n, h, w, cin), 5.0, device=dev(), dtype=torch.bfloat16)
+            if cin % 64 == 0:
+                ops.conv_fwd(shape, xd, wf, y, stats=stats)
+            if cout % 64 == 0:              # the dgrad's reduction dimension
+                ops.conv_dgrad(shape, gyd, wd, dx)
+            torch.cuda.synchronize()
+            outs[cfg] = (y.float().cpu(), stats[:rows].sum(0).cpu(), dx.float().cpu())
+    finally:
+        lib().mi355det_debug_set(0, 0)
+    y0, s0, d0 = outs[0]
+    for cfg in (29, 30):
+        y1, s1, d1 = outs[cfg]
+        assert float((y1 - y0).abs().max()) <= 1e-2 * float(y0.abs().max()) + 1e-6, cfg
+        assert float((d1 - d0).abs().max()) <= 1e-2 * float(d0.abs().max()) + 1e-6, cfg
+        torch.testing.assert_close(s1, s0, rtol=2e-2, atol=2e-2 * float(s0.abs().max()) + 1e-6)
+    ref = F.conv2d(x, wt, padding=1).permute(0, 2, 3, 1)
+    if cin % 64 == 0:
+        assert float((y0 - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
