@@ -67,6 +67,64 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_retina(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        from object_detectors_amd.parallel import GradSync
+        from object_detectors_amd.tvision.engine import RetinaNetEngine
+        eng = RetinaNetEngine(21, 9, 3, device=dev, seed=0)
+        for sp in eng.specs:
+            if sp.bn and sp.bn.endswith(".bn3"):
+                eng.buffers[sp.bn + ".weight"].fill_(0.2)
+        eng.refresh_frozen()
+        g = torch.Generator().manual_seed(200 + rank)
+        x = torch.rand((2, 3, 128, 128), generator=g).to(dev)
+        t = [{"boxes": torch.tensor([[8.0 + 10 * rank, 12.0, 70.0, 90.0], [40.0, 30.0, 120.0, 100.0 + rank]], device=dev),
+              "labels": torch.tensor([3, 7 + rank], device=dev)} for _ in range(2)]
+        eng.train_step(x, t)
+        torch.cuda.synchronize()
+        want = eng.flat_g.clone()
+        dist.all_reduce(want)
+        want /= world
+        sync = GradSync(eng.flat_g, bucket_mb=16)
+        sync.install(eng.plan(2, 128, 128, True))
+        eng.train_step(x, t)
+        sync.wait()
+        torch.cuda.synchronize()
+        err = float((eng.flat_g - want).abs().max()) / (float(want.abs().max()) + 1e-30)
+        # the head weights are shared by five levels: their bucket must fire after the LAST level's weight gradient
+        head = eng.grads["head.classification_head.cls_logits.weight"]
+        o = head.data_ptr() - eng.flat_g.data_ptr()
+        lo = o // 4
+        herr = float((eng.flat_g[lo:lo + head.numel()] - want[lo:lo + head.numel()]).abs().max()) / (float(want.abs().max()) + 1e-30)
+        q.put((rank, len(sync.buckets), err, herr))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, -1, repr(e), 0.0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_retinanet_shared_head_buckets():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_worker_retina, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, nb, err, herr in res:
+        assert nb >= 2, (rank, nb, err)
+        assert err < 5e-3 and herr < 5e-3, (rank, err, herr)
+
+
 def test_two_rank_gradient_average_and_weight_sync():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
