@@ -605,8 +605,10 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
 // per chunk drop 3x (staged bytes -31 % at 128x128).  Weights keep their own 2-deep ring (one tile per tap).
 // vmcnt bookkeeping: per step the wave issues B(s+1) first, then its share (2,2,1 pieces) of the next group's pixel tile,
 // so "all but the pieces issued after B(s)" is a compile-time count at each of the three unrolled positions.
-template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2>
+template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ? 1 : 2)) void igemm_dx_kernel(const IgemmParams p) {
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, t_f = 0, c_wait = 0, c_bar = 0, c_issue = 0, c_read = 0, c_mfma = 0, t_begin = 0, t_loop = 0;
+  STAMP(t_begin);
   constexpr int BK = 64, NT = WM * WN * 64, NW = WM * WN;
   constexpr int D = NSTB - 1;                            // weight tiles in flight ahead of the one being consumed
   static_assert(NSTB == 2 || NSTB == 3, "weight ring depth 2 or 3");
@@ -726,7 +728,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
     for (int q = 0; q < B_PER; ++q) bufld16(rsrc_w, bb + (wid * B_PER + q) * 1024, b_voff[q], koff);
   };
   (void)rowpitch2;
-
   // step index -> (chunk, kernel row, dx position) of the weight tile D steps ahead, kept incrementally
   const int NS = 3 * NQ;
   issue_a(0, A_PER, 0, 0, abuf0);
@@ -764,6 +765,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
     char* const abn = abuf0 + ((q + 1) & 1) * ABYTES;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+      STAMP(t_a);
       if (NSTB == 2) {
         // order per step: B(s+1), then this step's share of the next pixel tile -> those pieces may stay in flight
         if (i == 0 || !has_next) wait_vmcnt<0>();
@@ -776,7 +778,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
         else if (i == 1) { if (has_next) wait_vmcnt<B_PER + AC0>(); else wait_vmcnt<B_PER>(); }
         else { if (has_next) wait_vmcnt<B_PER + AC1>(); else wait_vmcnt<B_PER>(); }
       }
+      STAMP(t_b);
       __builtin_amdgcn_s_barrier();
+      STAMP(t_c);
       char* const bb = bbuf0 + sb * BBYTES;
       if (NSTB == 2) issue_next_b();
       if (has_next) {
@@ -785,6 +789,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
         else issue_a(AC0 + AC1, A_PER, cn, gn, abn);
       }
       if (NSTB != 2) issue_next_b();
+      STAMP(t_d);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8_t wf[TN], af[TM];
@@ -795,10 +800,25 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
           af[j] = *(const bf16x8_t*)(ab + (afrag[i][j] ^ (ks << 6)));
           if ((edge[i] >> j) & 1u) af[j] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
         }
+        if (PROF) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // diagnostic build: separate the fragment reads from the MFMAs
+          STAMP(t_e);
+          if (ks == 0) c_read += t_e - t_d; else c_read += t_e - t_f;
+        }
 #pragma unroll
         for (int t = 0; t < TN; ++t)
 #pragma unroll
           for (int j = 0; j < TM; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af[j], acc[t][j], 0, 0, 0);
+        if (PROF) {
+          asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[TN - 1][TM - 1][3]));
+          STAMP(t_f);
+          c_mfma += t_f - t_e;
+        }
+      }
+      if (PROF) {
+        c_wait += t_b - t_a;
+        c_bar += t_c - t_b;
+        c_issue += t_d - t_c;
       }
       sb = sb + 1 == NSTB ? 0 : sb + 1;
     }
@@ -806,6 +826,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
     g = gn;
   }
   wait_vmcnt<0>();            // the uniform-count dummy pieces of the last steps
+  if (PROF) {
+    STAMP(t_loop);
+    if (lane == 0 && p.dbg) {
+      unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wid) * 8;
+      d[0] = c_wait; d[1] = c_bar; d[2] = c_issue; d[3] = c_read; d[4] = c_mfma; d[5] = t_loop - t_begin; d[6] = NQ * 3; d[7] = 0;
+    }
+  }
   (void)AC2;
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
@@ -1293,8 +1320,10 @@ static bool dx_applicable(const IgemmParams& p, int bn = 128) {
   return p.dx[0] != p.dx[1] && p.dx[1] != p.dx[2] && p.dx[0] != p.dx[2];
 }
 
-template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2>
-int launch_dx(const IgemmParams& p, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = false>
+int launch_dx(const IgemmParams& p_in, hipStream_t st) {
+  IgemmParams p = p_in;
+  p.dbg = PROF ? g_dbg : nullptr;
   if (!dx_applicable(p, WN * TN * 16)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int A_PER = (BM / 8 + 2 + NW - 1) / NW;
@@ -1302,7 +1331,7 @@ int launch_dx(const IgemmParams& p, hipStream_t st) {
   constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
   constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
-  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB>;
+  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB, PROF>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1351,6 +1380,8 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 31: if (EPI == EPI_PLAIN) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, true>(p, st); break;   // interleaved issue
     case 25: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 5>(p, st); break;
     case 99: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, true>(p, st); break;   // phase-stamp diagnostic build
+    case 98: if (EPI == EPI_STATS && dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI, 2, true>(p, st); break;   // same for the shared-pixel-tile kernel
+    case 97: if (EPI == EPI_STATS && dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI, 3, true>(p, st); break;   // 256x128, 8 waves, ring 3
     default: break;
   }
   return launch_cfg<2, 2, 4, 4, 64, 2, EPI>(p, st);
