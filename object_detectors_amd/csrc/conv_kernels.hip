@@ -605,15 +605,16 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
 // per chunk drop 3x (staged bytes -31 % at 128x128).  Weights keep their own 2-deep ring (one tile per tap).
 // vmcnt bookkeeping: per step the wave issues B(s+1) first, then its share (2,2,1 pieces) of the next group's pixel tile,
 // so "all but the pieces issued after B(s)" is a compile-time count at each of the three unrolled positions.
-template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = false>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ? 1 : 2)) void igemm_dx_kernel(const IgemmParams p) {
+template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = false, int BK = 64>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ? 1 : (BK == 32 ? 3 : 2))) void igemm_dx_kernel(const IgemmParams p) {
   unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, t_e = 0, t_f = 0, c_wait = 0, c_bar = 0, c_issue = 0, c_read = 0, c_mfma = 0, t_begin = 0, t_loop = 0;
   STAMP(t_begin);
-  constexpr int BK = 64, NT = WM * WN * 64, NW = WM * WN;
+  constexpr int NT = WM * WN * 64, NW = WM * WN;
+  static_assert(BK == 64 || BK == 32, "k-step of 64 or 32 channels");
   constexpr int D = NSTB - 1;                            // weight tiles in flight ahead of the one being consumed
   static_assert(NSTB == 2 || NSTB == 3, "weight ring depth 2 or 3");
-  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, ROWB = 128, R = 8, CPR = 8;
-  constexpr int A_INSTR = BM / R + 2;                    // 8 halo rows each side (one LDS-DMA piece = 8 rows)
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, ROWB = BK * 2, R = 1024 / ROWB, CPR = BK / 8, KS = BK / 32;
+  constexpr int A_INSTR = BM / R + 2;                    // one LDS-DMA piece (R rows) of halo on each side
   constexpr int A_PER = (A_INSTR + NW - 1) / NW;         // pieces per wave per group (the surplus ones are dummies)
   constexpr int A_ROWS = A_PER * NW * R;
   constexpr int B_INSTR = BN / R, B_PER = B_INSTR / NW;
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
   const int mt = bid / ntn, nt = bid - mt * ntn;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const int n_first = (int)fdiv(fdiv((unsigned)max(m0 - 8, 0), p.dMW), p.dMH);
+  const int n_first = (int)fdiv(fdiv((unsigned)max(m0 - R, 0), p.dMW), p.dMH);
   const int Ktot = 9 * p.Cin;
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
@@ -650,15 +651,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
     dxi[g] = (int)((p.dx_pack >> (4 * g)) & 0xF) - 2;
   }
 
-  // ---- pixel-tile rows this lane stages: extended row e <-> lattice pixel m0 - 8 + e
-  const int lrow = lane >> 3, cpos = lane & 7;
+  // ---- pixel-tile rows this lane stages: extended row e <-> lattice pixel m0 - R + e
+  const int lrow = lane / CPR, cpos = lane % CPR;
   int a_voff[A_PER];
   unsigned a_valid[A_PER];      // bit g: source row y + dy_g inside the image
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
     const int instr = wid * A_PER + i;
     const int e = instr * R + lrow;
-    const int m = m0 - 8 + e;
+    const int m = m0 - R + e;
     unsigned vm = 0;
     int voff = OOB_VOFF;
     if (instr < A_INSTR && m >= 0 && m < p.M) {
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
     const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int e = r + 8 + dxi[i];
+      const int e = r + R + dxi[i];
       afrag[i][j] = e * ROWB + ((fq ^ swz<BK>(e)) << 4);
       const bool off = (dxi[i] < 0 && xx == 0) || (dxi[i] > 0 && xx == p.MW - 1);
       edge[i] |= off ? (1u << j) : 0u;
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
       if (NSTB != 2) issue_next_b();
       STAMP(t_d);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         bf16x8_t wf[TN], af[TM];
 #pragma unroll
         for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8_t*)(bb + (wfrag[t] ^ (ks << 6)));
@@ -1320,18 +1321,19 @@ static bool dx_applicable(const IgemmParams& p, int bn = 128) {
   return p.dx[0] != p.dx[1] && p.dx[1] != p.dx[2] && p.dx[0] != p.dx[2];
 }
 
-template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = false>
+template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = false, int BK = 64>
 int launch_dx(const IgemmParams& p_in, hipStream_t st) {
   IgemmParams p = p_in;
   p.dbg = PROF ? g_dbg : nullptr;
   if (!dx_applicable(p, WN * TN * 16)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int A_PER = (BM / 8 + 2 + NW - 1) / NW;
-  constexpr int lds_ring = 2 * A_PER * NW * 8 * 128 + NSTB * BN * 128;
+  constexpr int R = 1024 / (BK * 2);
+  constexpr int A_PER = (BM / R + 2 + NW - 1) / NW;
+  constexpr int lds_ring = 2 * A_PER * NW * 1024 + NSTB * BN * BK * 2;
   constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
   constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
-  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB, PROF>;
+  auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB, PROF, BK>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1366,6 +1368,7 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves
     case 18: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 8, 4, EPI>(p, st); break;   // dx reuse 256x256, 8 waves of 128x64
     case 19: if (dx_applicable(p)) return launch_dx<2, 2, 8, 4, EPI>(p, st); break;                           // dx reuse 256x128, 4 waves of 128x64
+    case 35: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI, 2, false, 32>(p, st); break;            // dx reuse 128x128x32: 3 workgroups/CU
     case 26: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI, 3>(p, st); break;                        // dx reuse 256x128, 8 waves, weight ring 3
     case 27: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI, 3>(p, st); break;                        // dx reuse 128x128, weight ring 3 (1 WG/CU)
     case 28: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI, 3>(p, st); break; // dx reuse 128x256, 8 waves, ring 3
@@ -1453,7 +1456,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
   float best_ms = 1e30f;
-  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28};
+  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28};     // 35 (BK 32, 3 workgroups per CU) measured slower: not tried
   for (int cfg : cands) {
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
     if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18 || cfg == 28) && p.CoutPad % 256 != 0))) continue;

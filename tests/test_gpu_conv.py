@@ -325,7 +325,7 @@ def test_dx_reuse_kernel_matches_default(case):
     rows = ops.conv_stats_rows(shape)
     outs = {}
     try:
-        for cfg in (1, 15, 16, 17, 18, 19, 26, 27, 28):
+        for cfg in (1, 15, 16, 17, 18, 19, 26, 27, 28, 35):
             lib().mi355det_debug_set(0, cfg)
             y = torch.full((n, h, w, cout), 5.0, device=dev(), dtype=torch.bfloat16)
             stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())
@@ -341,7 +341,7 @@ def test_dx_reuse_kernel_matches_default(case):
     yr = y_ref.detach().permute(0, 2, 3, 1)
     gr = xr.grad.permute(0, 2, 3, 1)
     y1, st1, dx1, dxr1 = outs[1]
-    for cfg in (15, 16, 17, 18, 19, 26, 27, 28):          # 17 / 18 / 28 (256-wide) fall back to the default tile when cout % 256 != 0
+    for cfg in (15, 16, 17, 18, 19, 26, 27, 28, 35):          # 17 / 18 / 28 (256-wide) fall back to the default tile when cout % 256 != 0
         y15, st15, dx15, dxr15 = outs[cfg]
         assert float((y15 - yr).abs().max()) <= 2e-2 * float(yr.abs().max()), cfg
         assert float((dx15 - gr).abs().max()) <= 2e-2 * float(gr.abs().max()), cfg
