@@ -179,3 +179,21 @@ def test_module_mirror_eval_and_train(setup):
     assert set(out.keys()) == {"classification", "bbox_regression"} and all(torch.isfinite(v) for v in out.values())
     with pytest.raises(ValueError):
         m(x.to(dev()), [{"boxes": torch.tensor([[10.0, 12.0, 5.0, 90.0]], device=dev()), "labels": torch.tensor([5], device=dev())}] * BS)
+
+
+def test_image_without_ground_truth(setup):
+    """retinanet.py:404-407: an image with no boxes is all background (matched = -1): finite losses, zero regression term for it."""
+    eng, _sd, x = setup
+    t = [{"boxes": torch.zeros((0, 4), device=dev()), "labels": torch.zeros((0,), dtype=torch.int64, device=dev())},
+         {"boxes": torch.tensor([[10.0, 12.0, 70.0, 90.0]], device=dev()), "labels": torch.tensor([5], device=dev())}]
+    losses = eng.train_step(x.to(dev()), t)
+    torch.cuda.synchronize()
+    p = eng._last_plan
+    assert bool(torch.isfinite(losses).all()) and float(losses[0]) > 0
+    assert int((p.matched[0] != -1).sum()) == 0 and int((p.matched[1] >= 0).sum()) > 0
+    assert float(eng.last_num_foreground[0]) == 0.0
+    assert float(p.gbbox[0].abs().max()) == 0.0 and float(p.gbbox[1].abs().max()) > 0.0
+    both_empty = [t[0], t[0]]
+    losses = eng.train_step(x.to(dev()), both_empty)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(losses).all()) and float(losses[1]) == 0.0
