@@ -71,6 +71,8 @@ enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4, EPI_
 #define EPI_LDS_OFF 4096                               // epilogue staging starts behind the BN-statistics scratch
 #define EPI_LDS_BYTES(nwaves) (EPI_LDS_OFF + (nwaves) * (64 * (8 * 16 * 2 + 16) + 256))   // upper bound (TN <= 8)
 
+extern int g_wgrad_general;   // wgrad_kernels.hip
+
 namespace {
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) {
@@ -1549,6 +1551,7 @@ extern "C" {
 
 int mi355det_debug_set(int key, int value) {
   if (key == 0) g_tune = value;
+  if (key == 1) g_wgrad_general = value;
   return 0;
 }
 

@@ -50,6 +50,8 @@ struct WgradParams {
   FastDiv dWo, dHo, dCin;
 };
 
+int g_wgrad_general = 0;   // diagnostic (mi355det_debug_set(1, v)): 1 = always the per-lane bookkeeping form (tests compare the two)
+
 namespace {
 
 #define WG_BKP 64      // pixels per k-step
@@ -61,6 +63,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) 
                                    (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 }
 
+// LDS-DMA through a buffer descriptor (per-lane 32-bit byte offset + SCALAR offset); a lane whose offset is out of range
+// gets zeros written to LDS
+__device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t rsrc, void* lds_dst_uniform, int voffset, int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, voffset, soffset, 0, 0);
+}
+#define OOB_VOFF ((int)0x80000000)
+
 __device__ __forceinline__ int rowf(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 __device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
@@ -71,7 +80,11 @@ __device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
 // CI x CJ = 16-wide fragments per wave along cout / n': 4 x 4 is the full 128x128 tile; layers whose Cout or k*k*Cin is 32 / 64 (the
 // first Darknet layers) use 1 or 2 so that the four waves split the REAL channels instead of multiplying zero fragments
 // (50-94 % of the MFMA issue with the full tile).  Staging and the slab layout are unchanged.
-template <int CI, int CJ>
+// GRP4: Wo % 4 == 0 (every feature map of a 32-divisible image), so the four pixels of one LDS-DMA piece lie in one image row:
+// their (n, ho, wo) bookkeeping is wave-uniform (SALU), the dY offsets are loop constants and the X offsets are a lane constant plus a
+// scalar; the per-step vector work drops from ~146 to ~25 VALU instructions (the general form spends more issue cycles on
+// addresses than on the 32 MFMAs of a step).
+template <int CI, int CJ, bool GRP4>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int STAGE = 2 * WG_BKP * WG_ROWB;   // dy tile + x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,6 +130,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   int r_n[4], r_ho[4], r_wo[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (GRP4) break;
     const unsigned um = (unsigned)(mA + (wid * 4 + i) * 4 + lrow);
     const unsigned q1 = fdiv(um, p.dWo);
     r_wo[i] = (int)(um - q1 * p.Wo);
@@ -125,7 +139,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     r_n[i] = (int)n;
   }
 
-  auto stage = [&](int m_base, int buf) {
+  // GRP4 state: per LDS-DMA piece (4 pixels of one image row) the scalar (n, ho, wo) of its first pixel; per lane and swizzle
+  // phase the constant parts of the X offset and of the bounds tests
+  int g_n[4], g_ho[4], g_wo[4], dyv[4], lc[2], ty[2], cx[2];
+  __amdgpu_buffer_rsrc_t rsrc_x;
+  if constexpr (GRP4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned um = (unsigned)(mA + (wid * 4 + i) * 4);
+      const unsigned q1 = fdiv(um, p.dWo);
+      g_wo[i] = (int)(um - q1 * p.Wo);
+      const unsigned n = fdiv(q1, p.dHo);
+      g_ho[i] = (int)(q1 - n * p.Ho);
+      g_n[i] = (int)n;
+      const int ph = (i >> 1) & 1;
+      dyv[i] = (ph ? dy_ok1 : dy_ok0) ? (((wid * 4 + i) * 4 + lrow) * p.lddy + dy_off[ph]) * 2 : OOB_VOFF;
+    }
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      // address = x - bias + [((n*H + ho*s)*W + wo*s) * ldx] + [((kh*W + lrow*s + kw) * ldx + ci)], bias = (pad*W + pad) * ldx
+      lc[ph] = (((x_tapdy[ph] + p.pad) * p.W + lrow * p.stride + x_tapdx[ph] + p.pad) * p.ldx + x_off[ph]) * 2;
+      ty[ph] = x_ok[ph] ? x_tapdy[ph] : -(1 << 24);
+      cx[ph] = lrow * p.stride + x_tapdx[ph];
+    }
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (p.pad * p.W + p.pad) * p.ldx), 0, 0x7FFFFFF0, 0x00020000);
+  }
+  auto stage_grp4 = [&](int m_base, int buf) {
+    char* sd = smem + buf * STAGE;
+    char* sx = sd + WG_BKP * WG_ROWB;
+    const int rem = mB - m_base;   // rows past it read zeros through the descriptor's range check
+    const __amdgpu_buffer_rsrc_t rsrc_dy =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (long long)m_base * p.lddy), 0, rem * p.lddy * 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int instr = wid * 4 + i;
+      const int ph = (i >> 1) & 1;
+      bufld16(rsrc_dy, sd + instr * 1024, dyv[i], 0);
+      const int hs = g_ho[i] * p.stride, ws = g_wo[i] * p.stride;
+      const int sb = ((g_n[i] * p.H + hs) * p.W + ws) * p.ldx * 2;
+      const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
+      bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, sb);
+      g_wo[i] += p.step_r;
+      g_ho[i] += p.step_q;
+      if (g_wo[i] >= p.Wo) {
+        g_wo[i] -= p.Wo;
+        g_ho[i] += 1;
+      }
+      while (g_ho[i] >= p.Ho) {
+        g_ho[i] -= p.Ho;
+        g_n[i] += 1;
+      }
+    }
+  };
+
+  auto stage_any = [&](int m_base, int buf) {
     char* sd = smem + buf * STAGE;
     char* sx = sd + WG_BKP * WG_ROWB;
 #pragma unroll
@@ -156,6 +223,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         r_n[i] += 1;
       }
     }
+  };
+
+  auto stage = [&](int m_base, int buf) {
+    if constexpr (GRP4)
+      stage_grp4(m_base, buf);
+    else
+      stage_any(m_base, buf);
   };
 
   f32x4_t acc[CI][CJ];
@@ -476,17 +550,23 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, S(stream), p);
   };
+  // scalar pixel bookkeeping needs 4-pixel groups inside one image row and 31-bit byte offsets into x
+  const bool grp4 = g_wgrad_general == 0 && p.Wo % 4 == 0 &&
+                    ((long long)s->n * p.H * p.W + (long long)p.pad * (p.W + 1)) * p.ldx * 2 < 0x7FFFFFF0ll &&
+                    (long long)chunk * p.lddy * 2 < 0x7FFFFFF0ll;
+#define WG_GO(a, b) (grp4 ? go(wgrad_kernel<a, b, true>) : go(wgrad_kernel<a, b, false>))
   switch (ci * 8 + cj) {
-    case 1 * 8 + 1: go(wgrad_kernel<1, 1>); break;
-    case 1 * 8 + 2: go(wgrad_kernel<1, 2>); break;
-    case 1 * 8 + 4: go(wgrad_kernel<1, 4>); break;
-    case 2 * 8 + 1: go(wgrad_kernel<2, 1>); break;
-    case 2 * 8 + 2: go(wgrad_kernel<2, 2>); break;
-    case 2 * 8 + 4: go(wgrad_kernel<2, 4>); break;
-    case 4 * 8 + 1: go(wgrad_kernel<4, 1>); break;
-    case 4 * 8 + 2: go(wgrad_kernel<4, 2>); break;
-    default: go(wgrad_kernel<4, 4>); break;
+    case 1 * 8 + 1: WG_GO(1, 1); break;
+    case 1 * 8 + 2: WG_GO(1, 2); break;
+    case 1 * 8 + 4: WG_GO(1, 4); break;
+    case 2 * 8 + 1: WG_GO(2, 1); break;
+    case 2 * 8 + 2: WG_GO(2, 2); break;
+    case 2 * 8 + 4: WG_GO(2, 4); break;
+    case 4 * 8 + 1: WG_GO(4, 1); break;
+    case 4 * 8 + 2: WG_GO(4, 2); break;
+    default: WG_GO(4, 4); break;
   }
+#undef WG_GO
   if (p.slab) {
     const long long total = (long long)p.Cout * (p.NP / 4);
     const int gx = (int)min((long long)2048, (total + 255) / 256);

@@ -390,3 +390,35 @@ def test_narrow_output_shared_pixel_tile_kernels(case):
     ref = F.conv2d(x, wt, padding=1).permute(0, 2, 3, 1)
     if cin % 64 == 0:
         assert float((y0 - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", [(3, 20, 12, 64, 128, 3, 1, 64, 128), (2, 24, 16, 32, 64, 3, 2, 48, 64), (2, 16, 16, 128, 72, 1, 1, 128, 80),
+                                  (5, 40, 40, 128, 256, 3, 1, 128, 256), (1, 4, 4, 256, 128, 3, 1, 256, 128)])
+def test_wgrad_scalar_bookkeeping_form_is_bit_identical(case):
+    """Maps whose width is a multiple of 4 take the wgrad form with wave-uniform pixel bookkeeping (buffer-descriptor LDS-DMA);
+    it must add exactly the same products in the same order as the general per-lane form, for every split count."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout, k, s, ldx, lddy = case
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s, in_ld=ldx, out_ld=lddy)
+    x = nhwc(rnd((n, cin, h, w), 11), ldx)
+    gy = nhwc(rnd((n, cout, shape.ho, shape.wo), 12), lddy)
+    x[..., cin:] = 7.0      # pitch padding must never be read as data
+    gy[..., cout:] = 7.0
+    outs = []
+    try:
+        for general in (1, 0):
+            lib().mi355det_debug_set(1, general)
+            dw = torch.zeros(cout, k * k * cin, device=dev())
+            db = torch.zeros(cout, device=dev())
+            ops.conv_wgrad(shape, x, gy, dw, dbias=db)
+            outs.append((dw.cpu(), db.cpu()))
+    finally:
+        lib().mi355det_debug_set(1, 0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4)
+    wz = torch.zeros(cout, cin, k, k, requires_grad=True)
+    y = torch.nn.functional.conv2d(x[..., :cin].float().permute(0, 3, 1, 2).cpu(), wz, stride=s, padding=(k - 1) // 2)
+    y.backward(gy[..., :cout].float().permute(0, 3, 1, 2).cpu())
+    got = outs[1][0].view(cout, k, k, cin).permute(0, 3, 1, 2)
+    assert (got - wz.grad).abs().max().item() < 1e-2 * wz.grad.abs().max().item()

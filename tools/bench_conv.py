@@ -32,11 +32,18 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
     stats = torch.zeros(rows + 64, 2, ops.cout_pad_of(cout), device=dev)
     fl = 2.0 * n * shape.ho * shape.wo * cout * cin * k * k
     msg = f"{cin:4d}->{cout:4d} k{k} s{s} @{shape.ho:3d}: "
+    # same tuning the engine does at plan build: first launch of a shape under autotune mode times the tile candidates
+    import ctypes as C
+    lib().mi355det_conv_autotune_mode(1)
+    ops.conv_fwd(shape, x, wf, y, stats=stats); ops.conv_dgrad(shape, dy, wd, dx)
+    lib().mi355det_conv_autotune_mode(0)
+    ws = torch.empty(lib().mi355det_conv_wgrad_workspace(C.byref(shape)), device=dev, dtype=torch.uint8)
+    lib().mi355det_conv_wgrad_autotune(C.byref(shape), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), None)
     for t in tunes:
         lib().mi355det_debug_set(0, t)
         us = timeit(lambda: ops.conv_fwd(shape, x, wf, y, stats=stats))
         msg += f" fwd[t{t}] {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
     lib().mi355det_debug_set(0, 0)
     us = timeit(lambda: ops.conv_dgrad(shape, dy, wd, dx)); msg += f" dgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
-    us = timeit(lambda: ops.conv_wgrad(shape, x, dy, dw)); msg += f" wgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF"
+    us = timeit(lambda: ops.conv_wgrad(shape, x, dy, dw, workspace=ws)); msg += f" wgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF"
     print(msg, flush=True)
