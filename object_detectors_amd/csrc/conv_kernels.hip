@@ -83,8 +83,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) 
 // LDS-DMA through a buffer descriptor: per-lane 32-bit byte offset + SCALAR offset (the tap / k-step part of the
 // address costs no vector instruction); a lane whose voffset is out of range gets zeros written to LDS, which is
 // exactly the convolution's zero padding.
-__device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t rsrc, void* lds_dst_uniform, int voffset, int soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, voffset, soffset, 0, 0);
+// Issued as inline assembly ON PURPOSE: for the builtin the compiler's wait-count pass assumes every later ds_read may alias
+// the DMA's LDS destination and puts s_waitcnt vmcnt(0) in front of the next fragment read, which turns every counted wait of
+// the ring into a full drain (no load/compute overlap inside a workgroup, whatever the ring depth).  The kernels order DMA and
+// reads themselves (counted vmcnt + barrier), so the compiler must not know about the LDS side of these loads.
+typedef __attribute__((ext_vector_type(4))) int srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_records) {
+  const unsigned long long a = (unsigned long long)base;
+  srd_t r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xFFFFu);
+  r[2] = (int)num_records;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void bufld16(srd_t rsrc, const void* lds_dst_uniform, int voffset, int soffset) {
+  const unsigned lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)lds_dst_uniform;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
 }
 #define OOB_VOFF ((int)0x80000000)
 
@@ -425,10 +440,8 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   // ---- buffer descriptors (wave-uniform): activations relative to the first image this tile touches
   const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
   const int Ktot = p.T * p.Cin;
-  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+  const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
+  const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
 
   // ---- per-lane byte offsets of the rows this lane stages
   const int lrow = lane / CPR, cpos = lane % CPR;
@@ -650,9 +663,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
 
   const int n_first = (int)fdiv(fdiv((unsigned)max(m0 - R, 0), p.dMW), p.dMH);
   const int Ktot = 9 * p.Cin;
-  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+  const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
+  const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
 
   // scalar tap geometry: kernel row g uses taps 3g..3g+2 (same dy); dx of position i is the same for every row
   int dyg[3], dxi[3];
@@ -885,9 +897,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_il_
   }
   const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
   const int Ktot = p.T * p.Cin;
-  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+  const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
+  const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
   const int lrow = lane / CPR, cpos = lane % CPR;
   int a_voff[A_PER], b_voff[B_PER], b_instr[B_PER];
   unsigned a_valid[A_PER];
@@ -1057,10 +1068,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64, 2) void igemm_ws_kernel(const 
     // ================================ loader wave ================================
     const int lw = wid - NC;
     const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad), 0, 0x7FFFFFF0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long long)n0 * Ktot), 0, 0x7FFFFFF0, 0x00020000);
+    const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
+    const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
     const int lrow = lane / CPR, cpos = lane % CPR;
     int a_voff[A_PER], b_voff[B_PER];
     unsigned a_valid[A_PER];
@@ -1374,6 +1383,13 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 13: return launch_ws<2, 2, 8, 4, 64, 3, 4, EPI>(p, st);   // ws 256x128x64 ring 3, 4 loaders
     case 14: return launch_ws<2, 2, 4, 4, 32, 4, 2, EPI>(p, st);   // ws 128x128x32 ring 4 (64 KB, 2 WG/CU), 2 loaders
     case 6: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 0>(p, st); break;   // interleaved 256x256x64, 8 waves of 128x64
+    case 50: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 32, 3, EPI>(p, st); break;   // 256x256x32 ring 3 (96 KB)
+    case 51: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 32, 4, EPI>(p, st); break;   // 256x256x32 ring 4 (128 KB)
+    case 52: return launch_cfg<2, 2, 8, 4, 32, 3, EPI>(p, st);                                     // 256x128x32 ring 3 (72 KB, 2 workgroups/CU)
+    case 53: return launch_cfg<2, 2, 8, 4, 32, 4, EPI>(p, st);                                     // 256x128x32 ring 4 (96 KB)
+    case 54: return launch_cfg<2, 2, 4, 4, 32, 4, EPI>(p, st);                                     // 128x128x32 ring 4 (64 KB, 2 workgroups/CU)
+    case 55: return launch_cfg<2, 2, 4, 4, 64, 3, EPI>(p, st);                                     // 128x128x64 ring 3 (96 KB, 1 workgroup/CU)
+    case 56: return launch_cfg<2, 2, 4, 4, 32, 6, EPI>(p, st);                                     // 128x128x32 ring 6 (96 KB)
     case 15: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI>(p, st); break;             // 3x3 s1: shared pixel tiles (dx reuse), 128x128
     case 16: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI>(p, st); break;             // dx reuse 256x128, 8 waves, 1 workgroup/CU
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves

@@ -64,9 +64,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_uniform) 
 }
 
 // LDS-DMA through a buffer descriptor (per-lane 32-bit byte offset + SCALAR offset); a lane whose offset is out of range
-// gets zeros written to LDS
-__device__ __forceinline__ void bufld16(__amdgpu_buffer_rsrc_t rsrc, void* lds_dst_uniform, int voffset, int soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, voffset, soffset, 0, 0);
+// gets zeros written to LDS.  Issued as inline assembly ON PURPOSE: for the builtin the compiler's wait-count pass assumes every
+// later ds_read may alias the DMA's LDS destination and puts s_waitcnt vmcnt(0) in front of the next fragment read, which
+// serialises the prefetch of stage s+1 with the reads of stage s (no load/compute overlap inside a workgroup).  The kernels
+// order DMA and reads themselves (counted vmcnt + barrier), so the compiler must not know.
+typedef __attribute__((ext_vector_type(4))) int srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base, unsigned num_records) {
+  const unsigned long long a = (unsigned long long)base;
+  srd_t r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xFFFFu);
+  r[2] = (int)num_records;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void bufld16(srd_t rsrc, const void* lds_dst_uniform, int voffset, int soffset) {
+  const unsigned lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)lds_dst_uniform;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
 }
 #define OOB_VOFF ((int)0x80000000)
 
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   // GRP4 state: per LDS-DMA piece (4 pixels of one image row) the scalar (n, ho, wo) of its first pixel; per lane and swizzle
   // phase the constant parts of the X offset and of the bounds tests
   int g_n[4], g_ho[4], g_wo[4], dyv[4], lc[2], ty[2], cx[2];
-  __amdgpu_buffer_rsrc_t rsrc_x;
+  srd_t rsrc_x;
   if constexpr (GRP4) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -162,14 +176,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       ty[ph] = x_ok[ph] ? x_tapdy[ph] : -(1 << 24);
       cx[ph] = lrow * p.stride + x_tapdx[ph];
     }
-    rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (p.pad * p.W + p.pad) * p.ldx), 0, 0x7FFFFFF0, 0x00020000);
+    rsrc_x = make_srd(p.x - (p.pad * p.W + p.pad) * p.ldx, 0x7FFFFFF0u);
   }
   auto stage_grp4 = [&](int m_base, int buf) {
     char* sd = smem + buf * STAGE;
     char* sx = sd + WG_BKP * WG_ROWB;
     const int rem = mB - m_base;   // rows past it read zeros through the descriptor's range check
-    const __amdgpu_buffer_rsrc_t rsrc_dy =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (long long)m_base * p.lddy), 0, rem * p.lddy * 2, 0x00020000);
+    const srd_t rsrc_dy = make_srd(p.dy + (long long)m_base * p.lddy, (unsigned)(rem * p.lddy * 2));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int instr = wid * 4 + i;
