@@ -5,10 +5,13 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from object_detectors_amd import ops
 from object_detectors_amd._lib import lib
 dev = torch.device('cuda:0')
-SHAPES = [  # n, h, w, cin, cout, k, s
-    (32, 80, 80, 128, 256, 3, 1), (32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1),
-    (32, 80, 80, 256, 128, 1, 1), (32, 40, 40, 512, 256, 1, 1), (32, 20, 20, 1024, 512, 1, 1),
-    (32, 160, 160, 64, 128, 3, 1), (32, 160, 160, 128, 256, 3, 2), (32, 320, 320, 32, 64, 3, 1),
+SHAPES = [  # n, h, w, cin, cout, k, s, launches per YOLOv3 step
+    (32, 80, 80, 128, 256, 3, 1, 11), (32, 40, 40, 256, 512, 3, 1, 11), (32, 20, 20, 512, 1024, 3, 1, 7),
+    (32, 40, 40, 512, 256, 1, 1, 10), (32, 80, 80, 256, 128, 1, 1, 10), (32, 640, 640, 32, 64, 3, 2, 1),
+    (32, 160, 160, 64, 128, 3, 1, 2), (32, 320, 320, 32, 64, 3, 1, 1), (32, 20, 20, 1024, 512, 1, 1, 7),
+    (32, 320, 320, 64, 128, 3, 2, 1), (32, 160, 160, 128, 256, 3, 2, 1), (32, 160, 160, 128, 64, 1, 1, 2),
+    (32, 320, 320, 64, 32, 1, 1, 1), (32, 40, 40, 512, 1024, 3, 2, 1), (32, 80, 80, 256, 512, 3, 2, 1),
+    (32, 80, 80, 384, 128, 1, 1, 1), (32, 40, 40, 768, 256, 1, 1, 1), (32, 40, 40, 256, 128, 1, 1, 1), (32, 20, 20, 512, 256, 1, 1, 1),
 ]
 tunes = [int(v) for v in sys.argv[1:]] or [0]
 which = 'fdw'
@@ -19,7 +22,8 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for (n, h, w, cin, cout, k, s) in SHAPES:
+tot = [0.0, 0.0, 0.0]
+for (n, h, w, cin, cout, k, s, cnt) in SHAPES:
     shape = ops.conv_shape(n, h, w, cin, cout, k, s)
     x = (torch.randn(n, h, w, cin, device=dev)).bfloat16()
     wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
@@ -43,7 +47,9 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
         lib().mi355det_debug_set(0, t)
         us = timeit(lambda: ops.conv_fwd(shape, x, wf, y, stats=stats))
         msg += f" fwd[t{t}] {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
+        if t == tunes[0]: tot[0] += cnt * us
     lib().mi355det_debug_set(0, 0)
-    us = timeit(lambda: ops.conv_dgrad(shape, dy, wd, dx)); msg += f" dgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
-    us = timeit(lambda: ops.conv_wgrad(shape, x, dy, dw, workspace=ws)); msg += f" wgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF"
-    print(msg, flush=True)
+    us = timeit(lambda: ops.conv_dgrad(shape, dy, wd, dx)); tot[1] += cnt * us; msg += f" dgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
+    us = timeit(lambda: ops.conv_wgrad(shape, x, dy, dw, workspace=ws)); tot[2] += cnt * us; msg += f" wgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF"
+    print(f"x{cnt:2d} " + msg, flush=True)
+print(f"sum over the step's launches (ms): fwd {tot[0] / 1e3:.2f}  dgrad {tot[1] / 1e3:.2f}  wgrad {tot[2] / 1e3:.2f}")
