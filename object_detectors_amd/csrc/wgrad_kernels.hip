@@ -94,11 +94,11 @@ __device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
 // CI x CJ = 16-wide fragments per wave along cout / n': 4 x 4 is the full 128x128 tile; layers whose Cout or k*k*Cin is 32 / 64 (the
 // first Darknet layers) use 1 or 2 so that the four waves split the REAL channels instead of multiplying zero fragments
 // (50-94 % of the MFMA issue with the full tile).  Staging and the slab layout are unchanged.
-// GRP4: Wo % 4 == 0 (every feature map of a 32-divisible image), so the four pixels of one LDS-DMA piece lie in one image row:
-// their (n, ho, wo) bookkeeping is wave-uniform (SALU), the dY offsets are loop constants and the X offsets are a lane constant plus a
-// scalar; the per-step vector work drops from ~146 to ~25 VALU instructions (the general form spends more issue cycles on
-// addresses than on the 32 MFMAs of a step).
-template <int CI, int CJ, bool GRP4>
+// GRP4: the (n, ho, wo) bookkeeping is kept per LDS-DMA piece (4 consecutive pixels) in SCALAR registers; when the piece lies in one
+// image row (always, for map widths that are multiples of 4) the dY offsets are loop constants and the X offsets a lane constant
+// plus a scalar: the per-step vector work drops from ~146 to ~25 VALU instructions (the general form spends more issue cycles on
+// addresses than on the 32 MFMAs of a step).  A piece that straddles a row end adds a per-lane select of the next row's scalars.
+template <int CI, int CJ, int GRP4>   // 0: per-lane bookkeeping, 1: scalar, pieces never straddle (Wo % 4 == 0), 2: scalar with straddling pieces
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int STAGE = 2 * WG_BKP * WG_ROWB;   // dy tile + x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,8 +190,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       bufld16(rsrc_dy, sd + instr * 1024, dyv[i], 0);
       const int hs = g_ho[i] * p.stride, ws = g_wo[i] * p.stride;
       const int sb = ((g_n[i] * p.H + hs) * p.W + ws) * p.ldx * 2;
-      const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
-      bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, sb);
+      if (GRP4 == 1 || (g_wo[i] + 4 <= p.Wo && instr * 4 + 4 <= rem)) {   // wave-uniform: the piece's four pixels lie in one image row
+        const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
+        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, sb);
+      } else {
+        // the piece straddles a row end (map widths that are not multiples of 4) or the end of the pixel range: lanes past the
+        // row end move to the next row / image by a scalar byte delta
+        const bool last_row = g_ho[i] + 1 == p.Ho;
+        const int hs1 = last_row ? 0 : hs + p.stride;
+        const int ex1 = ((last_row ? (p.H - (p.Ho - 1) * p.stride) * p.W : p.stride * p.W) - p.Wo * p.stride) * p.ldx * 2;
+        const bool wr = g_wo[i] + lrow >= p.Wo;
+        const int iy = (wr ? hs1 : hs) + ty[ph];
+        const int ix = ws + cx[ph] - (wr ? p.Wo * p.stride : 0);
+        const bool ok = instr * 4 + lrow < rem && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] + (wr ? ex1 : 0) : OOB_VOFF, sb);
+      }
       g_wo[i] += p.step_r;
       g_ho[i] += p.step_q;
       if (g_wo[i] >= p.Wo) {
@@ -563,11 +576,12 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, S(stream), p);
   };
-  // scalar pixel bookkeeping needs 4-pixel groups inside one image row and 31-bit byte offsets into x
-  const bool grp4 = g_wgrad_general == 0 && p.Wo % 4 == 0 &&
+  // scalar pixel bookkeeping: a 4-pixel piece may span at most two image rows, byte offsets into x must fit 31 bits
+  const int grp4 = g_wgrad_general != 0 || p.Wo < 4 ? 0 : (p.Wo % 4 == 0 ? 1 : 2);
+  const bool fits =
                     ((long long)s->n * p.H * p.W + (long long)p.pad * (p.W + 1)) * p.ldx * 2 < 0x7FFFFFF0ll &&
                     (long long)chunk * p.lddy * 2 < 0x7FFFFFF0ll;
-#define WG_GO(a, b) (grp4 ? go(wgrad_kernel<a, b, true>) : go(wgrad_kernel<a, b, false>))
+#define WG_GO(a, b) (!fits || grp4 == 0 ? go(wgrad_kernel<a, b, 0>) : grp4 == 1 ? go(wgrad_kernel<a, b, 1>) : go(wgrad_kernel<a, b, 2>))
   switch (ci * 8 + cj) {
     case 1 * 8 + 1: WG_GO(1, 1); break;
     case 1 * 8 + 2: WG_GO(1, 2); break;
