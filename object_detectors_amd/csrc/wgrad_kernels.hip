@@ -153,19 +153,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     r_n[i] = (int)n;
   }
 
-  // GRP4 state: per LDS-DMA piece (4 pixels of one image row) the scalar (n, ho, wo) of its first pixel; per lane and swizzle
-  // phase the constant parts of the X offset and of the bounds tests
-  int g_n[4], g_ho[4], g_wo[4], dyv[4], lc[2], ty[2], cx[2];
+  // GRP4 state: per LDS-DMA piece (4 consecutive pixels) the SCALED scalar coordinates of its first pixel (hs = ho*stride,
+  // ws = wo*stride) and the byte offset sb of that input pixel, all advanced by constants (no multiply in the loop); per lane and
+  // swizzle phase the constant parts of the X offset and of the bounds tests
+  int g_hs[4], g_ws[4], g_sb[4], dyv[4], lc[2], ty[2], cx[2];
   srd_t rsrc_x;
-  if constexpr (GRP4) {
+  const int WoS = p.Wo * p.stride, HoS = p.Ho * p.stride;
+  const int c_ws = p.step_r * p.stride, c_hs = p.step_q * p.stride;
+  const int c_sb = (c_hs * p.W + c_ws) * p.ldx * 2;                 // 64 pixels ahead without wrapping
+  const int c_row = (p.stride * p.W - WoS) * p.ldx * 2;             // extra bytes when wo wraps into the next output row
+  const int c_img = (p.H - HoS) * p.W * p.ldx * 2;                  // extra bytes when ho wraps into the next image
+  if constexpr (GRP4 != 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned um = (unsigned)(mA + (wid * 4 + i) * 4);
       const unsigned q1 = fdiv(um, p.dWo);
-      g_wo[i] = (int)(um - q1 * p.Wo);
+      const int wo = (int)(um - q1 * p.Wo);
       const unsigned n = fdiv(q1, p.dHo);
-      g_ho[i] = (int)(q1 - n * p.Ho);
-      g_n[i] = (int)n;
+      const int ho = (int)(q1 - n * p.Ho);
+      g_hs[i] = ho * p.stride;
+      g_ws[i] = wo * p.stride;
+      g_sb[i] = (((int)n * p.H + g_hs[i]) * p.W + g_ws[i]) * p.ldx * 2;
       const int ph = (i >> 1) & 1;
       dyv[i] = (ph ? dy_ok1 : dy_ok0) ? (((wid * 4 + i) * 4 + lrow) * p.lddy + dy_off[ph]) * 2 : OOB_VOFF;
     }
@@ -188,32 +196,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       const int instr = wid * 4 + i;
       const int ph = (i >> 1) & 1;
       bufld16(rsrc_dy, sd + instr * 1024, dyv[i], 0);
-      const int hs = g_ho[i] * p.stride, ws = g_wo[i] * p.stride;
-      const int sb = ((g_n[i] * p.H + hs) * p.W + ws) * p.ldx * 2;
-      if (GRP4 == 1 || (g_wo[i] + 4 <= p.Wo && instr * 4 + 4 <= rem)) {   // wave-uniform: the piece's four pixels lie in one image row
+      const int hs = g_hs[i], ws = g_ws[i];
+      if (GRP4 == 1 || (ws + 4 * p.stride <= WoS && instr * 4 + 4 <= rem)) {   // wave-uniform: the piece's four pixels lie in one image row
         const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
-        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, sb);
+        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[i]);
       } else {
         // the piece straddles a row end (map widths that are not multiples of 4) or the end of the pixel range: lanes past the
         // row end move to the next row / image by a scalar byte delta
-        const bool last_row = g_ho[i] + 1 == p.Ho;
+        const bool last_row = hs + p.stride == HoS;
         const int hs1 = last_row ? 0 : hs + p.stride;
-        const int ex1 = ((last_row ? (p.H - (p.Ho - 1) * p.stride) * p.W : p.stride * p.W) - p.Wo * p.stride) * p.ldx * 2;
-        const bool wr = g_wo[i] + lrow >= p.Wo;
+        const int ex1 = c_row + (last_row ? c_img : 0);
+        const bool wr = ws + lrow * p.stride >= WoS;
         const int iy = (wr ? hs1 : hs) + ty[ph];
-        const int ix = ws + cx[ph] - (wr ? p.Wo * p.stride : 0);
+        const int ix = ws + cx[ph] - (wr ? WoS : 0);
         const bool ok = instr * 4 + lrow < rem && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] + (wr ? ex1 : 0) : OOB_VOFF, sb);
+        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] + (wr ? ex1 : 0) : OOB_VOFF, g_sb[i]);
       }
-      g_wo[i] += p.step_r;
-      g_ho[i] += p.step_q;
-      if (g_wo[i] >= p.Wo) {
-        g_wo[i] -= p.Wo;
-        g_ho[i] += 1;
+      g_ws[i] += c_ws;
+      g_hs[i] += c_hs;
+      g_sb[i] += c_sb;
+      if (g_ws[i] >= WoS) {
+        g_ws[i] -= WoS;
+        g_hs[i] += p.stride;
+        g_sb[i] += c_row;
       }
-      while (g_ho[i] >= p.Ho) {
-        g_ho[i] -= p.Ho;
-        g_n[i] += 1;
+      if (g_hs[i] >= HoS) {   // a single wrap: the host only picks this form when 64 pixels span at most Ho - 1 rows
+        g_hs[i] -= HoS;
+        g_sb[i] += c_img;
       }
     }
   };
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   };
 
   auto stage = [&](int m_base, int buf) {
-    if constexpr (GRP4)
+    if constexpr (GRP4 != 0)
       stage_grp4(m_base, buf);
     else
       stage_any(m_base, buf);
@@ -577,7 +586,7 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, S(stream), p);
   };
   // scalar pixel bookkeeping: a 4-pixel piece may span at most two image rows, byte offsets into x must fit 31 bits
-  const int grp4 = g_wgrad_general != 0 || p.Wo < 4 ? 0 : (p.Wo % 4 == 0 ? 1 : 2);
+  const int grp4 = g_wgrad_general != 0 || p.Wo < 4 || WG_BKP / p.Wo + 1 > p.Ho ? 0 : (p.Wo % 4 == 0 ? 1 : 2);
   const bool fits =
                     ((long long)s->n * p.H * p.W + (long long)p.pad * (p.W + 1)) * p.ldx * 2 < 0x7FFFFFF0ll &&
                     (long long)chunk * p.lddy * 2 < 0x7FFFFFF0ll;
