@@ -170,11 +170,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 // (256/(c/8)) pixel lanes; partial sums combined in LDS, then one atomic per channel per block.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ g1, int g1_ld, const bf16_t* __restrict__ g2, int g2_ld,
                                                             const bf16_t* __restrict__ z, int z_ld, const float* __restrict__ ss, int c,
-                                                            long long pixels, float slope, float* __restrict__ sums, int pix_per_block) {
+                                                            long long pixels, float slope, float* __restrict__ sums, int pix_per_block, int groups) {
   __shared__ float red[256][17];
-  const int groups = c >> 3;                 // power of two <= 256 (checked on the host)
+  // groups = 8-channel groups per workgroup (power of two <= 256); blockIdx.y picks the channel slab when c/8 > groups
   const int gl = threadIdx.x % groups, pl = threadIdx.x / groups, npl = 256 / groups;
-  const int c0 = gl << 3;
+  const int cbase = blockIdx.y * groups * 8;
+  const int c0 = cbase + (gl << 3);
   float sc[8], sh[8], mu[8], is[8], a1[8], a2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -220,13 +221,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     red[threadIdx.x][8 + k] = a2[k];
   }
   __syncthreads();
-  // thread t < 2*c handles (which = t / c, channel = t % c)
-  for (int t = threadIdx.x; t < 2 * c; t += 256) {
-    const int which = t / c, ch = t - which * c;
+  // thread t < 2*cb handles (which = t / cb, channel = t % cb) of this workgroup's cb = groups*8 channels
+  const int cb = groups * 8;
+  for (int t = threadIdx.x; t < 2 * cb; t += 256) {
+    const int which = t / cb, ch = t - which * cb;
     const int gi = ch >> 3, k = ch & 7;
     float s = 0.f;
     for (int p2 = 0; p2 < npl; ++p2) s += red[p2 * groups + gi][which * 8 + k];
-    atomicAdd(sums + which * c + ch, s);
+    atomicAdd(sums + which * c + cbase + ch, s);
   }
 }
 
@@ -588,15 +590,20 @@ int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, in
   const int groups = c / 8;
   if (c <= 0 || c % 8 != 0 || groups > 256 || (groups & (groups - 1)) != 0)
     return fail(MI355DET_EINVAL, "%s: channels/8 must be a power of two <= 256 (got c=%lld)", "bn_act_bwd_reduce", c);
-  const int npl = 256 / groups;
+  // a workgroup covers at most 64-128 channels (whole 128-byte lines per pixel) and more pixels instead: every workgroup ends with
+  // 2 * (its channels) float atomics, ~24 G atomics/s device-wide measured (410 k of them are 17 us), so wide layers are cut into
+  // channel slabs (blockIdx.y) and large tensors get no more than ~2 workgroups per CU
+  const int gb = groups >= 32 ? 16 : (groups > 8 ? 8 : groups), slabs = groups / gb;
+  const int npl = 256 / gb;
   long long ppb = (long long)npl * 32;   // 32 pixels per pixel-lane
   long long blocks = (pixels + ppb - 1) / ppb;
-  if (blocks > 8192) {
-    ppb = (pixels + 8191) / 8192;
+  const long long cap = 512 / slabs > 64 ? 512 / slabs : 64;
+  if (blocks > cap) {
+    ppb = ((pixels + cap - 1) / cap + npl * 4 - 1) / (npl * 4) * (npl * 4);
     blocks = (pixels + ppb - 1) / ppb;
   }
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2, g2_ld,
-                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)ppb);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks, slabs), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2, g2_ld,
+                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)ppb, gb);
   return check_launch("bn_act_bwd_reduce");
 }
 
