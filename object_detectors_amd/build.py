@@ -25,6 +25,7 @@ SOURCES = [
     ("resnet_kernels.hip", []),
     ("conv_kernels.hip", []),
     ("wgrad_kernels.hip", []),
+    ("dgrad_s2_kernels.hip", []),
     ("elem_kernels.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-x", "hip"]

@@ -73,6 +73,9 @@ enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4, EPI_
 #define EPI_LDS_BYTES(nwaves) (EPI_LDS_OFF + (nwaves) * (64 * (8 * 16 * 2 + 16) + 256))   // upper bound (TN <= 8)
 
 extern int g_wgrad_general;   // wgrad_kernels.hip
+extern int g_dgrad_s2_off;     // dgrad_s2_kernels.hip
+int mi355det_internal_dgrad_s2(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                               void* stream);
 
 namespace {
 
@@ -471,8 +474,9 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
       voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ swz<BK>(row)) * 8) * 2;
 #pragma unroll
       for (int t = 0; t < MAX_TAPS; ++t) {   // tap table unpacked from two scalar registers (no memory access)
+        if (t >= p.T) break;                 // uniform: the 1-, 2- and 4-tap classes of a stride-2 data gradient stop early
         const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
-        const bool ok = t < p.T && (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
+        const bool ok = (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
         vm |= ok ? (1u << t) : 0u;
       }
     }
@@ -1581,6 +1585,7 @@ extern "C" {
 int mi355det_debug_set(int key, int value) {
   if (key == 0) g_tune = value;
   if (key == 1) g_wgrad_general = value;
+  if (key == 2) g_dgrad_s2_off = value;
   return 0;
 }
 
@@ -1867,6 +1872,11 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
   if (int e = check_shape(s, "conv_dgrad")) return e;
   if (int e = ensure_zero_page()) return e;
   if (s->cout % 32 != 0) return fail(MI355DET_EINVAL, "%s: Cout (the dgrad reduction dim) must be a multiple of 32 (got %lld)", "conv_dgrad", s->cout);
+  if (!partials && !g_autotune_mode) {
+    // few-channel 3x3 stride-2 layers: all four parity classes in one launch over shared dy tiles (dgrad_s2_kernels.hip)
+    const int r = mi355det_internal_dgrad_s2(s, dy, wt, dx, residual, residual_ld, stream);
+    if (r != 0) return r < 0 ? r : 0;
+  }
   const int cin_pad = (s->cin + 31) / 32 * 32;
   const bf16_t* wp = (const bf16_t*)wt;
   const int classes = s->stride == 1 ? 1 : 4;

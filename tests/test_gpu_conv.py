@@ -425,3 +425,38 @@ def test_wgrad_scalar_bookkeeping_form_is_bit_identical(case):
     y.backward(gy[..., :cout].float().permute(0, 3, 1, 2).cpu())
     got = outs[1][0].view(cout, k, k, cin).permute(0, 3, 1, 2)
     assert (got - wz.grad).abs().max().item() < 1e-2 * wz.grad.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [(2, 8, 128, 32, 64, 32, 64, False), (1, 6, 64, 32, 64, 40, 64, True), (2, 4, 64, 64, 64, 64, 64, True),
+                                  (1, 10, 256, 64, 64, 64, 72, False), (3, 4, 128, 32, 64, 32, 80, True), (2, 4, 64, 64, 128, 64, 128, True)])
+def test_stride2_dgrad_single_launch_matches_class_launches(case):
+    """3x3 stride-2 data gradient of the few-channel layers: the one-launch kernel over shared dy tiles (dgrad_s2_kernels.hip) against
+    the four parity-class launches (same products, different summation order) and against autograd."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout, ldx, lddy, with_res = case
+    shape = ops.conv_shape(n, h, w, cin, cout, 3, 2, in_ld=ldx, out_ld=lddy)
+    wt = rnd((cout, cin, 3, 3), 21, (2.0 / (cin * 9)) ** 0.5)
+    gy = rnd((n, cout, h // 2, w // 2), 22)
+    res = rnd((n, cin, h, w), 23) if with_res else None
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    gyd = nhwc(gy, lddy)
+    gyd[..., cout:] = 5.0
+    res_d = nhwc(res, ldx) if with_res else None
+    outs = []
+    try:
+        for off in (1, 0):
+            lib().mi355det_debug_set(2, off)
+            dx = torch.full((n, h, w, ldx), 3.0, dtype=torch.bfloat16, device=dev())
+            ops.conv_dgrad(shape, gyd, wd, dx, residual=res_d, residual_ld=ldx if with_res else 0)
+            outs.append(dx.float().cpu())
+    finally:
+        lib().mi355det_debug_set(2, 0)
+    assert torch.equal(outs[0][..., cin:], outs[1][..., cin:])          # pitch padding untouched by both
+    xr = torch.zeros(n, cin, h, w, requires_grad=True)
+    F.conv2d(xr, wt.bfloat16().float(), stride=2, padding=1).backward(gy.bfloat16().float())
+    ref = xr.grad + (res.bfloat16().float() if with_res else 0)
+    tol = 2e-2 * ref.abs().max().item()
+    for o in outs:
+        assert (o[..., :cin].permute(0, 3, 1, 2) - ref).abs().max().item() < tol
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-2 * ref.abs().max().item()
