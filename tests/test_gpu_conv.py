@@ -460,3 +460,32 @@ def test_stride2_dgrad_single_launch_matches_class_launches(case):
     for o in outs:
         assert (o[..., :cin].permute(0, 3, 1, 2) - ref).abs().max().item() < tol
     assert (outs[0] - outs[1]).abs().max().item() < 1e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("rows,c,c_pad", [(1600, 256, 256), (300, 96, 128), (257, 32, 32), (5000, 1024, 1024)])
+def test_bn_finalize_many_rows_single_launch(rows, c, c_pad):
+    """rows > 256: both reduction stages run in one launch (last workgroup of a channel slab finishes).  Repeated launches on fresh
+    data give fresh results (the arrival counters are left clean) and match a float64 reduction of the same partial rows."""
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    d = dev()
+    count = rows * 128
+    gamma = (rnd((c,), 31, 0.3) + 1.0).to(d)
+    beta = rnd((c,), 32, 0.2).to(d)
+    for rep in range(3):
+        part = torch.zeros(rows + 64, 2, c_pad)
+        part[:rows, 0, :c] = rnd((rows, c), 40 + rep, 30.0) + 5.0
+        part[:rows, 1, :c] = rnd((rows, c), 50 + rep, 20.0).abs() * 40 + 900.0
+        pd = part.to(d)
+        ss = torch.zeros(4 * c, device=d)
+        rm, rv = torch.zeros(c, device=d), torch.ones(c, device=d)
+        check(lib().mi355det_bn_finalize(ptr(pd), rows, c, c_pad, count, ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(rm), ptr(rv), ptr(ss), stream_ptr()))
+        s1 = part[:rows, 0, :c].double().sum(0)
+        s2 = part[:rows, 1, :c].double().sum(0)
+        mean = s1 / count
+        var = (s2 / count - mean * mean).clamp_min(0)
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        got = ss.cpu().double()
+        np.testing.assert_allclose(got[2 * c:3 * c], mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got[3 * c:], invstd, rtol=1e-4)
+        np.testing.assert_allclose(got[:c], gamma.cpu().double() * invstd, rtol=1e-4)
+        np.testing.assert_allclose(rm.cpu().double(), 0.1 * mean, rtol=1e-4, atol=1e-6)
