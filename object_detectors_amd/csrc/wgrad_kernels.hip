@@ -385,6 +385,50 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// Same reduction with the splits spread over 8 lanes of the workgroup (32 float4 columns x 8 split lanes, LDS tree at the end):
+// the column-per-thread form above walks the splits serially, 8 loads at a time, and is latency-bound (18 us average, 1.4 ms per
+// step); here every thread has ceil(splits / 8) independent loads.  Fixed association order: deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce8_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int NP, int co_tiles,
+                                                            int np_tiles, int splits) {
+  __shared__ float4 red[8][32];
+  const int tiles = co_tiles * np_tiles;
+  const long long total = (long long)Cout * (NP / 4);
+  const size_t sstride = (size_t)tiles * (WG_TILE * WG_TILE);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (long long i0 = (long long)blockIdx.x * 32; i0 < total; i0 += (long long)gridDim.x * 32) {
+    const long long i = i0 + tx;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* d = nullptr;
+    if (i < total) {
+      const int co = (int)(i / (NP / 4)), np = (int)(i - (long long)co * (NP / 4)) * 4;
+      const int ct = co / WG_TILE, nt = np / WG_TILE;
+      const int tile = nt * co_tiles + ct;
+      const float* src = slab + (size_t)tile * (WG_TILE * WG_TILE) + (co - ct * WG_TILE) * WG_TILE + (np - nt * WG_TILE);
+      d = dw + (long long)co * NP + np;
+      for (int s0 = ty; s0 < splits; s0 += 32) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = s0 + 8 * u < splits ? *(const float4*)(src + (size_t)(s0 + 8 * u) * sstride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+        }
+      }
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+      float4 o = *(const float4*)d;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        o.x += red[r][tx].x; o.y += red[r][tx].y; o.z += red[r][tx].z; o.w += red[r][tx].w;
+      }
+      *(float4*)d = o;
+    }
+    __syncthreads();
+  }
+}
+
 // per-channel sum over pixels of a bf16 NHWC tensor (bias gradient of the head convs)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ld, int c, long long pixels, float* __restrict__ out) {
   const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -605,9 +649,13 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
 #undef WG_GO
   if (p.slab) {
     const long long total = (long long)p.Cout * (p.NP / 4);
-    const int gx = (int)min((long long)2048, (total + 255) / 256);
-    const int gy = splits > 8 && gx < 512 ? min((splits + 7) / 8, max(1, 1024 / gx)) : 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, gy), dim3(256), 0, S(stream), p.slab, dw, p.Cout, p.NP, p.co_tiles, p.np_tiles, splits);
+    if (splits >= 8) {
+      const int gx = (int)min((long long)4096, (total + 31) / 32);
+      hipLaunchKernelGGL(wgrad_reduce8_kernel, dim3(gx), dim3(256), 0, S(stream), p.slab, dw, p.Cout, p.NP, p.co_tiles, p.np_tiles, splits);
+    } else {
+      const int gx = (int)min((long long)2048, (total + 255) / 256);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gx, 1), dim3(256), 0, S(stream), p.slab, dw, p.Cout, p.NP, p.co_tiles, p.np_tiles, splits);
+    }
   }
   if (dbias && s->out_ld % 8 == 0 && (s->cout + 7) / 8 <= 256 && ((s->cout + 7) / 8) * 8 <= s->out_ld && (((uintptr_t)dy) & 15) == 0) {
     const int groups = (s->cout + 7) / 8, npl = 256 / groups;
