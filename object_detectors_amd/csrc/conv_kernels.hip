@@ -1029,158 +1029,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_il_
   igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
 }
 
-// Warp-specialised variant: LW dedicated LOADER waves drive the LDS-DMA ring while the WM x WN CONSUMER waves only
-// read fragments and issue MFMAs.  Measured on the unified kernel above: a wave spends ~740 cycles per k-step issuing
-// its 8 LDS-DMA pieces (the CU's texture-address path is saturated meanwhile) and ~930 cycles in ds_read+MFMA, one
-// after the other, so the matrix pipe idles half the time; with separate roles the two phases overlap.
-template <int WM, int WN, int TM, int TN, int BK, int NST, int LW, int EPI>
-__global__ __launch_bounds__((WM * WN + LW) * 64, 2) void igemm_ws_kernel(const IgemmParams p) {
-  constexpr int NC = WM * WN;                 // consumer waves
-  constexpr int NT = (NC + LW) * 64;
-  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int ROWB = BK * 2, R = 1024 / ROWB, CPR = BK / 8;
-  constexpr int A_INSTR = BM / R, B_INSTR = BN / R;
-  constexpr int A_PER = A_INSTR / LW, B_PER = B_INSTR / LW;      // pieces per loader wave per stage
-  constexpr int PER = A_PER + B_PER;
-  constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int D = NST - 1;
-  static_assert(A_INSTR % LW == 0 && B_INSTR % LW == 0, "pieces must split evenly over the loader waves");
-  static_assert((D - 1) * PER <= 63, "vmcnt is a 6-bit counter");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_toff = (int*)(smem + NST * STAGE);
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool consumer = wid < NC;
-  const int wm = consumer ? wid % WM : 0, wn = consumer ? wid / WM : 0;
-
-  const int ntn = p.CoutPad / BN;
-  const int nblk = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int mt = bid / ntn, nt = bid - mt * ntn;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int Ktot = p.T * p.Cin;
-  const int ksteps = Ktot / BK;
-
-  if (tid == 0) {
-#pragma unroll
-    for (int t = 0; t < MAX_TAPS; ++t)
-      if (t < p.T) s_toff[t] = ((p.dy[t] * p.Win + p.dx[t]) * p.ldin + p.tap_pad) * 2;
-  }
-
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
-
-  if (!consumer) {
-    // ================================ loader wave ================================
-    const int lw = wid - NC;
-    const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
-    const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
-    const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
-    const int lrow = lane / CPR, cpos = lane % CPR;
-    int a_voff[A_PER], b_voff[B_PER];
-    unsigned a_valid[A_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int row = (lw * A_PER + i) * R + lrow;
-      const int m = m0 + row;
-      unsigned vm = 0;
-      int voff = OOB_VOFF;
-      if (m < p.M) {
-        const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
-        const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
-        const int iy0 = yy * p.sin, ix0 = xx * p.sin;
-        voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ swz<BK>(row)) * 8) * 2;
-#pragma unroll
-        for (int t = 0; t < MAX_TAPS; ++t) {
-          const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
-          const bool ok = t < p.T && (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
-          vm |= ok ? (1u << t) : 0u;
-        }
-      }
-      a_voff[i] = voff;
-      a_valid[i] = vm;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int row = (lw * B_PER + i) * R + lrow;
-      b_voff[i] = (row * Ktot + (cpos ^ swz<BK>(row)) * 8) * 2;
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();             // s_toff visible
-    const int cin_steps = p.Cin / BK;
-    int pf_t = 0, pf_c = 0;
-    auto stage = [&](int s, int buf) {
-      const int soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
-      char* sa = smem + buf * STAGE;
-      char* sb = sa + BM * ROWB;
-#pragma unroll
-      for (int i = 0; i < A_PER; ++i)
-        bufld16(rsrc_x, sa + (lw * A_PER + i) * 1024, ((a_valid[i] >> pf_t) & 1u) ? a_voff[i] : OOB_VOFF, soff);
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) bufld16(rsrc_w, sb + (lw * B_PER + i) * 1024, b_voff[i], s * (BK * 2));
-      if (++pf_c == cin_steps) {
-        pf_c = 0;
-        ++pf_t;
-      }
-    };
-#pragma unroll
-    for (int s = 0; s < D; ++s)
-      if (s < ksteps) stage(s, s);
-    int buf = 0;
-    for (int s = 0; s < ksteps; ++s) {
-      const int younger = min(D - 1, ksteps - 1 - s);
-      if (younger >= D - 1) wait_vmcnt<(D - 1 > 0 ? D - 1 : 0) * PER>();
-      else if (D >= 3 && younger == D - 2) wait_vmcnt<(D - 2 > 0 ? D - 2 : 0) * PER>();
-      else if (D >= 4 && younger == D - 3) wait_vmcnt<(D - 3 > 0 ? D - 3 : 0) * PER>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();           // stage s published; consumers have left buffer (s-1)%NST
-      if (s + D < ksteps) stage(s + D, buf == 0 ? NST - 1 : buf - 1);
-      buf = buf + 1 == NST ? 0 : buf + 1;
-    }
-  } else {
-    // ================================ consumer waves ================================
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    const int fr = lane & 15, fq = lane >> 4;
-    int buf = 0;
-    for (int s = 0; s < ksteps; ++s) {
-      __builtin_amdgcn_s_barrier();
-      const char* sa = smem + buf * STAGE;
-      const char* sb = sa + BM * ROWB;
-#pragma unroll
-      for (int ks = 0; ks < BK / 32; ++ks) {
-        bf16x8_t wf[TN], af[TM];
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-          const int row = wn * (TN * 16) + i * 16 + fr;
-          wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const int row = wm * (TM * 16) + j * 16 + fr;
-          af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-      }
-      buf = buf + 1 == NST ? 0 : buf + 1;
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
-  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, consumer, wm, wn, lane, mt, n0, m0);
-}
-
 // ------------------------------------------------------------------------------------------
 // weight packing: fp32 master [cout][cin][k][k] -> bf16 [cout_pad][tap][cin]  (K contiguous)
 __global__ void pack_fwd_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cout_pad, int cin, int cin_pad, int kk,
@@ -1294,23 +1142,6 @@ int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
   return check_launch("igemm");
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int NST, int LW, int EPI>
-int launch_ws(const IgemmParams& p, hipStream_t st) {
-  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int lds_ring = NST * (BM + BN) * BK * 2 + 64;
-  constexpr int lds_epi = EPI_LDS_OFF + WM * WN * (64 * (TN * 32 + 16) + 256);
-  constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-  const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
-  auto k = igemm_ws_kernel<WM, WN, TM, TN, BK, NST, LW, EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k, dim3(gm * gn), dim3((WM * WN + LW) * 64), lds, st, p);
-  return check_launch("igemm_ws");
-}
-
 template <int WM, int WN, int TM, int TN, int BK, int EPI, int SCHED>
 int launch_il(const IgemmParams& p, hipStream_t st) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -1388,22 +1219,15 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 3: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 64, 2, EPI>(p, st); break;
     case 4: return launch_cfg<2, 2, 4, 4, 32, 3, EPI>(p, st);
     case 5: return launch_cfg<2, 2, 4, 4, 32, 2, EPI, false, false, 4>(p, st);   // 32 KB LDS, <=128 VGPR: 4 workgroups/CU
-    case 7: return launch_ws<2, 2, 4, 4, 32, 4, 1, EPI>(p, st);    // warp-specialised 128x128x32, ring 4 (64 KB), 1 loader
-    case 8: return launch_ws<2, 2, 4, 4, 64, 2, 2, EPI>(p, st);    // warp-specialised 128x128x64, 2 buffers, 2 loaders
-    case 9: return launch_ws<2, 2, 8, 4, 32, 3, 1, EPI>(p, st);    // warp-specialised 256x128x32 (wave 128x64), ring 3 (72 KB)
-    case 10: return launch_ws<2, 2, 8, 4, 64, 2, 2, EPI>(p, st);   // warp-specialised 256x128x64, 2 buffers (96 KB), 2 loaders
-    case 11: return launch_ws<2, 2, 4, 4, 64, 3, 2, EPI>(p, st);   // ws 128x128x64 ring 3 (96 KB, 1 WG/CU), 2 loaders
-    case 12: return launch_ws<2, 2, 8, 4, 64, 3, 2, EPI>(p, st);   // ws 256x128x64 ring 3 (144 KB), 2 loaders
-    case 13: return launch_ws<2, 2, 8, 4, 64, 3, 4, EPI>(p, st);   // ws 256x128x64 ring 3, 4 loaders
-    case 14: return launch_ws<2, 2, 4, 4, 32, 4, 2, EPI>(p, st);   // ws 128x128x32 ring 4 (64 KB, 2 WG/CU), 2 loaders
     case 6: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 0>(p, st); break;   // interleaved 256x256x64, 8 waves of 128x64
-    case 50: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 32, 3, EPI>(p, st); break;   // 256x256x32 ring 3 (96 KB)
-    case 51: if (p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 32, 4, EPI>(p, st); break;   // 256x256x32 ring 4 (128 KB)
-    case 52: return launch_cfg<2, 2, 8, 4, 32, 3, EPI>(p, st);                                     // 256x128x32 ring 3 (72 KB, 2 workgroups/CU)
-    case 53: return launch_cfg<2, 2, 8, 4, 32, 4, EPI>(p, st);                                     // 256x128x32 ring 4 (96 KB)
-    case 54: return launch_cfg<2, 2, 4, 4, 32, 4, EPI>(p, st);                                     // 128x128x32 ring 4 (64 KB, 2 workgroups/CU)
-    case 55: return launch_cfg<2, 2, 4, 4, 64, 3, EPI>(p, st);                                     // 128x128x64 ring 3 (96 KB, 1 workgroup/CU)
-    case 56: return launch_cfg<2, 2, 4, 4, 32, 6, EPI>(p, st);                                     // 128x128x32 ring 6 (96 KB)
+    // 50-56: deeper rings, diagnostic (forward only): measured slower than depth 2 once the LDS-DMA really stays in flight
+    case 50: if (EPI == EPI_STATS && p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 32, 3, EPI>(p, st); break;   // 256x256x32 ring 3 (96 KB)
+    case 51: if (EPI == EPI_STATS && p.CoutPad % 256 == 0) return launch_cfg<2, 4, 8, 4, 32, 4, EPI>(p, st); break;   // 256x256x32 ring 4 (128 KB)
+    case 52: if (EPI == EPI_STATS) return launch_cfg<2, 2, 8, 4, 32, 3, EPI>(p, st); break;                                     // 256x128x32 ring 3 (72 KB, 2 workgroups/CU)
+    case 53: if (EPI == EPI_STATS) return launch_cfg<2, 2, 8, 4, 32, 4, EPI>(p, st); break;                                     // 256x128x32 ring 4 (96 KB)
+    case 54: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 4, EPI>(p, st); break;                                     // 128x128x32 ring 4 (64 KB, 2 workgroups/CU)
+    case 55: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 3, EPI>(p, st); break;                                     // 128x128x64 ring 3 (96 KB, 1 workgroup/CU)
+    case 56: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 6, EPI>(p, st); break;                                     // 128x128x32 ring 6 (96 KB)
     case 15: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI>(p, st); break;             // 3x3 s1: shared pixel tiles (dx reuse), 128x128
     case 16: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI>(p, st); break;             // dx reuse 256x128, 8 waves, 1 workgroup/CU
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves
@@ -1416,12 +1240,6 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 21: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 1>(p, st); break;   // ablations of cfg 1
     case 22: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 2>(p, st); break;
     case 23: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 3>(p, st); break;
-    case 41: return launch_il<2, 2, 4, 4, 64, EPI, 0>(p, st);    // interleaved 128x128x64
-    case 42: return launch_il<2, 2, 4, 4, 64, EPI, 1>(p, st);    // + sched_group_barrier pattern
-    case 43: return launch_il<2, 2, 8, 4, 64, EPI, 0>(p, st);    // interleaved 256x128x64 (wave 128x64), 96 KB
-    case 44: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 0>(p, st); break;   // interleaved 256x256x64, 8 waves
-    case 45: if (p.CoutPad % 256 == 0) return launch_il<2, 4, 8, 4, 64, EPI, 1>(p, st); break;
-    case 31: if (EPI == EPI_PLAIN) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, true>(p, st); break;   // interleaved issue
     case 25: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, false, false, 0, 5>(p, st); break;
     case 99: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 2, EPI, true>(p, st); break;   // phase-stamp diagnostic build
     case 98: if (EPI == EPI_STATS && dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI, 2, true>(p, st); break;   // same for the shared-pixel-tile kernel
