@@ -101,78 +101,6 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Both stages of the statistics reduction in ONE launch for layers with many pixel tiles: every workgroup reduces one chunk of
-// rows of one 32-channel slab into the spare rows (as bn_partial_kernel), and the LAST workgroup of a slab to finish (device-scope
-// counter, device-scope stores / loads of the chunk rows) sums the 64 chunk rows in a fixed order and writes scale / shift / running
-// statistics (as bn_finalize_kernel).  Deterministic: which workgroup is last does not change the order of the additions.
-// Saves one ~6 us latency-bound launch per layer on the forward critical path (56 layers per YOLOv3 step).
-__global__ __launch_bounds__(256) void bn_partial_finalize_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, int chunk,
-                                                                  float* scratch, unsigned* counters, double count,
-                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                                  float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                  float* __restrict__ ss) {
-  __shared__ float sh[8][32][2];
-  __shared__ double shd[8][32][2];
-  __shared__ int s_last;
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + cl;
-  const int r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
-  float s1 = 0.f, s2 = 0.f;
-  if (ch < c_pad)
-    for (int r = r0 + rl; r < r1; r += 8) {
-      s1 += partial[(size_t)r * 2 * c_pad + ch];
-      s2 += partial[(size_t)r * 2 * c_pad + c_pad + ch];
-    }
-  sh[rl][cl][0] = s1;
-  sh[rl][cl][1] = s2;
-  __syncthreads();
-  if (rl == 0 && ch < c_pad) {
-    for (int r = 1; r < 8; ++r) {
-      s1 += sh[r][cl][0];
-      s2 += sh[r][cl][1];
-    }
-    // device-scope (write-through) stores: visible to a workgroup on another XCD without writing the whole L2 back, which a
-    // release fence would do here (measured: +1.6 ms per step with __threadfence())
-    __hip_atomic_store(scratch + (size_t)blockIdx.y * 2 * c_pad + ch, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(scratch + (size_t)blockIdx.y * 2 * c_pad + c_pad + ch, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk row has been acknowledged ...
-  __syncthreads();                                   // ... for every writing thread, before the slab counter moves
-  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.y - 1;
-  __syncthreads();
-  if (!s_last) return;
-  if (threadIdx.x == 0) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for its next use
-  double d1 = 0, d2 = 0;
-  if (ch < c)
-    for (int r = rl; r < (int)gridDim.y; r += 8) {     // device-scope loads: the other workgroups' rows, not a stale cache line
-      d1 += (double)__hip_atomic_load(scratch + (size_t)r * 2 * c_pad + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      d2 += (double)__hip_atomic_load(scratch + (size_t)r * 2 * c_pad + c_pad + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  shd[rl][cl][0] = d1;
-  shd[rl][cl][1] = d2;
-  __syncthreads();
-  if (rl == 0 && ch < c) {
-    for (int r = 1; r < 8; ++r) {
-      d1 += shd[r][cl][0];
-      d2 += shd[r][cl][1];
-    }
-    const double mean = d1 / count;
-    double var = d2 / count - mean * mean;
-    if (var < 0) var = 0;
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float scl = gamma[ch] * invstd;
-    ss[ch] = scl;
-    ss[c + ch] = beta[ch] - (float)mean * scl;
-    ss[2 * c + ch] = (float)mean;
-    ss[3 * c + ch] = invstd;
-    if (rmean) {
-      rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
-      const double unb = count > 1 ? var * count / (count - 1) : var;
-      rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
-    }
-  }
-}
-
 // final stage of the fused BN-backward reduction: [rows<=256][2][c_pad] -> sums[2*c] (sum dy | sum dy*xhat)
 __global__ __launch_bounds__(256) void bn_bwd_sum_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, float* __restrict__ sums) {
   __shared__ float sh[8][32][2];
@@ -548,24 +476,6 @@ inline bool rows_form(int c, long long pixels, int* gshift, int* ppb, int* block
   return true;
 }
 
-// device-scope arrival counters of bn_partial_finalize_kernel: zeroed once, every launch takes the next slot of 64 counters and
-// leaves it zero again, so launches in flight on different streams never share one (4096 slots)
-unsigned* g_bn_counters = nullptr;
-unsigned g_bn_counter_next = 0;
-unsigned* bn_counter_slot(int slabs) {
-  constexpr int kSlots = 4096, kPer = 64;
-  if (slabs > kPer) return nullptr;
-  if (!g_bn_counters) {
-    void* p = nullptr;
-    if (hipMalloc(&p, (size_t)kSlots * kPer * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, (size_t)kSlots * kPer * sizeof(unsigned)) != hipSuccess) return nullptr;
-    g_bn_counters = (unsigned*)p;
-  }
-  unsigned* slot = g_bn_counters + (size_t)(g_bn_counter_next % kSlots) * kPer;
-  ++g_bn_counter_next;
-  return slot;
-}
-
 inline int grid_for(long long total) { return (int)min((long long)256 * 16, (total + 255) / 256); }
 
 }  // namespace
@@ -629,16 +539,14 @@ int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
   if (rows > 256) {
-    // two stages (deterministic) in one launch: 64 row-chunks reduced in parallel into the 64 spare rows behind the partials, the
-    // last workgroup of every 32-channel slab finishes
+    // two stages (deterministic): 64 row-chunks reduced in parallel into the 64 spare rows behind the partials.  (One launch whose
+    // last workgroup per channel slab finalises was measured too: the device-scope stores / loads it needs make it 15 us against
+    // 7 + 6 us for the two launches, 1011-1017 vs 1020 images/s on the same box; with __threadfence() it writes the L2 back: -5 %.)
     const int chunks = 64, chunk = (rows + chunks - 1) / chunks;
     float* scratch = const_cast<float*>(stats) + (size_t)rows * 2 * c_pad;
-    const int slabs = (c_pad + 31) / 32;
-    unsigned* counters = bn_counter_slot(slabs);
-    if (!counters) return fail(MI355DET_ELAUNCH, "%s: counter allocation failed", "bn_finalize");
-    hipLaunchKernelGGL(bn_partial_finalize_kernel, dim3(slabs, chunks), dim3(256), 0, S(stream), stats, rows, c, c_pad, chunk, scratch, counters,
-                       (double)count, gamma, beta, eps, momentum, running_mean, running_var, scale_shift);
-    return check_launch("bn_finalize");
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((c_pad + 31) / 32, chunks), dim3(256), 0, S(stream), stats, rows, c_pad, chunk, scratch);
+    stats = scratch;
+    rows = chunks;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
                      momentum, running_mean, running_var, scale_shift);

@@ -463,9 +463,9 @@ def test_stride2_dgrad_single_launch_matches_class_launches(case):
 
 
 @pytest.mark.parametrize("rows,c,c_pad", [(1600, 256, 256), (300, 96, 128), (257, 32, 32), (5000, 1024, 1024)])
-def test_bn_finalize_many_rows_single_launch(rows, c, c_pad):
-    """rows > 256: both reduction stages run in one launch (last workgroup of a channel slab finishes).  Repeated launches on fresh
-    data give fresh results (the arrival counters are left clean) and match a float64 reduction of the same partial rows."""
+def test_bn_finalize_many_rows(rows, c, c_pad):
+    """rows > 256: two-stage reduction through the 64 spare rows; repeated launches on fresh data match a float64 reduction of the
+    same partial rows."""
     from object_detectors_amd._lib import check, lib, ptr, stream_ptr
     d = dev()
     count = rows * 128
