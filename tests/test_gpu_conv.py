@@ -489,3 +489,31 @@ def test_bn_finalize_many_rows(rows, c, c_pad):
         np.testing.assert_allclose(got[3 * c:], invstd, rtol=1e-4)
         np.testing.assert_allclose(got[:c], gamma.cpu().double() * invstd, rtol=1e-4)
         np.testing.assert_allclose(rm.cpu().double(), 0.1 * mean, rtol=1e-4, atol=1e-6)
+
+
+def test_stride2_dgrad_single_launch_full_size():
+    """BASELINE size of the layer the single-launch kernel exists for (32 -> 64, 3x3 / 2, 640 px, batch 32): identical to the four
+    class launches up to the summation order, on every pixel of the 839 MB gradient."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout = 32, 640, 640, 32, 64
+    shape = ops.conv_shape(n, h, w, cin, cout, 3, 2)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5).to(dev())
+    wf, wd = ops.pack_weights(shape, wt)
+    gy = torch.randn(n, h // 2, w // 2, cout, device=dev(), generator=torch.Generator(device=dev()).manual_seed(6)).bfloat16()
+    outs = []
+    try:
+        for off in (1, 0):
+            lib().mi355det_debug_set(2, off)
+            dx = torch.empty(n, h, w, cin, dtype=torch.bfloat16, device=dev())
+            ops.conv_dgrad(shape, gy, wd, dx)
+            outs.append(dx)
+    finally:
+        lib().mi355det_debug_set(2, 0)
+    diff = (outs[0].float() - outs[1].float()).abs().max().item()
+    scale = outs[0].float().abs().max().item()
+    assert scale > 0 and diff <= 1e-2 * scale
+    # one bf16 ulp at most wherever the two summation orders round differently
+    rel = ((outs[0].float() - outs[1].float()).abs() / (outs[0].float().abs() + 1e-3)).max().item()
+    assert rel < 2e-2
