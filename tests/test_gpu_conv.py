@@ -198,6 +198,14 @@ def test_upsample_and_layout():
     unf = F.unfold(img, 3, padding=1).view(2, 3, 9, 72).permute(0, 3, 2, 1).reshape(2 * 72, 27)   # k = tap*3 + c
     assert torch.equal(col[:, :27].float().cpu(), unf)
     assert (col[:, 27:] == 0).all()
+    # rows wider than one 128-pixel segment, last segment partial
+    img = rnd((1, 3, 5, 300), 25).bfloat16().float()
+    col = torch.full((5 * 300 + 8, 32), 9.0, dtype=torch.bfloat16, device=d)
+    img_d = img.to(d)
+    check(lib().mi355det_stem_im2col(ptr(img_d), ptr(col), 1, 5, 300, stream_ptr()))
+    unf = F.unfold(img, 3, padding=1).view(1, 3, 9, 1500).permute(0, 3, 2, 1).reshape(1500, 27)
+    assert torch.equal(col[:1500, :27].float().cpu(), unf)
+    assert (col[:1500, 27:] == 0).all() and (col[1500:] == 9.0).all()
     # layout converters
     t = rnd((2, 5, 4, 6), 24)
     o = torch.zeros(2, 4, 6, 8, dtype=torch.bfloat16, device=d)
