@@ -31,12 +31,13 @@ for s, r in zip(specs, fwd):
 for s, r in zip(reversed(specs), wg):
     agg[(s.cin, s.cout, s.k, s.stride, hw(s))][3] += dur(r)
 # dgrad: igemm kernels after the first wgrad, grouped per layer in backward order (stride-2 layers have 4 launches)
-allig = sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
+allig = sorted([r for r in last if 'igemm' in r['Kernel_Name'] or 'dgrad_s2_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
 dg = allig[75:]
 it = iter(dg)
 for s in reversed(specs):
     if s.name == 'backbone.conv1': continue
     n = 4 if s.stride == 2 else 1
+    if s.stride == 2 and s.cout == 64 and s.cin in (32, 64): n = 1    # single-launch stride-2 data gradient (dgrad_s2_kernels.hip)
     t = sum(dur(next(it)) for _ in range(n))
     agg[(s.cin, s.cout, s.k, s.stride, hw(s))][2] += t
 print(f"{'cin->cout k s @hw':28s} {'n':>3s} {'fwd us':>8s} {'TF':>6s} {'dgrad':>8s} {'TF':>6s} {'wgrad':>8s} {'TF':>6s}  tot ms")
