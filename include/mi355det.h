@@ -35,7 +35,8 @@ extern "C" {
 #define MI355DET_MAX_ANCHORS 8
 
 const char* mi355det_last_error(void);
-int mi355det_debug_set(int key, int value);   /* bring-up / tuning knobs; key 0 = conv tile configuration */
+int mi355det_debug_set(int key, int value);   /* bring-up / test knobs: key 0 = force a conv tile configuration (0 = tuned), 1 = weight gradient
+                                                 with per-lane bookkeeping, 2 = stride-2 data gradient as four class launches (tests compare the forms) */
 int mi355det_debug_ptr(int key, void* ptr);   /* key 0 = device buffer for the diagnostic (phase-stamp) conv build */
 int mi355det_version(void);
 
