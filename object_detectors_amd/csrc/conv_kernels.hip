@@ -1320,7 +1320,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
     g_igemm_tuned[igemm_key(p, EPI)] = best;
     return best;
   }
-  if (!(p.CoutPad % 128 == 0 && p.Cin % 64 == 0)) return 0;
+  if (!(p.CoutPad % 128 == 0 && p.Cin % 64 == 0)) return launch_igemm<EPI>(p, st);   // nothing to choose: a plain launch, the output stays valid
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
