@@ -716,12 +716,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
     b_voff[i] = (row * Ktot + (cpos ^ swz<BK>(row)) * 8) * 2;
   }
 
-  // ---- fragment read offsets: pixel fragments per dx position (row shift + its own swizzle phase) and edge masks
+  // ---- fragment read offsets: pixel fragments per dx position (row shift + its own swizzle phase).  A lane whose pixel has no
+  // neighbour in direction dx_i (image edge: the neighbour in memory is the previous / next image row) reads a ZERO row instead:
+  // the dummy pieces behind the tile are staged out of range, i.e. as zeros, in every group, so the edge costs no instruction in
+  // the loop (it used to be 64 v_cndmask per three k-steps)
+  static_assert(A_PER * NW > A_INSTR, "needs a dummy (zero) piece behind the pixel tile");
   const int fr = lane & 15, fq = lane >> 4;
   int afrag[3][TM];
-  unsigned edge[3];             // bit j: this lane's pixel of group j has no neighbour in direction dx_i
-#pragma unroll
-  for (int i = 0; i < 3; ++i) edge[i] = 0;
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int r = wm * (TM * 16) + j * 16 + fr;
@@ -730,9 +731,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int e = r + R + dxi[i];
-      afrag[i][j] = e * ROWB + ((fq ^ swz_shift<BK>(e)) << 4);
       const bool off = (dxi[i] < 0 && xx == 0) || (dxi[i] > 0 && xx == p.MW - 1);
-      edge[i] |= off ? (1u << j) : 0u;
+      afrag[i][j] = off ? A_INSTR * R * ROWB + (fq << 4) : e * ROWB + ((fq ^ swz_shift<BK>(e)) << 4);
     }
   }
   int wfrag[TN];
@@ -836,7 +836,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           af[j] = *(const bf16x8_t*)(ab + (afrag[i][j] ^ (ks << 6)));
-          if ((edge[i] >> j) & 1u) af[j] = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
         }
         if (PROF) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // diagnostic build: separate the fragment reads from the MFMAs
