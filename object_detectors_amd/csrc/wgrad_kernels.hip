@@ -98,7 +98,8 @@ __device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
 // image row (always, for map widths that are multiples of 4) the dY offsets are loop constants and the X offsets a lane constant
 // plus a scalar: the per-step vector work drops from ~146 to ~25 VALU instructions (the general form spends more issue cycles on
 // addresses than on the 32 MFMAs of a step).  A piece that straddles a row end adds a per-lane select of the next row's scalars.
-template <int CI, int CJ, int GRP4>   // 0: per-lane bookkeeping, 1: scalar, pieces never straddle (Wo % 4 == 0), 2: scalar with straddling pieces
+template <int CI, int CJ, int GRP4>   // 0: per-lane bookkeeping, 1: scalar, pieces never straddle (Wo % 4 == 0), 2: scalar with straddling pieces,
+                                      // 3: scalar, one tracker per wave (Wo % 16 == 0)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   constexpr int STAGE = 2 * WG_BKP * WG_ROWB;   // dy tile + x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   const int c_sb = (c_hs * p.W + c_ws) * p.ldx * 2;                 // 64 pixels ahead without wrapping
   const int c_row = (p.stride * p.W - WoS) * p.ldx * 2;             // extra bytes when wo wraps into the next output row
   const int c_img = (p.H - HoS) * p.W * p.ldx * 2;                  // extra bytes when ho wraps into the next image
+  const int c_piece = 4 * p.stride * p.ldx * 2;                     // bytes between the pieces of one wave inside a row (GRP4 == 3)
   if constexpr (GRP4 != 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -196,8 +198,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       const int instr = wid * 4 + i;
       const int ph = (i >> 1) & 1;
       bufld16(rsrc_dy, sd + instr * 1024, dyv[i], 0);
-      const int hs = g_hs[i], ws = g_ws[i];
-      if (GRP4 == 1 || (ws + 4 * p.stride <= WoS && instr * 4 + 4 <= rem)) {   // wave-uniform: the piece's four pixels lie in one image row
+      if (GRP4 == 3) {   // Wo % 16 == 0: the wave's four pieces are 16 consecutive pixels of ONE image row, one tracker serves them
+        const int hs = g_hs[0], ws = g_ws[0] + i * 4 * p.stride;
+        const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
+        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[0] + i * c_piece);
+        if (i < 3) continue;
+      }
+      const int ti = GRP4 == 3 ? 0 : i;
+      const int hs = g_hs[ti], ws = g_ws[ti];
+      if (GRP4 == 3) {
+      } else if (GRP4 == 1 || (ws + 4 * p.stride <= WoS && instr * 4 + 4 <= rem)) {   // wave-uniform: the piece's four pixels lie in one image row
         const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
         bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[i]);
       } else {
@@ -212,17 +222,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
         const bool ok = instr * 4 + lrow < rem && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] + (wr ? ex1 : 0) : OOB_VOFF, g_sb[i]);
       }
-      g_ws[i] += c_ws;
-      g_hs[i] += c_hs;
-      g_sb[i] += c_sb;
-      if (g_ws[i] >= WoS) {
-        g_ws[i] -= WoS;
-        g_hs[i] += p.stride;
-        g_sb[i] += c_row;
+      g_ws[ti] += c_ws;
+      g_hs[ti] += c_hs;
+      g_sb[ti] += c_sb;
+      if (g_ws[ti] >= WoS) {
+        g_ws[ti] -= WoS;
+        g_hs[ti] += p.stride;
+        g_sb[ti] += c_row;
       }
-      if (g_hs[i] >= HoS) {   // a single wrap: the host only picks this form when 64 pixels span at most Ho - 1 rows
-        g_hs[i] -= HoS;
-        g_sb[i] += c_img;
+      if (g_hs[ti] >= HoS) {   // a single wrap: the host only picks this form when 64 pixels span at most Ho - 1 rows
+        g_hs[ti] -= HoS;
+        g_sb[ti] += c_img;
       }
     }
   };
@@ -630,11 +640,11 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     hipLaunchKernelGGL(kern, dim3(tiles * splits), dim3(256), lds, S(stream), p);
   };
   // scalar pixel bookkeeping: a 4-pixel piece may span at most two image rows, byte offsets into x must fit 31 bits
-  const int grp4 = g_wgrad_general != 0 || p.Wo < 4 || WG_BKP / p.Wo + 1 > p.Ho ? 0 : (p.Wo % 4 == 0 ? 1 : 2);
+  const int grp4 = g_wgrad_general != 0 || p.Wo < 4 || WG_BKP / p.Wo + 1 > p.Ho ? 0 : (p.Wo % 16 == 0 ? 3 : (p.Wo % 4 == 0 ? 1 : 2));
   const bool fits =
                     ((long long)s->n * p.H * p.W + (long long)p.pad * (p.W + 1)) * p.ldx * 2 < 0x7FFFFFF0ll &&
                     (long long)chunk * p.lddy * 2 < 0x7FFFFFF0ll;
-#define WG_GO(a, b) (!fits || grp4 == 0 ? go(wgrad_kernel<a, b, 0>) : grp4 == 1 ? go(wgrad_kernel<a, b, 1>) : go(wgrad_kernel<a, b, 2>))
+#define WG_GO(a, b) (!fits || grp4 == 0 ? go(wgrad_kernel<a, b, 0>) : grp4 == 1 ? go(wgrad_kernel<a, b, 1>) : grp4 == 2 ? go(wgrad_kernel<a, b, 2>) : go(wgrad_kernel<a, b, 3>))
   switch (ci * 8 + cj) {
     case 1 * 8 + 1: WG_GO(1, 1); break;
     case 1 * 8 + 2: WG_GO(1, 2); break;

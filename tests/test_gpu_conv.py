@@ -403,7 +403,8 @@ def test_narrow_output_shared_pixel_tile_kernels(case):
 @pytest.mark.parametrize("case", [(3, 20, 12, 64, 128, 3, 1, 64, 128), (2, 24, 16, 32, 64, 3, 2, 48, 64), (2, 16, 16, 128, 72, 1, 1, 128, 80),
                                   (5, 40, 40, 128, 256, 3, 1, 128, 256), (1, 4, 4, 256, 128, 3, 1, 256, 128),
                                   (3, 13, 13, 64, 128, 3, 1, 64, 128), (2, 25, 25, 64, 64, 3, 2, 64, 64), (3, 7, 7, 128, 128, 3, 1, 128, 128),
-                                  (2, 50, 50, 64, 128, 1, 1, 64, 128), (1, 9, 5, 32, 32, 3, 1, 40, 32)])
+                                  (2, 50, 50, 64, 128, 1, 1, 64, 128), (1, 9, 5, 32, 32, 3, 1, 40, 32),
+                                  (2, 32, 32, 64, 128, 3, 1, 64, 136), (2, 64, 64, 32, 64, 3, 2, 32, 64), (1, 7, 48, 128, 128, 3, 1, 128, 128)])
 def test_wgrad_scalar_bookkeeping_form_is_bit_identical(case):
     """Maps at least 4 wide take the wgrad form with wave-uniform pixel bookkeeping (buffer-descriptor LDS-DMA; pieces that
     straddle a row end when the width is not a multiple of 4);
