@@ -87,3 +87,12 @@ class GradSync:
         plan._gradsync = self
         self.side_stream = getattr(plan, "side_stream", None)
         self.buckets = buckets
+
+
+def step_stream(device):
+    """High-priority stream for the training step's dependency chain.  Make it current (`torch.cuda.set_stream` or
+    `with torch.cuda.stream(...)`) BEFORE the engine builds its plan: plans bind their launches to the stream that is current
+    at build time, and their side stream (weight gradients, gradient all-reduce) stays at the default priority, so the chain
+    is never queued behind side-stream work."""
+    return torch.cuda.Stream(device=device, priority=-1)
+
