@@ -22,6 +22,8 @@ def main():
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.tvision.frcnn import fasterrcnn_resnet50_fpn
     dev = torch.device("cuda:0")
+    from object_detectors_amd.parallel import step_stream
+    torch.cuda.set_stream(step_stream(dev))      # dependency chain above the side stream (weight gradients), as bench.py
     torch.manual_seed(0)
     model = fasterrcnn_resnet50_fpn(num_classes=91, device=dev)
     eng = model.engine

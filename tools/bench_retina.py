@@ -24,6 +24,8 @@ def main():
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.tvision.engine import RetinaNetEngine
     dev = torch.device("cuda:0")
+    from object_detectors_amd.parallel import step_stream
+    torch.cuda.set_stream(step_stream(dev))      # dependency chain above the side stream (weight gradients), as bench.py
     eng = RetinaNetEngine(args.classes, 9, 3, device=dev, seed=0, body=args.body)
     # random-init residual stacks with FROZEN BatchNorm have no normalisation at all: damp the last BN of every bottleneck
     # (as zero-init-residual / pretrained weights do) so that 33 blocks of ResNet-101 stay finite in bf16
