@@ -16,6 +16,8 @@
 //   2 workgroups per CU overlap each other's waits.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <unordered_map>
 
 using namespace mi355;
@@ -1326,6 +1328,11 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   float best_ms = 1e30f;
   const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28};     // 35 (BK 32, 3 workgroups per CU) measured slower: not tried
   for (int cfg : cands) {
+    // data gradients run next to the weight-gradient stream: only tiles of <= 64 KB LDS (two workgroups per CU), which can share a CU
+    // with a 64 KB weight-gradient workgroup; the one-per-CU tiles are a little faster alone and slower in the step (same-box A/B:
+    // 1046-1047 vs 1039-1041 images/s).  MI355DET_DGRAD_BIG_LDS=1 restores the full candidate list.
+    static const bool small_lds = getenv("MI355DET_DGRAD_BIG_LDS") == nullptr;
+    if (small_lds && (EPI == EPI_PLAIN || EPI == EPI_RES) && (cfg == 3 || cfg == 6 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 26 || cfg == 27 || cfg == 28)) continue;
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
     if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18 || cfg == 28) && p.CoutPad % 256 != 0))) continue;
     int e = run_cfg<EPI>(cfg, p, st);
