@@ -24,6 +24,7 @@ SOURCES = [
     ("roi_kernels.hip", ["-ffp-contract=off"]),
     ("resnet_kernels.hip", []),
     ("conv_kernels.hip", []),
+    ("igemm8_kernels.hip", []),
     ("wgrad_kernels.hip", []),
     ("dgrad_s2_kernels.hip", []),
     ("elem_kernels.hip", []),
