@@ -871,7 +871,8 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 54: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 4, EPI>(p, st); break;                                     // 128x128x32 ring 4 (64 KB, 2 workgroups/CU)
     case 55: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 3, EPI>(p, st); break;                                     // 128x128x64 ring 3 (96 KB, 1 workgroup/CU)
     case 56: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 6, EPI>(p, st); break;                                     // 128x128x32 ring 6 (96 KB)
-    case 40: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st); break;   // phase-staggered 256x256x64, 8 waves
+    case 40: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st, false); break;   // phase-staggered 256x256x64, 8 waves
+    case 41: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st, true); break;    // the same as one persistent workgroup per CU (stream-K)
     case 15: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI>(p, st); break;             // 3x3 s1: shared pixel tiles (dx reuse), 128x128
     case 16: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI>(p, st); break;             // dx reuse 256x128, 8 waves, 1 workgroup/CU
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves
@@ -959,7 +960,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
   int best = 1;
   float best_ms = 1e30f;
-  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28};     // 35 (BK 32, 3 workgroups per CU) measured slower: not tried
+  const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28, 40};     // 35 (BK 32, 3 workgroups per CU) measured slower: not tried
   for (int cfg : cands) {
     // data gradients run next to the weight-gradient stream: only tiles of <= 64 KB LDS (two workgroups per CU), which can share a CU
     // with a 64 KB weight-gradient workgroup; the one-per-CU tiles are a little faster alone and slower in the step (same-box A/B:
@@ -967,6 +968,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
     static const bool small_lds = getenv("MI355DET_DGRAD_BIG_LDS") == nullptr;
     if (small_lds && (EPI == EPI_PLAIN || EPI == EPI_RES) && (cfg == 3 || cfg == 6 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 26 || cfg == 27 || cfg == 28)) continue;
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
+    if (cfg == 40 && !(igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF))) continue;
     if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18 || cfg == 28) && p.CoutPad % 256 != 0))) continue;
     int e = run_cfg<EPI>(cfg, p, st);
     if (e) return e;
@@ -984,6 +986,8 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   g_igemm_tuned[igemm_key(p, EPI)] = best;
+  static const bool tune_log = getenv("MI355DET_TUNE_LOG") != nullptr;
+  if (tune_log) fprintf(stderr, "[mi355det] igemm tune: M=%d Cout=%d Cin=%d T=%d epi=%d -> cfg %d (%.1f us)\n", p.M, p.CoutPad, p.Cin, p.T, EPI, best, best_ms * 1e3f / 3.f);
   return best;
 }
 
@@ -1065,6 +1069,7 @@ int mi355det_conv_autotune_mode(int on) {
 
 int mi355det_debug_ptr(int key, void* ptr) {
   if (key == 0) g_dbg = (unsigned long long*)ptr;
+  if (key == 1) igemm8_set_dbg((unsigned long long*)ptr);
   return 0;
 }
 

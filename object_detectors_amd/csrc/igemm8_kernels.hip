@@ -19,9 +19,28 @@
 // wave before the phase's first barrier, and it is read one phase later (RAW through counted vmcnt + barrier; WAR by
 // re-staging a half no earlier than two phases after its last read, which covers the one-barrier stagger).
 // Addressing, zero padding (out-of-range buffer offsets), swizzle and the epilogues are those of igemm_kernel.
+//
+// Stream-K form (SK = true): the big Darknet layers have 800 / 400 / 200 / 100 tiles on 256 CUs (3.1 / 1.6 / 0.8 / 0.4 rounds), so a
+// tile-per-workgroup grid idles 22-60 % of the chip in its last round.  One persistent workgroup per CU instead walks a contiguous
+// range of (tile, k-step) units, U / 256 each.  A range that starts inside a tile computes that tile's TAIL first and hands its fp32
+// accumulators over through a slab (write-through stores + flag, cdna_hip_programming.md Guideline 16 R1); the workgroup whose range
+// ENDS with the tile's head (k-step 0) adds the slabs of its successors - written at their very start, long before it asks - and
+// runs the epilogue.  At most one slab write and one tile finish per workgroup; sums are taken in a fixed order (deterministic).
 #include "igemm_common.h"
 
+#include <unordered_map>
+
+struct SkParams {
+  float* slabs;        // [nwg][8 waves][32][64 lanes][4] fp32
+  unsigned* flags;     // [nwg] epoch of the last slab published by that workgroup, [nwg] = error word
+  unsigned epoch;      // launch counter of this workspace (never 0)
+  int nwg;
+  unsigned long long* dbg;   // diagnostic: per-workgroup s_memrealtime stamps (mi355det_debug_ptr key 1), or null
+};
+
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 constexpr int kBM = 256, kBN = 256, kBK = 64, kROWB = 128;
 constexpr int kHALF = 128 * kROWB;            // 16 KB: one half-tile
@@ -38,232 +57,369 @@ __device__ __forceinline__ void bar() {
   asm volatile("" ::: "memory");
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p) {
+template <int EPI, bool SK, bool PROF = false>
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const SkParams sk) {
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;     // waves 0-3 = pixel half 0, waves 4-7 = pixel half 1 (SIMD partners)
+  const int tid0 = threadIdx.x;
 
   const int ntn = p.CoutPad / kBN, nblk = gridDim.x;
   int bid = blockIdx.x;
   {
+    // blocks b and b + 8 share an XCD: give each XCD a contiguous run of tiles / unit ranges (L2 reuse of pixel and weight tiles, and a
+    // finishing workgroup usually reads a slab written on its own XCD); bijective for any grid size
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int mt = bid / ntn, nt = bid - mt * ntn;
-  const int m0 = mt * kBM, n0 = nt * kBN;
-
-  const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
   const int Ktot = p.T * p.Cin;
-  const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
-  const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
-
-  // ---- rows this lane stages: per half h two pieces (8 rows of 128 B each); LDS row r' of a half <-> tile row
-  const int lrow = lane >> 3, cpos = lane & 7;
-  int a_voff[2][2], b_voff[2][2];
-  unsigned a_valid[2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r2 = (2 * wid + i) * 8 + lrow;                  // row inside the half, 0..127
-      const int sw = ((h * 128 + r2) >> 1) & 7;
-      {
-        const int row = (r2 >> 6) * 128 + h * 64 + (r2 & 63);   // pixel row of the tile
-        const int m = m0 + row;
-        unsigned vm = 0;
-        int voff = OOB_VOFF;
-        if (p.lin_in) {
-          if (m < p.M) {
-            voff = ((m - n_first * p.Hin * p.Win) * p.ldin + (cpos ^ sw) * 8) * 2;
-            vm = 1u;
-          }
-        } else if (m < p.M) {
-          const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
-          const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
-          const int iy0 = yy * p.sin, ix0 = xx * p.sin;
-          voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ sw) * 8) * 2;
-#pragma unroll
-          for (int t = 0; t < MAX_TAPS; ++t) {
-            if (t >= p.T) break;
-            const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
-            const bool ok = (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
-            vm |= ok ? (1u << t) : 0u;
-          }
-        }
-        a_voff[h][i] = voff;
-        a_valid[h][i] = vm;
-      }
-      {
-        const int row = (r2 >> 5) * 64 + h * 32 + (r2 & 31);    // channel row of the tile
-        b_voff[h][i] = (row * Ktot + (cpos ^ sw) * 8) * 2;
-      }
-    }
-
-  // ---- fragment read addresses (byte offsets into a k-step buffer, k-substep 0; substep 1 = ^64)
-  const int fr = lane & 15, fq = lane >> 4;
-  const int fsw = (fr >> 1) & 7;
-  int xrd = (wm * 64 + fr) * kROWB + ((fq ^ fsw) << 4);                  // + h*kHALF + jj*16*kROWB
-  int wrd = 2 * kHALF + (wn * 32 + fr) * kROWB + ((fq ^ fsw) << 4);      // + h*kHALF + ii*16*kROWB
-
   const int ksteps = Ktot / kBK, cin_steps = p.Cin / kBK;
 
-  // scalar state of the k-steps being prefetched: tile t+1 (slot 1) and t+2 (slot 2)
-  auto tap_off = [&](int tap) {
-    const int dyt = (int)((p.dy_pack >> (4 * tap)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * tap)) & 0xF) - 2;
-    return ((dyt * p.Win + dxt) * p.ldin + p.tap_pad) * 2;
-  };
-  int pf_t = 0, pf_c = 0, pf_s = 0;               // (tap, cin-step, k-step) of the NEXT tile to set up
-  struct Slot { int tap, soffx, soffw, live; };
-  auto next_slot = [&]() {
-    Slot s;
-    s.live = pf_s < ksteps;
-    s.tap = s.live ? pf_t : 31;                   // bit 31 of the tap masks is never set: a dead tile stages zeros
-    s.soffx = s.live ? tap_off(pf_t) + pf_c * (kBK * 2) : 0;
-    s.soffw = s.live ? pf_s * (kBK * 2) : 0;
-    ++pf_s;
-    if (++pf_c == cin_steps) {
-      pf_c = 0;
-      ++pf_t;
+  // unit range of this workgroup: unit = tile * ksteps + k-step
+  const int ntiles = ((p.M + kBM - 1) / kBM) * ntn;
+  const unsigned U = (unsigned)ntiles * (unsigned)ksteps;          // U * nblk < 2^31 (checked by the host)
+  unsigned u = SK ? (U * (unsigned)bid) / (unsigned)nblk : (unsigned)bid * (unsigned)ksteps;
+  const unsigned u_end = SK ? (U * (unsigned)(bid + 1)) / (unsigned)nblk : u + (unsigned)ksteps;
+
+  int stamp_i = 0;
+  auto stamp = [&](int tag) {
+    if (PROF && SK && sk.dbg && threadIdx.x == 0 && stamp_i < 15) {
+      sk.dbg[(size_t)bid * 16 + stamp_i] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00FFFFFFFFFFFFFFull);
+      ++stamp_i;
     }
-    return s;
   };
-  // one half-tile (2 pieces of this wave): which = 0 pixels / 1 weights
-  auto issue_x = [&](const Slot& s, int h, int buf) {
-    char* dst = smem + buf * kSTAGE + h * kHALF + (2 * wid) * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) bufld16(rsrc_x, dst + i * 1024, ((a_valid[h][i] >> s.tap) & 1u) ? a_voff[h][i] : OOB_VOFF, s.soffx);
-  };
-  auto issue_w = [&](const Slot& s, int h, int buf) {
-    char* dst = smem + buf * kSTAGE + (2 + h) * kHALF + (2 * wid) * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) bufld16(rsrc_w, dst + i * 1024, s.live ? b_voff[h][i] : OOB_VOFF, s.soffw);
-  };
+  stamp(1);
+  while (u < u_end) {
+    const int tile = (int)(u / (unsigned)ksteps);
+    const int k0 = (int)(u - (unsigned)tile * (unsigned)ksteps);
+    const int k1 = min(ksteps, k0 + (int)(u_end - u));
+    u += (unsigned)(k1 - k0);
+    // lane-derived values are re-derived per segment from an opaque copy of the thread index: kept live across the main loop and
+    // the epilogue of every segment they cost registers the stream-K form does not have (the accumulators fill half the file)
+    int tid = tid0;
+    if (SK) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;     // waves 0-3 = pixel half 0, waves 4-7 = pixel half 1 (SIMD partners)
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int fsw = (fr >> 1) & 7;
+    const int mt = tile / ntn, nt = tile - mt * ntn;
+    const int m0 = mt * kBM, n0 = nt * kBN;
 
-  f32x4_t acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+    const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
+    const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
+    const srd_t rsrc_w = make_srd(p.w + (long long)n0 * Ktot, 0x7FFFFFF0u);
 
-  // ---- prologue: X0(0) W0(0) W1(0) X1(0) X0(1) W0(1), the steady-state issue order
-  Slot s1 = next_slot();          // tile 0
-  issue_x(s1, 0, 0);
-  issue_w(s1, 0, 0);
-  issue_w(s1, 1, 0);
-  issue_x(s1, 1, 0);
-  s1 = next_slot();               // tile 1
-  issue_x(s1, 0, 1);
-  issue_w(s1, 0, 1);
-  Slot s2 = next_slot();          // tile 2
-  wait_vm<8>();
-  bar();
-  if (wm == 1) bar();             // the second pixel half runs one barrier behind
+    // ---- rows this lane stages: per half h two pieces (8 rows of 128 B each); LDS row r' of a half <-> tile row
+    int a_voff[2][2], b_voff[2][2];
+    unsigned a_valid[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r2 = (2 * wid + i) * 8 + lrow;                  // row inside the half, 0..127
+        const int sw = ((h * 128 + r2) >> 1) & 7;
+        {
+          const int row = (r2 >> 6) * 128 + h * 64 + (r2 & 63);   // pixel row of the tile
+          const int m = m0 + row;
+          unsigned vm = 0;
+          int voff = OOB_VOFF;
+          if (p.lin_in) {
+            if (m < p.M) {
+              voff = ((m - n_first * p.Hin * p.Win) * p.ldin + (cpos ^ sw) * 8) * 2;
+              vm = 1u;
+            }
+          } else if (m < p.M) {
+            const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
+            const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
+            const int iy0 = yy * p.sin, ix0 = xx * p.sin;
+            voff = ((((n - n_first) * p.Hin + iy0) * p.Win + ix0) * p.ldin + (cpos ^ sw) * 8) * 2;
+#pragma unroll
+            for (int t = 0; t < MAX_TAPS; ++t) {
+              if (t >= p.T) break;
+              const int dyt = (int)((p.dy_pack >> (4 * t)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * t)) & 0xF) - 2;
+              const bool ok = (unsigned)(iy0 + dyt) < (unsigned)p.Hin && (unsigned)(ix0 + dxt) < (unsigned)p.Win;
+              vm |= ok ? (1u << t) : 0u;
+            }
+          }
+          a_voff[h][i] = voff;
+          a_valid[h][i] = vm;
+        }
+        {
+          const int row = (r2 >> 5) * 64 + h * 32 + (r2 & 31);    // channel row of the tile
+          b_voff[h][i] = (row * Ktot + (cpos ^ sw) * 8) * 2;
+        }
+      }
 
-  bf16x8_t xf[2][4][2], wf[2][2][2];    // [half][tile][k-substep]
-  auto read_x = [&](int h) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (xrd ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
-  };
-  auto read_w = [&](int h) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (wrd ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
-  };
-  auto mfma_q = [&](int hw, int hx) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          acc[hw * 2 + ii][hx * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
+    // ---- fragment read addresses (byte offsets into a k-step buffer, k-substep 0; substep 1 = ^64)
+    int xrd = (wm * 64 + fr) * kROWB + ((fq ^ fsw) << 4);                  // + h*kHALF + jj*16*kROWB
+    int wrd = 2 * kHALF + (wn * 32 + fr) * kROWB + ((fq ^ fsw) << 4);      // + h*kHALF + ii*16*kROWB
 
-  int buf = 0;
-  for (int t = 0; t < ksteps; ++t) {
-    // ---- phase 1
-    read_w(0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_x(0);
-    issue_w(s1, 1, buf ^ 1);
+    // scalar state of the k-steps being prefetched: tile t+1 (slot 1) and t+2 (slot 2)
+    auto tap_off = [&](int tap) {
+      const int dyt = (int)((p.dy_pack >> (4 * tap)) & 0xF) - 2, dxt = (int)((p.dx_pack >> (4 * tap)) & 0xF) - 2;
+      return ((dyt * p.Win + dxt) * p.ldin + p.tap_pad) * 2;
+    };
+    int pf_s = k0, pf_t = k0 / cin_steps, pf_c = k0 - pf_t * cin_steps;   // (k-step, tap, cin-step) of the NEXT k-step to set up
+    struct Slot { int tap, soffx, soffw, live; };
+    auto next_slot = [&]() {
+      Slot s;
+      s.live = pf_s < k1;
+      s.tap = s.live ? pf_t : 31;                   // bit 31 of the tap masks is never set: a dead k-step stages zeros
+      s.soffx = s.live ? tap_off(pf_t) + pf_c * (kBK * 2) : 0;
+      s.soffw = s.live ? pf_s * (kBK * 2) : 0;
+      ++pf_s;
+      if (++pf_c == cin_steps) {
+        pf_c = 0;
+        ++pf_t;
+      }
+      return s;
+    };
+    auto issue_x = [&](const Slot& s, int h, int buf) {
+      char* dst = smem + buf * kSTAGE + h * kHALF + (2 * wid) * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bufld16(rsrc_x, dst + i * 1024, ((a_valid[h][i] >> s.tap) & 1u) ? a_voff[h][i] : OOB_VOFF, s.soffx);
+    };
+    auto issue_w = [&](const Slot& s, int h, int buf) {
+      char* dst = smem + buf * kSTAGE + (2 + h) * kHALF + (2 * wid) * 1024;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bufld16(rsrc_w, dst + i * 1024, s.live ? b_voff[h][i] : OOB_VOFF, s.soffw);
+    };
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+    if (SK && k0 == 0 && k1 < ksteps) {
+      // ---- head part of a tile whose other k-steps live at the START of the next workgroups' ranges: begin from the sum of their
+      //      slabs (published long before this workgroup reaches the last segment of its range) instead of zero, in rank order.
+      //      Done here, before the main loop, because nothing else is live yet: after the loop the accumulators and the epilogue's
+      //      temporaries leave no registers for 32 loads in flight.
+      int covered = k1, nxt = bid + 1;
+      while (covered < ksteps && nxt < nblk) {
+        const unsigned nu0 = (U * (unsigned)nxt) / (unsigned)nblk, nu1 = (U * (unsigned)(nxt + 1)) / (unsigned)nblk;
+        if (nu1 == nu0) {           // a workgroup without units publishes nothing
+          ++nxt;
+          continue;
+        }
+        if (wid == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(sk.flags + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 22)) {       // ~seconds: the producer never ran; flag the launch instead of hanging
+              if (lane == 0) __hip_atomic_store(sk.flags + sk.nwg, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const f32x4_t* sl = (const f32x4_t*)(sk.slabs + (size_t)nxt * (8 * 32 * 64 * 4)) + (size_t)wid * 32 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] += sl[(i * TM + j) * 64];
+        covered += min(ksteps - covered, (int)(nu1 - nu0));
+        ++nxt;
+      }
+    }
+
+    // ---- prologue: X0(0) W0(0) W1(0) X1(0) X0(1) W0(1), the steady-state issue order
+    Slot s1 = next_slot();          // k-step k0
+    issue_x(s1, 0, 0);
+    issue_w(s1, 0, 0);
+    issue_w(s1, 1, 0);
+    issue_x(s1, 1, 0);
+    s1 = next_slot();               // k0 + 1
+    issue_x(s1, 0, 1);
+    issue_w(s1, 0, 1);
+    Slot s2 = next_slot();          // k0 + 2
     wait_vm<8>();
     bar();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_q(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    bar();
-    // ---- phase 2
-    read_w(1);
-    issue_x(s1, 1, buf ^ 1);
-    wait_vm<8>();
-    bar();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_q(1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    bar();
-    // ---- phase 3
-    read_x(1);
-    issue_x(s2, 0, buf);
-    wait_vm<8>();
-    bar();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_q(1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    bar();
-    // ---- phase 4
-    issue_w(s2, 0, buf);
-    wait_vm<8>();
-    bar();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_q(0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    bar();
-    s1 = s2;
-    s2 = next_slot();
-    buf ^= 1;
-    xrd ^= kSTAGE;
-    wrd ^= kSTAGE;
+    if (wm == 1) bar();             // the second pixel half runs one barrier behind
+
+    bf16x8_t xf[2][4][2], wf[2][2][2];    // [half][tile][k-substep]
+    auto read_x = [&](int h) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (xrd ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
+    };
+    auto read_w = [&](int h) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (wrd ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
+    };
+    auto mfma_q = [&](int hw, int hx) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            acc[hw * 2 + ii][hx * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    int buf = 0;
+    for (int t = k0; t < k1; ++t) {
+      // ---- phase 1
+      read_w(0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_x(0);
+      issue_w(s1, 1, buf ^ 1);
+      wait_vm<8>();
+      bar();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bar();
+      // ---- phase 2
+      read_w(1);
+      issue_x(s1, 1, buf ^ 1);
+      wait_vm<8>();
+      bar();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bar();
+      // ---- phase 3
+      read_x(1);
+      issue_x(s2, 0, buf);
+      wait_vm<8>();
+      bar();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bar();
+      // ---- phase 4
+      issue_w(s2, 0, buf);
+      wait_vm<8>();
+      bar();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_q(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bar();
+      s1 = s2;
+      s2 = next_slot();
+      buf ^= 1;
+      xrd ^= kSTAGE;
+      wrd ^= kSTAGE;
+    }
+    stamp(2);
+    if (wm == 0) bar();             // re-align the two halves
+    wait_vm<0>();                   // the zero-fill pieces of the dead k-steps
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    bar();                          // the epilogue reuses smem
+    stamp(7);
+
+    if (SK && k0 > 0) {
+      // ---- tail part of a tile whose head belongs to an earlier workgroup: hand the accumulators over.  Write-through (sc1) stores,
+      //      every storing wave drains, one lane publishes the epoch
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sk.slabs + (size_t)bid * (8 * 32 * 64 * 4)), 0, 8 * 32 * 64 * 16, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, (wid * 32 * 64 + lane) * 16, (i * TM + j) * 1024, 16);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(sk.flags + bid, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      stamp(3);
+      continue;
+    }
+    igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, 512, true, wm, wn, lane, mt, n0, m0);
+    stamp(8);
+    if (SK) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      bar();                        // the next segment's LDS-DMA overwrites the epilogue's staging area
+    }
+    stamp(6);
   }
-  if (wm == 0) bar();             // re-align the two halves
-  wait_vm<0>();                   // the zero-fill pieces of the dead tiles
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  bar();                          // the epilogue reuses smem
+}
 
-  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, 512, true, wm, wn, lane, mt, n0, m0);
+struct SkWorkspace {
+  float* slabs = nullptr;
+  unsigned* flags = nullptr;
+  unsigned epoch = 0;
+};
+unsigned long long* g_sk_dbg = nullptr;
+std::unordered_map<void*, SkWorkspace> g_sk_ws;       // per stream: launches on one stream are ordered, so they may share slabs
+constexpr int kNWG = 256;                             // one persistent workgroup per CU
+constexpr size_t kSlabFloats = 8 * 32 * 64 * 4;       // 256 KB of fp32 per workgroup
+
+int sk_workspace(hipStream_t st, SkWorkspace** out) {
+  auto it = g_sk_ws.find((void*)st);
+  if (it == g_sk_ws.end()) {
+    SkWorkspace w;
+    void* a = nullptr;
+    void* b = nullptr;
+    if (hipMalloc(&a, kNWG * kSlabFloats * sizeof(float)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMalloc(stream-K slabs) failed", "igemm8");
+    if (hipMalloc(&b, (kNWG + 16) * sizeof(unsigned)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMalloc(stream-K flags) failed", "igemm8");
+    if (hipMemset(b, 0, (kNWG + 16) * sizeof(unsigned)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMemset(stream-K flags) failed", "igemm8");
+    w.slabs = (float*)a;
+    w.flags = (unsigned*)b;
+    it = g_sk_ws.emplace((void*)st, w).first;
+  }
+  *out = &it->second;
+  return 0;
 }
 
 template <int EPI>
-int launch8(const IgemmParams& p, hipStream_t st) {
+int launch8(const IgemmParams& p, hipStream_t st, bool streamk) {
   const int gm = (p.M + kBM - 1) / kBM, gn = p.CoutPad / kBN;
-  auto k = igemm8_kernel<EPI>;
+  SkParams sk{};
+  if (streamk) {
+    SkWorkspace* w = nullptr;
+    if (int e = sk_workspace(st, &w)) return e;
+    if (++w->epoch == 0) w->epoch = 1;
+    sk.slabs = w->slabs;
+    sk.flags = w->flags;
+    sk.epoch = w->epoch;
+    sk.nwg = kNWG;
+    sk.dbg = g_sk_dbg;
+    auto k = igemm8_kernel<EPI, true>;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(k, dim3(kNWG), dim3(512), kLDS, st, p, sk);
+    return check_launch("igemm8_sk");
+  }
+  auto k = igemm8_kernel<EPI, false>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(512), kLDS, st, p);
+  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(512), kLDS, st, p, sk);
   return check_launch("igemm8");
 }
 
 }  // namespace
 
-bool igemm8_applicable(const IgemmParams& p) { return p.CoutPad % kBN == 0 && p.Cin % kBK == 0 && p.T >= 1 && p.T <= MAX_TAPS; }
+bool igemm8_applicable(const IgemmParams& p) {
+  if (!(p.CoutPad % kBN == 0 && p.Cin % kBK == 0 && p.T >= 1 && p.T <= MAX_TAPS)) return false;
+  const long long units = (long long)((p.M + kBM - 1) / kBM) * (p.CoutPad / kBN) * (p.T * p.Cin / kBK);
+  return units * kNWG < (1ll << 31);      // 32-bit unit arithmetic in the kernel
+}
 
-int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st) {
+void igemm8_set_dbg(unsigned long long* ptr) { g_sk_dbg = ptr; }
+
+// streamk: one persistent workgroup per CU over (tile, k-step) units instead of one workgroup per tile
+int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk) {
   if (!igemm8_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the phase-staggered kernel", "igemm8");
   switch (epi) {
-    case EPI_STATS: return launch8<EPI_STATS>(p, st);
-    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st);
-    case EPI_RES: return launch8<EPI_RES>(p, st);
-    case EPI_AFF: return launch8<EPI_AFF>(p, st);
+    case EPI_STATS: return launch8<EPI_STATS>(p, st, streamk);
+    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st, streamk);
+    case EPI_RES: return launch8<EPI_RES>(p, st, streamk);
+    case EPI_AFF: return launch8<EPI_AFF>(p, st, streamk);
     default: break;
   }
   return fail(MI355DET_EINVAL, "%s: epilogue not built for the phase-staggered kernel", "igemm8");

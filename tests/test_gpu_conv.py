@@ -530,7 +530,7 @@ def test_stride2_dgrad_single_launch_full_size():
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 3, 1), (2, 9, 11, 128, 256, 3, 1), (1, 20, 20, 512, 1024, 3, 1), (2, 40, 40, 256, 512, 3, 1),
                                   (3, 13, 13, 512, 256, 1, 1), (1, 26, 26, 256, 512, 3, 2), (2, 1, 1, 256, 256, 3, 1), (5, 2, 1, 64, 256, 3, 1),
-                                  (1, 8, 8, 768, 256, 1, 1), (4, 20, 20, 512, 512, 3, 1)])
+                                  (1, 8, 8, 768, 256, 1, 1), (4, 20, 20, 512, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (8, 80, 80, 128, 256, 3, 1)])
 def test_phase_staggered_kernel_matches_default(case):
     """Tile configuration 40 (igemm8_kernels.hip: 256x256x64, four phases per k-step, SIMD partners one barrier apart) against PyTorch fp32
     and the default configuration: forward (+ BN partial statistics), data gradient (+ residual); image edges, tile tails, one- and many-step K."""
@@ -550,7 +550,7 @@ def test_phase_staggered_kernel_matches_default(case):
     rows = ops.conv_stats_rows(shape)
     outs = {}
     try:
-        for cfg in (1, 40):
+        for cfg in (1, 40, 41):
             lib().mi355det_debug_set(0, cfg)
             y = torch.full((n, shape.ho, shape.wo, cout), 5.0, device=dev(), dtype=torch.bfloat16)
             stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())
@@ -566,10 +566,11 @@ def test_phase_staggered_kernel_matches_default(case):
     yr = y_ref.detach().permute(0, 2, 3, 1)
     gr = xr.grad.permute(0, 2, 3, 1)
     y1, st1, dx1, dxr1 = outs[1]
-    y8, st8, dx8, dxr8 = outs[40]
-    assert float((y8 - yr).abs().max()) <= 2e-2 * float(yr.abs().max())
-    assert float((dx8 - gr).abs().max()) <= 2e-2 * float(gr.abs().max())
-    assert float((y8 - y1).abs().max()) <= 1e-2 * float(y1.abs().max())
-    assert float((dx8 - dx1).abs().max()) <= 1e-2 * float(dx1.abs().max())
-    assert float((dxr8 - dxr1).abs().max()) <= 1e-2 * float(dxr1.abs().max())
-    torch.testing.assert_close(st8, st1, rtol=2e-2, atol=2e-2 * float(st1.abs().max()))
+    for cfg in (40, 41):              # 41 = the same kernel as one persistent workgroup per CU over (tile, k-step) units (stream-K)
+        y8, st8, dx8, dxr8 = outs[cfg]
+        assert float((y8 - yr).abs().max()) <= 2e-2 * float(yr.abs().max()), cfg
+        assert float((dx8 - gr).abs().max()) <= 2e-2 * float(gr.abs().max()), cfg
+        assert float((y8 - y1).abs().max()) <= 1e-2 * float(y1.abs().max()), cfg
+        assert float((dx8 - dx1).abs().max()) <= 1e-2 * float(dx1.abs().max()), cfg
+        assert float((dxr8 - dxr1).abs().max()) <= 1e-2 * float(dxr1.abs().max()), cfg
+        torch.testing.assert_close(st8, st1, rtol=2e-2, atol=2e-2 * float(st1.abs().max()))
