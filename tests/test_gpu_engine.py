@@ -170,7 +170,9 @@ def test_engine_end_to_end_vs_oracle(golden):
 
 
 def test_engine_golden_reference_outputs(golden):
-    """Against the REFERENCE modules' own outputs (fixture g8, 64 px): loose, bf16 through 40-75 chaotic layers."""
+    """Against the REFERENCE modules' own outputs (fixture g8, 64 px): loose, bf16 through 40-75 chaotic layers (2x2 maps: BN over 8
+    values).  The eval-mode half needs the same tolerance only because it runs on the ENGINE's running statistics, which that noisy
+    train-mode pass produced; test_engine_vs_reference_256px is the meaningful network-level comparison."""
     g = golden("g8_network")
     for bname in ("darknet_21", "darknet_53"):
         wseed, xseed, cseed, px, bs = [int(v) for v in g[bname + "_meta"]]
@@ -187,6 +189,54 @@ def test_engine_golden_reference_outputs(golden):
         for k, o in enumerate(ev):
             ref = torch.from_numpy(g[f"{bname}_evalout{k}"])
             assert rel(o.cpu(), ref) < 0.45, (bname, "eval", k, rel(o.cpu(), ref))
+
+
+def test_engine_vs_reference_256px(golden):
+    """Network-level parity at a size where it means something: the REFERENCE YoloHead (Darknet-53) at 256 px, batch 4 (fixture g8b).
+    * eval mode on the reference's own running statistics: every head within 3 % of its largest value (measured 1.1-2.0 %);
+    * train mode (batch statistics): bf16 STORAGE noise grows ~1.15x per layer through 75 train-mode BN layers, whoever does the arithmetic:
+      the fp32 oracle run with bf16-rounded storage is 0.12-0.23 (relative L2) away from the fp32 reference at the heads, and the engine
+      must stay within that envelope AT EVERY LAYER (engine error <= 1.3 x the storage-noise error + 0.003), i.e. it adds nothing of its own.
+    (The 64-px g8 test above needs 0.45 in eval mode only because its running statistics come from the engine's own train-mode pass over
+    2x2 maps - BN over 8 values - not from the reference: measured here, eval mode itself is 1-2 % accurate.)"""
+    from object_detectors_amd.yolo.nets.engine import bn_name
+    g = golden("g8b_network256")
+    wseed, xseed, px, bs = [int(v) for v in g["meta"]]
+    eng, sd = make_engine("darknet_53", wseed)
+    off = 0
+    for name, size in zip(g["bn_names"], g["bn_sizes"]):
+        sd[str(name) + ".running_mean"] = torch.from_numpy(g["running_mean"][off:off + int(size)].copy())
+        sd[str(name) + ".running_var"] = torch.from_numpy(g["running_var"][off:off + int(size)].copy())
+        off += int(size)
+    eng.load_reference_state_dict(sd)
+    x = detrand.uniform(xseed, (bs, 3, px, px), -2.0, 2.0)
+    xd = torch.from_numpy(x).to(dev())
+    ev = eng.forward(xd, training=False)
+    for k, o in enumerate(ev):
+        ref = torch.from_numpy(g[f"eval_out{k}"])
+        step = o.shape[-1] // 8
+        err = float((o.cpu()[:, :, ::step, ::step] - ref).abs().max()) / float(g[f"eval_out{k}_absmax"][0])
+        assert err < 0.03, ("eval", k, err)
+    # train mode: engine vs the reference, and layer by layer vs the fp32 oracle next to the storage-noise envelope
+    outs = eng.forward(xd, training=True)
+    torch.cuda.synchronize()
+    plan = eng._last_plan
+    rec32, rec16 = {}, {}
+    o32 = net_oracle.forward(sd, torch.from_numpy(x), "darknet_53", training=True, record=rec32)
+    o16 = net_oracle.forward(sd, torch.from_numpy(x), "darknet_53", training=True, quant=bf16q, record=rec16)
+    for k, o in enumerate(outs):
+        ref = torch.from_numpy(g[f"train_out{k}"])
+        step = o.shape[-1] // 8
+        assert rel(o32[k][:, :, ::step, ::step], ref) < 1e-3, k                   # the oracle IS the reference (fp32 both)
+        e_eng, e_q = rel(o.cpu(), o32[k]), rel(o16[k], o32[k])
+        assert e_eng < 1.3 * e_q + 3e-3 and e_eng < 0.35, ("train head", k, e_eng, e_q)
+    worst = 0.0
+    for name, r in plan.layers.items():
+        if r.get("res") is not None:
+            continue
+        e_eng, e_q = rel(view(r["a"]), rec32[name][1]), rel(rec16[name][1], rec32[name][1])
+        worst = max(worst, e_eng / (e_q + 1e-9))
+        assert e_eng < 1.3 * e_q + 3e-3, (name, e_eng, e_q)
 
 
 def test_yolohead_module_autograd_and_fused_step():

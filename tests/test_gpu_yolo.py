@@ -142,9 +142,12 @@ def test_nms_majority_gpu(golden):
             P = torch.from_numpy(g[n + "_in"].copy()).to(dev())
             out = helper.nms_majority(P, thr)
             assert np.array_equal(out.cpu().numpy(), g[key]), n + tag     # keep set, order, relabels: bit-exact
-            # in-place relabel of the input, like the reference (helper.py:374-375)
-            ref_in, _ = yo.nms_majority(g[n + "_in"], thr)
-            assert sorted(P[:, 5].cpu().numpy().tolist()) is not None
+            # in-place relabel of the INPUT, like the reference (helper.py:374-375: the kept row is a view of P): the kept rows of P carry
+            # the voted label afterwards, every other row and every other column is untouched
+            ref_rows, ref_keep = yo.nms_majority(g[n + "_in"], thr)
+            want_in = g[n + "_in"].copy()
+            want_in[ref_keep, 5] = ref_rows[:, 5]
+            assert np.array_equal(P.cpu().numpy(), want_in), n + tag
 
 
 def test_nms_majority_large_vs_oracle():

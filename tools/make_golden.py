@@ -367,6 +367,53 @@ def g8_network(yolohead, darknet):
     np.savez_compressed(os.path.join(OUT, "g8_network.npz"), **d)
 
 
+
+def g8b_network256(yolohead, darknet):
+    """Darknet-53 + YoloHead of the reference at 256 px, batch 4: the 8x8 / 16x16 / 32x32 maps give BatchNorm 256-4096 values per channel, so
+    the comparison can tell storage rounding from a defect (the 64-px g8 fixture cannot: BN over 8 values).  Train-mode outputs, the running
+    statistics the train-mode pass leaves behind (momentum 1.0 = the batch statistics themselves), and eval-mode outputs on those statistics.
+    Heads are stored on a spatial sub-grid (every head 8x8 positions) to keep the fixture small."""
+    d = {}
+    bname, fn, px, bs = "darknet_53", darknet.darknet53, 256, 4
+    yolohead.backbone_fn[bname] = (lambda f: (lambda path: f(None)))(fn)
+    cfg = {"backbone": {"backbone_name": bname, "backbone_pretrained": ""},
+           "dataset": {"anchors": COCO_ANCHORS}, "yolo": {"classes": 80},
+           "neck": {"fpn": False, "spp": False, "spp_bottleneck": True, "pyramids": []}}
+    torch.manual_seed(0)
+    m = yolohead.YoloHead(cfg)
+    det_weights(m, 5000)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.momentum = 1.0
+    x = detrand.uniform(4242, (bs, 3, px, px), -2.0, 2.0)
+    m.train()
+    with torch.no_grad():
+        outs = m(torch.from_numpy(x))
+    d["meta"] = np.array([5000, 4242, px, bs], np.int64)
+    for k, o in enumerate(outs):
+        step = o.shape[-1] // 8
+        d[f"train_out{k}"] = o[:, :, ::step, ::step].numpy().copy()
+        d[f"train_out{k}_absmax"] = np.array([float(o.abs().max())], np.float32)
+    names, rm, rv = [], [], []
+    for n, mod in m.named_modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            names.append(n)
+            rm.append(mod.running_mean.numpy().copy())
+            rv.append(mod.running_var.numpy().copy())
+    d["bn_names"] = np.array(names)
+    d["bn_sizes"] = np.array([len(a) for a in rm], np.int64)
+    d["running_mean"] = np.concatenate(rm)
+    d["running_var"] = np.concatenate(rv)
+    m.eval()
+    with torch.no_grad():
+        eo = m(torch.from_numpy(x))
+    for k, o in enumerate(eo):
+        step = o.shape[-1] // 8
+        d[f"eval_out{k}"] = o[:, :, ::step, ::step].numpy().copy()
+        d[f"eval_out{k}_absmax"] = np.array([float(o.abs().max())], np.float32)
+    np.savez_compressed(os.path.join(OUT, "g8b_network256.npz"), **d)
+
+
 # ----------------------------------------------------------------------------- torchvision_models side
 def import_tvision():
     for k in [k for k in sys.modules if k == "utilities" or k.startswith("utilities.")]:
@@ -644,18 +691,32 @@ def g13_frcnn():
 
 
 def main():
+    """python tools/make_golden.py [fixture ...]   (no argument: all; names = the npz stems, e.g. g8b_network256)"""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only  # noqa: E731
     helper, custom, yolo_forw, yolohead, darknet = import_yolo()
-    g1_bbox_iou(helper)
-    g2_nms_majority(helper)
-    g9_focal(custom)
-    g3_yolo(helper, custom, yolo_forw)
-    g11_postproc(helper, custom, yolo_forw)
-    g8_network(yolohead, darknet)
-    g5_7_tvision()
-    g12_retinanet()
-    g13_frcnn()
+    if want("g1_bbox_iou"):
+        g1_bbox_iou(helper)
+    if want("g2_nms_majority"):
+        g2_nms_majority(helper)
+    if want("g9_focal"):
+        g9_focal(custom)
+    if want("g3_yolo_forw"):
+        g3_yolo(helper, custom, yolo_forw)
+    if want("g11_postproc"):
+        g11_postproc(helper, custom, yolo_forw)
+    if want("g8_network"):
+        g8_network(yolohead, darknet)
+    if want("g8b_network256"):
+        g8b_network256(yolohead, darknet)
+    if want("g5_7_tvision"):
+        g5_7_tvision()
+    if want("g12_retinanet"):
+        g12_retinanet()
+    if want("g13_frcnn"):
+        g13_frcnn()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
