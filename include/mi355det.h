@@ -368,6 +368,21 @@ int mi355det_adam_step(float* w, float* g, float* exp_avg, float* exp_avg_sq, in
                        void* stream);
 
 
+/* ---- Fast R-CNN box-head loss (csrc/frcnn_kernels.hip) ------------------------------------------------------------------
+ * Replaces `fastrcnn_loss` (torchvision_models/tvision/roi_heads.py:24-96) as RoIHeads.forward calls it (:826-827):
+ *   fastrcnn_loss(tfidf * class_logits, box_regression, labels, regression_targets, weights=classification_weights, loss_type)
+ * class_logits [n,k] fp32, box_regression [n,4k], labels [n] int64 (0 = background), regression_targets [n,4];
+ * class_scale [k] or NULL = the tf-idf row multiplied into the logits; class_weights [k] or NULL ('ce' only);
+ * loss_type 0 'ce', 1 'bce', 2 'focal_loss', 3 'gombit' (incl. its "/4 above 5" branch), 4 'gombit_fl'.
+ * losses [2] = (loss_classifier, loss_box_reg); grad_logits [n,k] / grad_box [n,4k] (nullable) = d(loss_classifier)/d(class_logits)
+ * (UNSCALED logits) and d(loss_box_reg)/d(box_regression).  Deterministic (no atomics).  Returns EINVAL for n < 1, k < 2, a loss_type
+ * outside 0..4 or class weights with a loss other than 'ce'. */
+size_t mi355det_fastrcnn_loss_workspace(int32_t n);
+int mi355det_fastrcnn_loss(const float* class_logits, const float* box_regression, const int64_t* labels,
+                           const float* regression_targets, const float* class_scale, const float* class_weights, int32_t n,
+                           int32_t k, int32_t loss_type, float* losses, float* grad_logits, float* grad_box, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* layout / dtype converters at the module boundary */
 int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h,
                               int32_t w, float* out, void* stream);

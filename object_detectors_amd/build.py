@@ -22,6 +22,7 @@ SOURCES = [
     ("yolo_kernels.hip", ["-ffp-contract=off"]),
     ("box_kernels.hip", ["-ffp-contract=off"]),
     ("roi_kernels.hip", ["-ffp-contract=off"]),
+    ("frcnn_kernels.hip", ["-ffp-contract=off"]),
     ("resnet_kernels.hip", []),
     ("conv_kernels.hip", []),
     ("igemm8_kernels.hip", []),

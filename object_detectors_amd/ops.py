@@ -442,3 +442,29 @@ def roi_align_nhwc(feats, rois, output_size, scales, sampling_ratio=2, aligned=F
     check(lib().mi355det_roi_align_nhwc(P, hs, ws, lds, sc, nl, ptr(rois), K, Cc, ph, pw, int(sampling_ratio), int(aligned), k_min, k_max,
                                         None, ptr(g), G, stream_ptr()), "roi_align_nhwc_bwd")
     return dfs
+
+
+FRCNN_LOSS_TYPES = {"ce": 0, "bce": 1, "focal_loss": 2, "gombit": 3, "gombit_fl": 4}
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, class_scale=None, class_weights=None, loss_type="ce", want_grad=True):
+    """roi_heads.py:24-96 (+ the tf-idf scaling of its call site :826-827) -> (losses [2], grad_logits, grad_box)."""
+    if loss_type not in FRCNN_LOSS_TYPES:
+        raise ValueError(f"fastrcnn_loss: unknown loss_type {loss_type!r} (reference: 'ce', 'bce', 'focal_loss', 'gombit', 'gombit_fl')")
+    x, b = _f32c(class_logits), _f32c(box_regression)
+    n, k = x.shape
+    if b.shape != (n, 4 * k):
+        raise ValueError("fastrcnn_loss: box_regression must be [n, 4*k]")
+    lab = labels.to(torch.int64).contiguous()
+    tgt = _f32c(regression_targets)
+    cs = None if class_scale is None else _f32c(class_scale.reshape(-1))
+    cw = None if class_weights is None else _f32c(class_weights.reshape(-1))
+    L = lib()
+    wsb = L.mi355det_fastrcnn_loss_workspace(n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    losses = torch.empty(2, dtype=torch.float32, device=x.device)
+    gl = torch.empty_like(x) if want_grad else None
+    gb = torch.empty_like(b) if want_grad else None
+    check(L.mi355det_fastrcnn_loss(ptr(x), ptr(b), ptr(lab), ptr(tgt), ptr(cs), ptr(cw), n, k, FRCNN_LOSS_TYPES[loss_type], ptr(losses), ptr(gl),
+                                   ptr(gb), ptr(ws), wsb, stream_ptr()), "fastrcnn_loss")
+    return losses, gl, gb

@@ -89,6 +89,51 @@ class GradSync:
         self.buckets = buckets
 
 
+class ParamGradSync:
+    """Gradient averaging for ordinary torch parameters that live OUTSIDE an engine's flat buffer: the TwoMLPHead / FastRCNNPredictor of
+    `tvision.frcnn.FasterRCNN` (`model.head_parameters()`; torch DDP covers them in the reference, detection/train.py:160).  Their
+    gradients are produced by autograd before the engine's backward starts, so ONE flattened all-reduce right after `loss.backward()` runs
+    under the whole backbone backward:
+
+        sync = GradSync(model.engine.flat_g); sync.install(plan)         # backbone + RPN
+        hsync = ParamGradSync(model.head_parameters())                   # box head
+        losses = model(images, targets); hsync.reduce(); sync.wait(); hsync.wait()
+    """
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.flat = None
+        self.handle = None
+
+    def reduce(self):
+        if self.world == 1 or not self.params:
+            return
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        self.flat = torch.cat([g.reshape(-1) for g in grads])
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        self.handle = dist.all_reduce(self.flat, op=op, group=self.group, async_op=True)
+
+    def wait(self):
+        if self.handle is None:
+            return
+        self.handle.wait()
+        self.handle = None
+        if not self.use_avg:
+            self.flat.div_(self.world)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+
 def step_stream(device):
     """High-priority stream for the training step's dependency chain.  Make it current (`torch.cuda.set_stream` or
     `with torch.cuda.stream(...)`) BEFORE the engine builds its plan: plans bind their launches to the stream that is current

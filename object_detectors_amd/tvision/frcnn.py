@@ -24,7 +24,7 @@ from ._utils import BoxCoder
 from .engine import FasterRCNNEngine
 from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals
 from .roi_align import MultiScaleRoIAlign
-from .roi_heads import RoIHeadTargets, fastrcnn_loss
+from .roi_heads import RoIHeadTargets, fastrcnn_loss, minibatch_tfidf
 from .rpn import RPNTargets
 
 
@@ -77,8 +77,29 @@ class FasterRCNN(nn.Module):
         self.box_predictor = FastRCNNPredictor(1024, num_classes).to(dev)
         self.box_score_thresh, self.box_nms_thresh, self.box_detections_per_img = box_score_thresh, box_nms_thresh, box_detections_per_img
         self.bbox_reg_weights = weights
-        self.loss_type = loss_type
-        self.tfidf_post = 1.0 if tfidf is None else tfidf["values"].to(dev).float()
+        # ---- the tf-idf state of the reference RoIHeads (roi_heads.py:566-572; the dict is built in detection/train.py:103-135):
+        #      'values' [1,K] row multiplied into the class logits (training: self.tfidf, replaced per batch when 'mini_batch'; inference:
+        #      the untouched copy tfidf_post), 'classification_weights' [K] or None (cross-entropy class weights), 'loss_function'
+        if tfidf is None:
+            tfidf = {}
+        unknown = set(tfidf) - {"values", "num_classes", "mini_batch", "tfidf_norm", "loss_function", "classification_weights"}
+        if unknown:
+            raise ValueError(f"FasterRCNN: unsupported tfidf fields {sorted(unknown)}")
+        if tfidf.get("num_classes", num_classes) != num_classes:
+            raise ValueError("FasterRCNN: tfidf['num_classes'] differs from num_classes")
+        values = tfidf.get("values")
+        values = torch.ones(1, num_classes) if values is None else values
+        self.tfidf = values.detach().to(dev).float().reshape(1, num_classes)
+        self.tfidf_post = self.tfidf.clone()
+        self.tfidf_mini_batch = bool(tfidf.get("mini_batch", False))
+        self.tfidf_norm = tfidf.get("tfidf_norm", 0)
+        self.loss_function_name = tfidf.get("loss_function", loss_type)
+        if self.loss_function_name not in ops.FRCNN_LOSS_TYPES:
+            raise ValueError(f"FasterRCNN: unknown loss function {self.loss_function_name!r} (reference: {sorted(ops.FRCNN_LOSS_TYPES)})")
+        cw = tfidf.get("classification_weights")
+        self.classification_weights = None if cw is None else cw.detach().to(dev).float()
+        self.loss_type = self.loss_function_name
+        self.num_classes = num_classes
         self.rpn_coder = BoxCoder((1.0, 1.0, 1.0, 1.0))
 
     def head_parameters(self):
@@ -126,6 +147,8 @@ class FasterRCNN(nn.Module):
                     raise ValueError("All bounding boxes should have positive height and width.")
         n = images.shape[0]
         image_shapes = [(images.shape[-2], images.shape[-1])] * n
+        if targets is not None and self.tfidf_mini_batch:         # roi_heads.py:801-809
+            self.tfidf = minibatch_tfidf(targets, self.num_classes, self.tfidf_norm).to(images.device).float().reshape(1, -1)
         out = self.engine.forward(images, training=self.training)
         plan = self.engine._last_plan
         boxes, _scores = self._proposals(out, plan, image_shapes)
@@ -145,10 +168,14 @@ class FasterRCNN(nn.Module):
         proposals, _mi, labels, reg_targets = self.roi_targets.select_training_samples([b.detach() for b in boxes], targets)
         x = self.box_roi_pool.forward_nhwc(feats, proposals, image_shapes)
         cls, reg = self.box_predictor(self.box_head(x))
-        loss_cls, loss_box = fastrcnn_loss(cls, reg, labels, reg_targets, loss_type=self.loss_type)
+        # roi_heads.py:826-827: fastrcnn_loss(self.tfidf * class_logits, ..., weights=self.classification_weights, loss_type=...)
+        loss_cls, loss_box = fastrcnn_loss(cls, reg, labels, reg_targets, weights=self.classification_weights, loss_type=self.loss_function_name,
+                                           class_scale=self.tfidf)
         losses = {"loss_classifier": loss_cls, "loss_box_reg": loss_box}
         losses.update(rpn_losses)
         sum(losses.values()).backward()
+        if getattr(self, "head_grad_sync", None) is not None:     # data parallel: parallel.ParamGradSync over head_parameters(), overlapped with
+            self.head_grad_sync.reduce()                          # the whole backbone backward below
         self.engine.backward(obj.grad, dl.grad, [f.grad for f in feats])
         return {k: v.detach() for k, v in losses.items()}
 

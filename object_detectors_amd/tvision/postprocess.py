@@ -94,11 +94,46 @@ def roi_heads_postprocess_detections(class_logits, box_regression, proposals, im
         boxes, scores, labels = boxes[inds], scores[inds], labels[inds]
         keep = box_ops.remove_small_boxes(boxes, 1e-2)
         boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
-        if boxes.shape[0] > 16384:   # NMS kernel capacity: keep the best 16384 candidates (sorted anyway by NMS)
-            _v, top, _c = ops.topk_rows(scores.reshape(1, -1), 16384)
-            boxes, scores, labels = boxes[top[0]], scores[top[0]], labels[top[0]]
-        keep = box_ops.batched_nms(boxes, scores, labels, nms_thresh)[:detections_per_img]
-        out_b.append(boxes[keep])
-        out_s.append(scores[keep])
-        out_l.append(labels[keep])
+        kb, ks, kl = batched_nms_topn(boxes, scores, labels, nms_thresh, detections_per_img)
+        out_b.append(kb)
+        out_s.append(ks)
+        out_l.append(kl)
     return out_b, out_s, out_l
+
+
+NMS_CAPACITY = 16384     # boxes per launch of the NMS kernels (include/mi355det.h)
+
+
+def batched_nms_topn(boxes, scores, labels, nms_thresh, top_n, capacity=NMS_CAPACITY):
+    """boxes[keep], scores[keep], labels[keep] for keep = batched_nms(boxes, scores, labels, nms_thresh)[:top_n] (roi_heads.py:771-774), for ANY
+    number of candidates (LVIS: 1000 proposals x 1203 classes).  Greedy NMS only ever lets a HIGHER-scoring kept box suppress a lower one, so
+    the candidates can be consumed in descending-score chunks: the survivors of the best `capacity` candidates are final, and if there are at
+    least top_n of them the rest cannot enter the result.  Otherwise the next chunk is judged together with ALL survivors so far (fewer than
+    top_n, so they fit beside it).  Exact, not a truncation."""
+    n = boxes.shape[0]
+    if top_n >= capacity:
+        raise ValueError(f"batched_nms_topn: top_n must be below the NMS capacity ({capacity})")
+    if n <= capacity:
+        keep = box_ops.batched_nms(boxes, scores, labels, nms_thresh)[:top_n]
+        return boxes[keep], scores[keep], labels[keep]
+    # the per-category coordinate offsets of batched_nms depend on the largest coordinate of the set it is given: fix them once for the
+    # whole candidate set, as a single call over all candidates would
+    off = labels.to(boxes) * (boxes.max() + 1)
+    shifted = boxes + off[:, None]
+    remaining = scores.clone()
+    kept_idx = torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    taken = 0
+    while taken < n:
+        room = capacity - kept_idx.numel()
+        k = min(room, n - taken)
+        _v, idx, _c = ops.topk_rows(remaining.reshape(1, -1), k)      # next k best (descending score, ties by index)
+        chunk = idx[0]
+        remaining[chunk] = float("-inf")
+        taken += k
+        cand = torch.cat([kept_idx, chunk])                            # survivors first: they outrank the chunk and never suppress each other
+        keep = ops.nms(shifted[cand], scores[cand], nms_thresh)
+        kept_idx = cand[keep]
+        if kept_idx.numel() >= top_n:
+            break
+    kept_idx = kept_idx[:top_n]
+    return boxes[kept_idx], scores[kept_idx], labels[kept_idx]

@@ -1,40 +1,58 @@
 """Training-side mirrors of `RoIHeads` (tvision/roi_heads.py) over the HIP kernels.
 
-  fastrcnn_loss                 roi_heads.py:22-98     'ce' | 'bce' | 'focal_loss' (the gombit variants are not on this path)
+  fastrcnn_loss                 roi_heads.py:22-98     'ce' | 'bce' | 'focal_loss' | 'gombit' | 'gombit_fl', fused forward + gradients (mi355det_fastrcnn_loss)
+  minibatch_tfidf               roi_heads.py:801-809   per-batch smoothed idf row
   assign_targets_to_proposals   roi_heads.py:627-651   fused box_iou + Matcher(0.5, 0.5) per image
   select_training_samples       roi_heads.py:688-713   + add_gt_proposals, sampler (torch, row a19), BoxCoder(10,10,5,5).encode
   postprocess_detections        roi_heads.py:715-781   -> tvision/postprocess.py:roi_heads_postprocess_detections
   box_roi_pool                  roi_heads.py:818       -> tvision/roi_align.py:MultiScaleRoIAlign
 """
 import torch
-import torch.nn.functional as F
+
+from .. import ops
 
 from ._utils import BalancedPositiveNegativeSampler, BoxCoder, Matcher
-from .focal_loss import sigmoid_focal_loss
 
 
-def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, weights=None, loss_type="ce"):
+class _FastRCNNLossFn(torch.autograd.Function):
+    """Forward and both gradients come out of ONE kernel launch sequence (csrc/frcnn_kernels.hip); backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, class_logits, box_regression, labels, regression_targets, class_scale, class_weights, loss_type):
+        losses, gl, gb = ops.fastrcnn_loss(class_logits, box_regression, labels, regression_targets, class_scale, class_weights, loss_type, want_grad=True)
+        ctx.save_for_backward(gl, gb)
+        return losses[0], losses[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box):
+        gl, gb = ctx.saved_tensors
+        return gl * g_cls, gb * g_box, None, None, None, None, None
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets, weights=None, loss_type="ce", class_scale=None):
+    """roi_heads.py:24-96: (classification_loss, box_loss) for loss_type 'ce' | 'bce' | 'focal_loss' | 'gombit' | 'gombit_fl'.
+
+    The reference multiplies the tf-idf row into the logits at the call site (:826-827 `fastrcnn_loss(self.tfidf * class_logits, ...)`);
+    pass that row as `class_scale` to have the kernel apply it (the returned gradient is w.r.t. the unscaled logits), or pre-multiply and
+    leave it None, as the reference's callers do."""
     labels = torch.cat(labels, dim=0)
-    bs = labels.shape[0]
     regression_targets = torch.cat(regression_targets, dim=0)
-    if loss_type == "ce":
-        classification_loss = F.cross_entropy(class_logits, labels, weight=weights)
-    else:
-        y = torch.zeros_like(class_logits)
-        y.scatter_(1, labels.unsqueeze(1), 1)
-        y[:, 0] = 0.0
-        if loss_type == "bce":
-            classification_loss = F.binary_cross_entropy_with_logits(class_logits, y, reduction="sum") / bs
-        elif loss_type == "focal_loss":
-            classification_loss = sigmoid_focal_loss(class_logits, y, reduction="sum") / bs
-        else:
-            raise NotImplementedError(f"loss_type {loss_type!r}: only 'ce', 'bce', 'focal_loss' are on the accelerated path")
-    pos = torch.nonzero(labels > 0).squeeze(1)
-    labels_pos = labels[pos]
-    n = class_logits.shape[0]
-    box_regression = box_regression.reshape(n, -1, 4)
-    box_loss = F.smooth_l1_loss(box_regression[pos, labels_pos], regression_targets[pos], reduction="sum") / labels.numel()
-    return classification_loss, box_loss
+    if loss_type not in ops.FRCNN_LOSS_TYPES:
+        raise ValueError(f"fastrcnn_loss: unknown loss_type {loss_type!r}")
+    if weights is not None and loss_type != "ce":
+        weights = None                     # the reference passes `weights` along but only F.cross_entropy reads it (roi_heads.py:45-46)
+    return _FastRCNNLossFn.apply(class_logits, box_regression, labels, regression_targets, class_scale, weights, loss_type)
+
+
+def minibatch_tfidf(targets, num_classes, tfidf_norm=0):
+    """roi_heads.py:801-809: smoothed idf of the classes present in this mini-batch, optionally p-normalised ([num_classes] float)."""
+    w = torch.stack([torch.bincount(t["labels"], minlength=num_classes) for t in targets])
+    w[w > 0] = 1
+    w = w.sum(axis=0)
+    w = torch.log((len(targets) + 1) / (w + 1)) + 1
+    if tfidf_norm != 0:
+        w = w / torch.norm(w, p=tfidf_norm)
+    return w
 
 
 class RoIHeadTargets:

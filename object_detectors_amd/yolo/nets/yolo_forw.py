@@ -5,6 +5,7 @@ Same call signature and return values as the reference (`YOLOForw(out, targets=N
 terms, their gradients and the decode are fused HIP kernels that read the head tensors in place.
 """
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -126,7 +127,9 @@ class YOLOForw(nn.Module):
         hv, keep = ops.head_views(heads, len(self.anchors[0]) * self.bbox_attrs)
         out, score, label = ops.yolo_decode(geom, hv, self._idf(keep[0].device), keep[0].shape[0], softmax_cls=True, want_scores=True)
         # conf*max(cls) / arg-max from the same pass (channels-last heads), picked up by procedures.test_one_epoch.postprocess
-        self.last_decode_scores = (out.data_ptr(), score, label) if score is not None else None
+        # keyed on the tensor OBJECT (weak reference) and its version counter, not on its address: the caching allocator hands a freed block's
+        # address to the next tensor of the same size, which would otherwise match a stale entry
+        self.last_decode_scores = (weakref.ref(out), out._version, score, label) if score is not None else None
         return out
 
     def get_target(self, targets, grids, device=None):

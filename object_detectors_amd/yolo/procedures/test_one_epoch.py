@@ -12,8 +12,9 @@ def postprocess(predictions, confidence=0.1, iou_threshold=0.6, num_classes=None
     num_classes = num_classes or (attrs - 5)
     score = label = None
     fused = getattr(criterion, "last_decode_scores", None) if criterion is not None else None
-    if fused is not None and fused[0] == predictions.data_ptr():
-        score, label = fused[1], fused[2]       # computed by the decode kernel: the 85-wide rows are not re-read
+    if fused is not None and fused[0]() is predictions and fused[1] == predictions._version:
+        score, label = fused[2], fused[3]       # computed by the decode kernel for THIS tensor, unmodified since: the 85-wide rows are not re-read
+        criterion.last_decode_scores = None     # consumed
     cand, count = ops.yolo_candidates(predictions, confidence, score=score, label=label)
     counts = count.tolist()                     # one host sync for the ragged python-list output
     if max(counts) > cand.shape[1]:

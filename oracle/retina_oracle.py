@@ -27,7 +27,11 @@ ANCHOR_SIZES = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x
 ASPECT_RATIOS = ((0.5, 1.0, 2.0),) * 5
 
 
-def body_keys(prefix="backbone.body."):
+BODY_LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}      # utilities/resnet.py:292-313
+
+
+def body_keys(prefix="backbone.body.", layers=None):
+    layers = layers or LAYERS
     out = []
 
     def conv(name, cout, cin, k):
@@ -39,7 +43,7 @@ def body_keys(prefix="backbone.body."):
     conv("conv1", 64, 3, 7)
     bn("bn1", 64)
     inpl = 64
-    for li, (planes, nb) in enumerate(zip(PLANES, LAYERS), 1):
+    for li, (planes, nb) in enumerate(zip(PLANES, layers), 1):
         for b in range(nb):
             q = f"layer{li}.{b}"
             conv(q + ".conv1", planes, inpl, 1)
@@ -78,8 +82,9 @@ def head_keys(num_classes=91, num_anchors=9, prefix="head."):
     return out
 
 
-def state_keys(num_classes=91, num_anchors=9):
-    return body_keys() + fpn_keys() + head_keys(num_classes, num_anchors)
+def state_keys(num_classes=91, num_anchors=9, body="resnet50"):
+    """`body` = "resnet101" composes BASELINE config 5 (resnet_fpn_backbone('resnet101', ...) + RetinaNet(backbone, 1204))."""
+    return body_keys(layers=BODY_LAYERS[body]) + fpn_keys() + head_keys(num_classes, num_anchors)
 
 
 def det_fill(key, shape, seed):
@@ -105,9 +110,9 @@ def det_fill(key, shape, seed):
     return detrand.uniform(seed, shape, -s, s)
 
 
-def det_state(seed, num_classes=91, num_anchors=9, keys=None):
+def det_state(seed, num_classes=91, num_anchors=9, keys=None, body="resnet50"):
     sd = {}
-    for i, (k, shp) in enumerate(keys or state_keys(num_classes, num_anchors)):
+    for i, (k, shp) in enumerate(keys or state_keys(num_classes, num_anchors, body)):
         sd[k] = torch.from_numpy(np.ascontiguousarray(det_fill(k, shp, seed + i)))
     return sd
 
@@ -135,9 +140,11 @@ def body_forward(sd, x, prefix="backbone.body."):
     x = F.relu(frozen_bn(F.conv2d(x, sd[prefix + "conv1.weight"], stride=2, padding=3), sd, prefix + "bn1"))
     x = F.max_pool2d(x, 3, 2, 1)
     feats = []
-    for li, nb in enumerate(LAYERS, 1):
-        for b in range(nb):
+    for li in range(1, 5):
+        b = 0
+        while f"{prefix}layer{li}.{b}.conv1.weight" in sd:      # block counts from the state dict: 3/4/6/3 (R50), 3/4/23/3 (R101)
             x = bottleneck(x, sd, f"{prefix}layer{li}.{b}", 2 if (b == 0 and li > 1) else 1)
+            b += 1
         feats.append(x)
     return feats
 

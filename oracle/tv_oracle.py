@@ -288,23 +288,106 @@ def roi_assign(proposals, gt_boxes, gt_labels, high=0.5, low=0.5):
     return np.clip(m, 0, None), lab
 
 
-def fastrcnn_loss(class_logits, box_regression, labels, reg_targets, loss_type="ce"):
+def fastrcnn_loss(class_logits, box_regression, labels, reg_targets, loss_type="ce", weights=None, want_grad=False):
+    """roi_heads.py:24-96 on logits that already carry the tf-idf row (the caller multiplies, as roi_heads.py:826-827 does).
+    float64 inside.  -> (cls_loss, box_loss) or, with want_grad, (cls_loss, box_loss, d cls / d logits, d box / d box_regression)."""
     x = class_logits.astype(np.float64)
     n, k = x.shape
+    rows = np.arange(n)
     if loss_type == "ce":
         mx = x.max(1, keepdims=True)
-        lse = mx[:, 0] + np.log(np.exp(x - mx).sum(1))
-        cls = (lse - x[np.arange(n), labels]).mean()
+        se = np.exp(x - mx).sum(1)
+        lse = mx[:, 0] + np.log(se)
+        w = np.ones(n) if weights is None else np.asarray(weights, np.float64)[labels]
+        cls = (w * (lse - x[rows, labels])).sum() / w.sum()                        # F.cross_entropy(weight=..., reduction='mean')
+        g = np.exp(x - mx) / se[:, None]
+        g[rows, labels] -= 1.0
+        g *= (w / w.sum())[:, None]
     else:
         y = np.zeros_like(x)
-        y[np.arange(n), labels] = 1.0
+        y[rows, labels] = 1.0
         y[:, 0] = 0.0
+        p = 1.0 / (1.0 + np.exp(-x))
+        bce = np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))
         if loss_type == "bce":
-            cls = (np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))).sum() / n
+            cls = bce.sum() / n
+            g = (p - y) / n
+        elif loss_type == "focal_loss":
+            pt = p * y + (1 - p) * (1 - y)
+            at = 0.25 * y + 0.75 * (1 - y)
+            cls = (at * bce * (1 - pt) ** 2).sum() / n
+            dpt = (2 * y - 1) * p * (1 - p)
+            g = at * ((1 - pt) ** 2 * (p - y) - 2 * (1 - pt) * dpt * bce) / n
+        elif loss_type.startswith("gombit"):
+            u = x - 1.96                                                            # :59-61
+            c = np.clip(u, -3, 5)
+            passg = (u >= -3) & (u <= 5)
+            e = np.exp(-c)
+            pe = np.exp(-e)                                                         # 1 / exp(exp(-c))
+            b = np.where(y > 0.5, e, -np.log(1 - pe))                               # F.binary_cross_entropy(pestim, y)
+            db = np.where(y > 0.5, -1 / pe, 1 / (1 - pe))
+            dpe = pe * e
+            if loss_type.endswith("fl"):
+                pt = pe * y + (1 - pe) * (1 - y)
+                at = 0.25 * y + 0.75 * (1 - y)
+                cls = (at * b * (1 - pt) ** 2).sum() / n
+                g = at * (2 * (1 - pt) * (-(2 * y - 1)) * b + (1 - pt) ** 2 * db) * dpe / n
+            else:
+                cls = b.sum() / n
+                g = db * dpe / n
+                if cls > 5:                                                         # :71-72
+                    cls, g = cls / 4, g / 4
+            g = np.where(passg, g, 0.0)
         else:
-            l, _ = sigmoid_focal_loss(class_logits.astype(F32), y.astype(F32))
-            cls = l.astype(np.float64).sum() / n
+            raise ValueError(loss_type)
     pos = np.nonzero(labels > 0)[0]
     br = box_regression.reshape(n, -1, 4)
     box = smooth_l1_sum(br[pos, labels[pos]], reg_targets[pos], 1.0) / labels.size
-    return F32(cls), F32(box)
+    if not want_grad:
+        return F32(cls), F32(box)
+    gb = np.zeros(br.shape, np.float64)
+    d = br[pos, labels[pos]].astype(np.float64) - reg_targets[pos].astype(np.float64)
+    gb[pos, labels[pos]] = np.where(np.abs(d) < 1.0, d, np.sign(d)) / labels.size
+    return F32(cls), F32(box), g, gb.reshape(n, -1)
+
+
+def minibatch_tfidf(label_lists, num_classes, norm=0):
+    """roi_heads.py:801-809."""
+    w = np.stack([np.bincount(np.asarray(l), minlength=num_classes) for l in label_lists])
+    w = (w > 0).sum(0).astype(np.float64)
+    w = np.log((len(label_lists) + 1) / (w + 1)) + 1
+    if norm != 0:
+        w = w / np.linalg.norm(w, ord=norm)
+    return w.astype(F32)
+
+
+def roi_postprocess_detections(class_logits, box_regression, proposals, image_shapes, tfidf_post=1.0, loss_type="ce", score_thresh=0.05,
+                               nms_thresh=0.5, detections_per_img=100, weights=(10.0, 10.0, 5.0, 5.0)):
+    """RoIHeads.postprocess_detections (roi_heads.py:715-781) -> list of (boxes [d,4], scores [d], labels [d]) per image."""
+    x = np.asarray(tfidf_post, F32) * class_logits.astype(F32)
+    if loss_type == "ce":
+        z = x - x.max(-1, keepdims=True)
+        ez = np.exp(z)
+        scores = (ez / ez.sum(-1, keepdims=True)).astype(F32)
+    elif loss_type.startswith("gombit"):
+        scores = (1 / (np.exp(np.exp(-np.asarray(tfidf_post, F32) * (class_logits.astype(F32) - F32(1.96)))))).astype(F32)
+    else:
+        scores = (1 / (1 + np.exp(-x))).astype(F32)
+    k = class_logits.shape[-1]
+    out, off = [], 0
+    for props, shape in zip(proposals, image_shapes):
+        r = len(props)
+        codes = box_regression[off:off + r].reshape(r * k, 4)
+        boxes = decode_boxes(codes, np.repeat(np.asarray(props, F32), k, 0), weights).reshape(r, k, 4)
+        sc = scores[off:off + r]
+        off += r
+        boxes = clip_boxes_to_image(boxes, shape)
+        labels = np.broadcast_to(np.arange(k)[None, :], sc.shape)
+        boxes, sc, labels = boxes[:, 1:].reshape(-1, 4), sc[:, 1:].reshape(-1), labels[:, 1:].reshape(-1)
+        inds = np.nonzero(sc > F32(score_thresh))[0]
+        boxes, sc, labels = boxes[inds], sc[inds], labels[inds]
+        keep = remove_small_boxes(boxes, 1e-2)
+        boxes, sc, labels = boxes[keep], sc[keep], labels[keep]
+        keep = batched_nms(boxes, sc, labels, nms_thresh)[:detections_per_img]
+        out.append((boxes[keep], sc[keep], labels[keep].astype(np.int64)))
+    return out

@@ -192,17 +192,16 @@ def test_engine_golden_reference_outputs(golden):
 
 
 def test_engine_vs_reference_256px(golden):
-    """Network-level parity at a size where it means something: the REFERENCE YoloHead (Darknet-53) at 256 px, batch 4 (fixture g8b).
-    * eval mode on the reference's own running statistics: every head within 3 % of its largest value (measured 1.1-2.0 %);
-    * train mode (batch statistics): bf16 STORAGE noise grows ~1.15x per layer through 75 train-mode BN layers, whoever does the arithmetic:
-      the fp32 oracle run with bf16-rounded storage is 0.12-0.23 (relative L2) away from the fp32 reference at the heads, and the engine
-      must stay within that envelope AT EVERY LAYER (engine error <= 1.3 x the storage-noise error + 0.003), i.e. it adds nothing of its own.
-    (The 64-px g8 test above needs 0.45 in eval mode only because its running statistics come from the engine's own train-mode pass over
-    2x2 maps - BN over 8 values - not from the reference: measured here, eval mode itself is 1-2 % accurate.)"""
-    from object_detectors_amd.yolo.nets.engine import bn_name
+    """Network-level parity at a size where it means something: the REFERENCE YoloHead (Darknet-53) at 256 px, batch 4 (fixture g8b:
+    8x8 / 16x16 / 32x32 maps, BatchNorm over 256-4096 values; residual branches damped x0.2 like trained / zero-init-residual networks),
+    eval mode on the reference's own running statistics and train mode on batch statistics.
+    Yardstick: bf16 STORAGE alone (fp32 arithmetic, activations and weights rounded to bf16 between layers: the oracle with quant=bf16)
+    sits 4-10 % of the largest value away from the fp32 reference after 75 layers (max over ~10^5-10^6 elements; measured eval 0.047 /
+    0.084 / 0.103, train 0.051 / 0.080 / 0.126 for the engine against 0.050 / 0.086 / 0.107 and 0.051 / 0.078 / 0.102 for that yardstick),
+    so the bound is relative to it: engine error <= 1.3 x storage-noise error + 0.01, and <= 0.16 outright."""
     g = golden("g8b_network256")
     wseed, xseed, px, bs = [int(v) for v in g["meta"]]
-    eng, sd = make_engine("darknet_53", wseed)
+    eng, sd = make_engine("darknet_53", wseed, damp=float(g["damp"][0]))
     off = 0
     for name, size in zip(g["bn_names"], g["bn_sizes"]):
         sd[str(name) + ".running_mean"] = torch.from_numpy(g["running_mean"][off:off + int(size)].copy())
@@ -211,31 +210,41 @@ def test_engine_vs_reference_256px(golden):
     eng.load_reference_state_dict(sd)
     x = detrand.uniform(xseed, (bs, 3, px, px), -2.0, 2.0)
     xd = torch.from_numpy(x).to(dev())
-    ev = eng.forward(xd, training=False)
-    for k, o in enumerate(ev):
-        ref = torch.from_numpy(g[f"eval_out{k}"])
-        step = o.shape[-1] // 8
-        err = float((o.cpu()[:, :, ::step, ::step] - ref).abs().max()) / float(g[f"eval_out{k}_absmax"][0])
-        assert err < 0.03, ("eval", k, err)
-    # train mode: engine vs the reference, and layer by layer vs the fp32 oracle next to the storage-noise envelope
-    outs = eng.forward(xd, training=True)
+    for mode, training in (("eval", False), ("train", True)):
+        outs = eng.forward(xd, training=training)
+        o32 = net_oracle.forward(sd, torch.from_numpy(x), "darknet_53", training=training)
+        o16 = net_oracle.forward(sd, torch.from_numpy(x), "darknet_53", training=training, quant=bf16q)
+        for k, o in enumerate(outs):
+            ref = torch.from_numpy(g[f"{mode}_out{k}"])
+            step = o.shape[-1] // 8
+            amax = float(g[f"{mode}_out{k}_absmax"][0])
+            assert float((o32[k][:, :, ::step, ::step] - ref).abs().max()) / amax < 1e-3, (mode, k)      # the oracle IS the reference (fp32 both)
+            err = float((o.cpu()[:, :, ::step, ::step] - ref).abs().max()) / amax
+            err_q = float((o16[k] - o32[k]).abs().max()) / amax
+            assert err < 1.3 * err_q + 0.01 and err < 0.16, (mode, k, err, err_q)
+
+
+def test_engine_error_envelope_undamped_weights():
+    """Undamped random weights make the 75-layer train-mode map chaotic: bf16 STORAGE noise grows ~1.15x per layer whoever does the
+    arithmetic - the fp32 oracle evaluated with bf16-rounded storage ends 0.12-0.23 (relative L2) away from the fp32 run at the heads
+    (256 px, batch 4).  The engine must stay inside that envelope AT EVERY LAYER (its error <= 1.3 x the storage-noise error + 0.003):
+    it adds nothing of its own.  (This is also why the 64-px g8 test above needs 0.45 even in eval mode: its running statistics come
+    from such a noisy train-mode pass over 2x2 maps.  Eval mode is exactly as accurate as its bf16 storage allows: test_engine_vs_reference_256px.)"""
+    eng, sd = make_engine("darknet_53", 5000)
+    x = detrand.uniform(4242, (4, 3, 256, 256), -2.0, 2.0)
+    outs = eng.forward(torch.from_numpy(x).to(dev()), training=True)
     torch.cuda.synchronize()
     plan = eng._last_plan
     rec32, rec16 = {}, {}
     o32 = net_oracle.forward(sd, torch.from_numpy(x), "darknet_53", training=True, record=rec32)
     o16 = net_oracle.forward(sd, torch.from_numpy(x), "darknet_53", training=True, quant=bf16q, record=rec16)
     for k, o in enumerate(outs):
-        ref = torch.from_numpy(g[f"train_out{k}"])
-        step = o.shape[-1] // 8
-        assert rel(o32[k][:, :, ::step, ::step], ref) < 1e-3, k                   # the oracle IS the reference (fp32 both)
         e_eng, e_q = rel(o.cpu(), o32[k]), rel(o16[k], o32[k])
         assert e_eng < 1.3 * e_q + 3e-3 and e_eng < 0.35, ("train head", k, e_eng, e_q)
-    worst = 0.0
     for name, r in plan.layers.items():
         if r.get("res") is not None:
             continue
         e_eng, e_q = rel(view(r["a"]), rec32[name][1]), rel(rec16[name][1], rec32[name][1])
-        worst = max(worst, e_eng / (e_q + 1e-9))
         assert e_eng < 1.3 * e_q + 3e-3, (name, e_eng, e_q)
 
 

@@ -39,7 +39,7 @@ report("yolo_loss fwd+bwd (assign + noobj + positives + reduce)", timeit(lambda:
 report("yolo_decode (bs=32)", timeit(lambda: crit(heads)), 2 * bs * N * 85 * 4)
 pred = crit(heads)
 report("yolo_candidates (score+compaction)", timeit(lambda: ops.yolo_candidates(pred, 0.1)), bs * N * 85 * 4, "reads decoded predictions once")
-_p, sc_, lb_ = crit.last_decode_scores
+_r, _v, sc_, lb_ = crit.last_decode_scores
 report("yolo_candidates with fused decode scores", timeit(lambda: ops.yolo_candidates(pred, 0.1, score=sc_, label=lb_)), bs * N * 8, "score+label arrays only")
 for n in (1000, 5000, 10000):
     c = torch.rand(bs, n, 2, device=dev) * 600 + 20

@@ -382,6 +382,13 @@ def g8b_network256(yolohead, darknet):
     torch.manual_seed(0)
     m = yolohead.YoloHead(cfg)
     det_weights(m, 5000)
+    # residual branches damped (gamma of every block's second BN x 0.2), as zero-init-residual / trained networks are: with the undamped
+    # random weights the 75-layer map is chaotic (bf16 STORAGE rounding alone grows 1.15x per layer, tests/test_gpu_engine.py), which would
+    # hide a real defect behind a loose tolerance
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith(".bn2.weight"):
+                p_.mul_(0.2)
     for mod in m.modules():
         if isinstance(mod, nn.BatchNorm2d):
             mod.momentum = 1.0
@@ -390,6 +397,7 @@ def g8b_network256(yolohead, darknet):
     with torch.no_grad():
         outs = m(torch.from_numpy(x))
     d["meta"] = np.array([5000, 4242, px, bs], np.int64)
+    d["damp"] = np.array([0.2], np.float32)
     for k, o in enumerate(outs):
         step = o.shape[-1] // 8
         d[f"train_out{k}"] = o[:, :, ::step, ::step].numpy().copy()
@@ -567,8 +575,10 @@ class FrozenBN(nn.Module):
         return x * scale + (b - rm * scale)
 
 
-def g12_retinanet():
-    from oracle import retina_oracle as ro
+def stub_torchvision_permissive():
+    """Fresh permissive torchvision stubs + the reference's torchvision_models tree on the path (idempotent)."""
+    if isinstance(sys.modules.get("torchvision"), _Permissive):
+        return
     for k in [k for k in sys.modules if k == "utilities" or k.startswith("utilities.") or k == "tvision" or k.startswith("tvision.")
               or k == "torchvision" or k.startswith("torchvision.")]:
         del sys.modules[k]
@@ -581,6 +591,11 @@ def g12_retinanet():
     sys.modules["torchvision"].ops = sys.modules["torchvision.ops"]
     sys.modules["torchvision.ops"].misc = sys.modules["torchvision.ops.misc"]
     sys.modules["torchvision.ops"].boxes = sys.modules["torchvision.ops.boxes"]
+
+
+def g12_retinanet():
+    from oracle import retina_oracle as ro
+    stub_torchvision_permissive()
     from utilities import resnet
     seed = 7000
     d = {"meta": np.array([seed, 7100, 64], np.int64)}
@@ -634,6 +649,7 @@ def g13_frcnn():
     """RegionProposalNetwork.assign_targets_to_anchors / compute_loss and roi_heads.fastrcnn_loss / assign_targets_to_proposals of the
     reference, called unbound on a namespace that carries the reference's own Matcher and a DETERMINISTIC stand-in sampler."""
     import types as _t
+    stub_torchvision_permissive()
     from tvision import _utils, rpn, roi_heads
     d = {}
     rng_anchor = detrand.uniform(900, (600, 2), 0, 700)
@@ -687,6 +703,73 @@ def g13_frcnn():
     d["frcnn_logits"], d["frcnn_breg"], d["frcnn_labels"], d["frcnn_tgt"] = logits.numpy(), breg.numpy(), lbl, tgt.numpy()
     c, b = roi_heads.fastrcnn_loss(logits, breg, [torch.from_numpy(lbl)], [tgt], loss_type="ce")
     d["frcnn_losses_ce"] = np.array([float(c), float(b)], np.float64)
+    # ---- every classification loss of the reference (roi_heads.py:24-96) exactly as RoIHeads.forward calls it (:826-827):
+    #      fastrcnn_loss(tfidf * class_logits, ..., weights=classification_weights, loss_type=...), with gradients.
+    #      torchvision's sigmoid_focal_loss is not installed: the restatement of SURVEY Appendix B stands in for it (unpinned op).
+    from oracle import tv_oracle as tvo
+
+    def focal_stub(inputs, targets, alpha=0.25, gamma=2, reduction="none"):
+        p = torch.sigmoid(inputs)
+        ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+        p_t = p * targets + (1 - p) * (1 - targets)
+        loss = ce * ((1 - p_t) ** gamma)
+        if alpha >= 0:
+            loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+        return loss.sum() if reduction == "sum" else loss.mean() if reduction == "mean" else loss
+    import torch.nn.functional as F
+    roi_heads.sigmoid_focal_loss = focal_stub
+    tfidf_vec = torch.from_numpy(detrand.uniform(950, (1, k), 0.6, 1.6))
+    cw = torch.from_numpy(detrand.uniform(951, (k,), 0.5, 2.0))
+    d["frcnn_tfidf"], d["frcnn_cw"] = tfidf_vec.numpy(), cw.numpy()
+    real_cuda_ft = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = torch.FloatTensor                    # roi_heads.py:49 hard-codes the device of the one-hot buffer
+    try:
+        for lt, scale in (("ce", 1.0), ("bce", 1.0), ("focal_loss", 1.0), ("gombit", 1.0), ("gombit_fl", 1.0), ("gombit", 3.0), ("gombit", -1.0)):
+            lg = (logits * scale if scale > 0 else logits * 0.5 - 5.0).clone().requires_grad_(True)      # -1: low logits, the loss stays below 5 (no /4)
+            br = breg.clone().requires_grad_(True)
+            c, b = roi_heads.fastrcnn_loss(tfidf_vec * lg, br, [torch.from_numpy(lbl)], [tgt], weights=cw if lt == "ce" else None, loss_type=lt)
+            (c + b).backward()
+            tag = lt + ("_x3" if scale == 3.0 else "_lo" if scale < 0 else "")       # logits x3: the plain gombit loss exceeds 5 and takes its /4 branch (:71-72)
+            d[f"frcnn_w_losses_{tag}"] = np.array([float(c.detach()), float(b.detach())], np.float64)
+            d[f"frcnn_w_glogits_{tag}"] = lg.grad.numpy().copy()
+            if lt == "ce":
+                d["frcnn_w_gbreg"] = br.grad.numpy().copy()
+    finally:
+        torch.cuda.FloatTensor = real_cuda_ft
+    # ---- RoIHeads.forward in eval mode on a namespace: the mini-batch tf-idf update (:801-809) and postprocess_detections (:715-781) of
+    #      the reference itself; pooling / MLP / predictor are stand-ins returning fixed tensors; the torchvision box ops are the
+    #      restatements of oracle/tv_oracle.py (unpinned ops), so this pins the reference-owned glue around them.
+    bx = sys.modules["torchvision.ops.boxes"]
+    bx.clip_boxes_to_image = lambda b_, size: torch.from_numpy(tvo.clip_boxes_to_image(b_.numpy(), size))
+    bx.remove_small_boxes = lambda b_, min_size: torch.from_numpy(tvo.remove_small_boxes(b_.numpy(), min_size))
+    bx.batched_nms = lambda b_, s_, i_, thr: torch.from_numpy(tvo.batched_nms(b_.numpy(), s_.numpy(), i_.numpy(), thr))
+    for name in ("clip_boxes_to_image", "remove_small_boxes", "batched_nms"):
+        setattr(roi_heads.box_ops, name, getattr(bx, name))
+    kk, R = 21, 150
+    props2 = [torch.from_numpy(np.concatenate([detrand.uniform(960 + i, (R, 2), 0, 500), detrand.uniform(962 + i, (R, 2), 0, 500)], 1)) for i in range(2)]
+    for pp in props2:
+        pp[:, 2:] = pp[:, :2] + pp[:, 2:] * 0.4 + 8
+    cl2 = torch.from_numpy(detrand.uniform(970, (2 * R, kk), -2, 4))
+    cl2[:, 0] -= 1.0
+    br2 = torch.from_numpy(detrand.uniform(971, (2 * R, kk * 4), -0.6, 0.6))
+    tg2 = [{"boxes": torch.from_numpy(synth_gt_xyxy(980 + i, 4)), "labels": torch.from_numpy(detrand.randint(982 + i, (4,), 1, kk))} for i in range(2)]
+    d["pp_props0"], d["pp_props1"], d["pp_logits"], d["pp_breg"] = props2[0].numpy(), props2[1].numpy(), cl2.numpy(), br2.numpy()
+    d["pp_labels0"], d["pp_labels1"] = tg2[0]["labels"].numpy(), tg2[1]["labels"].numpy()
+    d["pp_tfidf_post"] = detrand.uniform(985, (1, kk), 0.7, 1.4)
+    for lt in ("ce", "bce", "gombit"):
+        for norm in (0, 2):
+            ns = _t.SimpleNamespace(training=False, tfidf_mini_batch=True, num_classes=kk, tfidf_norm=norm, tfidf=None,
+                                    tfidf_post=torch.from_numpy(d["pp_tfidf_post"]), loss_function_name=lt, classification_weights=None,
+                                    box_coder=_utils.BoxCoder((10.0, 10.0, 5.0, 5.0)), score_thresh=0.05, nms_thresh=0.5, detections_per_img=20,
+                                    has_keypoint=lambda: False, has_mask=lambda: False, keypoint_roi_pool=None, keypoint_head=None, keypoint_predictor=None,
+                                    box_roi_pool=lambda f, p_, s_: torch.zeros(1), box_head=lambda x_: x_, box_predictor=lambda x_: (cl2, br2))
+            ns.postprocess_detections = lambda *a, _ns=ns: roi_heads.RoIHeads.postprocess_detections(_ns, *a)
+            res, _loss = roi_heads.RoIHeads.forward(ns, None, [pp.clone() for pp in props2], [(512, 640), (480, 512)], tg2)
+            if lt == "ce":
+                d[f"pp_minibatch_tfidf_norm{norm}"] = ns.tfidf.float().numpy().copy()
+            if norm == 0:
+                for i, r in enumerate(res):
+                    d[f"pp_{lt}_boxes{i}"], d[f"pp_{lt}_scores{i}"], d[f"pp_{lt}_labels{i}"] = r["boxes"].numpy(), r["scores"].numpy(), r["labels"].numpy()
     np.savez_compressed(os.path.join(OUT, "g13_frcnn.npz"), **d)
 
 
