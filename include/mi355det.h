@@ -383,6 +383,18 @@ int mi355det_fastrcnn_loss(const float* class_logits, const float* box_regressio
                            int32_t k, int32_t loss_type, float* losses, float* grad_logits, float* grad_box, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* ---- input-side transform (csrc/transform_kernels.hip) -------------------------------------------------
+ * resize_bilinear: `planes` fp32 planes [planes][h][w] -> out [planes][pad_h][pad_w]: F.interpolate(mode='bilinear', align_corners=False)
+ *   to (out_h, out_w) with the sampling scale taken from the two sizes (recompute_scale_factor=True / size=...), zeros in the pad.
+ *   mean/std [c] (nullable together): (x - mean[p % c]) / std[p % c] applied to the taps = GeneralizedRCNNTransform.normalize followed by
+ *   resize and batch_images (torchvision_models/tvision/transform.py:120-135,215-226) for one image (planes = c = 3) written into its slot
+ *   of the padded batch; with mean = NULL and planes = N*C it is the YOLO multi-scale resize (yolo/procedures/train_one_epoch.py:64-69).
+ * resize_boxes: transform.py:279-293, boxes [n,4] xyxy scaled by float32 ratios new/orig. */
+int mi355det_resize_bilinear(const float* in, int32_t planes, int32_t c, int32_t h, int32_t w, const float* mean, const float* stdv,
+                             float* out, int32_t out_h, int32_t out_w, int32_t pad_h, int32_t pad_w, void* stream);
+int mi355det_resize_boxes(const float* boxes, float* out, int64_t n, int32_t orig_h, int32_t orig_w, int32_t new_h, int32_t new_w,
+                          void* stream);
+
 /* layout / dtype converters at the module boundary */
 int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h,
                               int32_t w, float* out, void* stream);

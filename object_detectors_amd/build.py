@@ -23,6 +23,7 @@ SOURCES = [
     ("box_kernels.hip", ["-ffp-contract=off"]),
     ("roi_kernels.hip", ["-ffp-contract=off"]),
     ("frcnn_kernels.hip", ["-ffp-contract=off"]),
+    ("transform_kernels.hip", ["-ffp-contract=off"]),
     ("resnet_kernels.hip", []),
     ("conv_kernels.hip", []),
     ("igemm8_kernels.hip", []),

@@ -245,11 +245,18 @@ class RetinaNetEngine:
         torch.cuda.current_stream().synchronize()      # `tab` is freed on return
 
     # ------------------------------------------------------------------ plan / step
+    MAX_PLANS = 4     # a plan owns every activation buffer of its shape: keep the few most recently used (multi-size inputs, train + eval)
+
     def plan(self, n, H, W, training):
-        key = (n, H, W, bool(training), torch.cuda.current_stream().cuda_stream)
-        if key not in self.plans:
-            self.plans[key] = RetinaPlan(self, n, H, W, training, key[-1])
-        return self.plans[key]
+        key = (n, H, W, bool(training), bool(self.normalize), torch.cuda.current_stream().cuda_stream)
+        p = self.plans.pop(key, None)
+        if p is None:
+            while len(self.plans) >= self.MAX_PLANS:
+                torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
+                self.plans.pop(next(iter(self.plans)))
+            p = RetinaPlan(self, n, H, W, training, key[-1])
+        self.plans[key] = p                                          # most recently used last
+        return p
 
     def forward(self, images, training=None):
         """images [n,3,H,W] fp32 in 0..1 (already resized/batched) -> {'cls_logits': [n, sum HWA, K], 'bbox_regression': [n, sum HWA, 4]}."""

@@ -14,18 +14,20 @@ Where the work runs:
   * TwoMLPHead / FastRCNNPredictor (frcnn.py:238-290) are plain dense GEMMs on [512*N, 12544]: `torch.nn.Linear` (rocBLAS/hipBLASLt,
     the library path the MI355X rules reserve for plain GEMMs); their parameters are ordinary torch parameters, the backbone's live in
     `model.engine.flat_w` (optimise with `optim.FlatSGD.for_engine(model.engine)` + a torch optimizer over `model.head_parameters()`).
-Images must already be resized / batched to one [N,3,H,W] tensor with H, W multiples of 32 (see tvision/retinanet.py).
+Inputs as in tvision/retinanet.py: a list of [3,H,W] images goes through the GPU GeneralizedRCNNTransform (generalized_rcnn.py:78-79,110), a ready
+[N,3,H,W] batch skips it.
 """
 import torch
 from torch import nn
 
 from .. import ops
 from ._utils import BoxCoder
-from .engine import FasterRCNNEngine
+from .engine import IMAGE_MEAN, IMAGE_STD, FasterRCNNEngine
 from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals
 from .roi_align import MultiScaleRoIAlign
 from .roi_heads import RoIHeadTargets, fastrcnn_loss, minibatch_tfidf
 from .rpn import RPNTargets
+from .transform import GeneralizedRCNNTransform
 
 
 class TwoMLPHead(nn.Module):
@@ -62,9 +64,10 @@ class FasterRCNN(nn.Module):
                  rpn_nms_thresh=0.7, rpn_fg_iou_thresh=0.7, rpn_bg_iou_thresh=0.3, rpn_batch_size_per_image=256, rpn_positive_fraction=0.5,
                  rpn_score_thresh=0.0, box_score_thresh=0.05, box_nms_thresh=0.5, box_detections_per_img=100, box_fg_iou_thresh=0.5,
                  box_bg_iou_thresh=0.5, box_batch_size_per_image=512, box_positive_fraction=0.25, bbox_reg_weights=None, loss_type="ce",
-                 device=None, seed=0, body="resnet50"):
+                 device=None, seed=0, body="resnet50", min_size=800, max_size=1333, image_mean=None, image_std=None):
         super().__init__()
         self.engine = FasterRCNNEngine(trainable_backbone_layers, device=device, seed=seed, body=body)
+        self.transform = GeneralizedRCNNTransform(min_size, max_size, image_mean or list(IMAGE_MEAN), image_std or list(IMAGE_STD))   # frcnn.py:232-236
         dev = self.engine.device
         self.rpn_targets = RPNTargets(rpn_fg_iou_thresh, rpn_bg_iou_thresh, rpn_batch_size_per_image, rpn_positive_fraction)
         self.rpn_pre = dict(training=rpn_pre_nms_top_n_train, testing=rpn_pre_nms_top_n_test)
@@ -132,12 +135,18 @@ class FasterRCNN(nn.Module):
                                     self.rpn_post[mode], self.rpn_nms_thresh, self.rpn_score_thresh)
 
     def forward(self, images, targets=None):
-        if isinstance(images, (list, tuple)):
-            if len({tuple(i.shape) for i in images}) != 1:
-                raise NotImplementedError("images of different sizes: resize/pad them to one size first")
-            images = torch.stack(list(images))
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")          # generalized_rcnn.py:60-61
+        original_image_sizes = None
+        if isinstance(images, (list, tuple)):
+            original_image_sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]      # generalized_rcnn.py:72-76
+            self.transform.train(self.training)
+            image_list, targets = self.transform(images, targets)                              # generalized_rcnn.py:78
+            images, image_shapes = image_list.tensors, list(image_list.image_sizes)
+            self.engine.normalize = False              # normalised before padding by the transform: padded pixels are exact zeros
+        else:
+            image_shapes = [(images.shape[-2], images.shape[-1])] * images.shape[0]
+            self.engine.normalize = True
         if self.training:
             for t in targets:
                 b = t["boxes"]
@@ -146,7 +155,6 @@ class FasterRCNN(nn.Module):
                 if b.numel() and bool((b[:, 2:] <= b[:, :2]).any()):
                     raise ValueError("All bounding boxes should have positive height and width.")
         n = images.shape[0]
-        image_shapes = [(images.shape[-2], images.shape[-1])] * n
         if targets is not None and self.tfidf_mini_batch:         # roi_heads.py:801-809
             self.tfidf = minibatch_tfidf(targets, self.num_classes, self.tfidf_norm).to(images.device).float().reshape(1, -1)
         out = self.engine.forward(images, training=self.training)
@@ -159,7 +167,10 @@ class FasterRCNN(nn.Module):
                 cls, reg = self.box_predictor(self.box_head(x))
                 b, s, l = roi_heads_postprocess_detections(cls, reg, boxes, image_shapes, self.tfidf_post, self.box_score_thresh,
                                                            self.box_nms_thresh, self.box_detections_per_img, self.bbox_reg_weights, self.loss_type)
-            return [{"boxes": bb, "labels": ll, "scores": ss} for bb, ll, ss in zip(b, l, s)]
+            det = [{"boxes": bb, "labels": ll, "scores": ss} for bb, ll, ss in zip(b, l, s)]
+            if original_image_sizes is not None:
+                det = self.transform.postprocess(det, image_shapes, original_image_sizes)      # generalized_rcnn.py:110
+            return det
         # ---- training: RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient)
         obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
         dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)

@@ -4,23 +4,27 @@
     losses = model(images, targets)        # training: {'classification': ..., 'bbox_regression': ...} (backward already done)
     detections = model(images)             # eval: [{'boxes','scores','labels'}]
 
-Differences (documented in INTEGRATION.md): images must already be resized / batched to one [N,3,H,W] tensor with H, W
-multiples of 32 (GeneralizedRCNNTransform's resize is data-pipeline work outside the hot path; its normalisation is fused
-into the stem); in training mode the call runs the fused forward + loss + backward and leaves the gradients in
+Inputs: a LIST of [3,H,W] images of any sizes goes through the reference's GeneralizedRCNNTransform (normalise, bilinear resize to
+min_size 800 / max_size 1333, zero-pad to a multiple of 32, targets' boxes rescaled; detections mapped back to the input frame) on the
+GPU (tvision/transform.py); a ready [N,3,H,W] batch (H, W multiples of 32) skips resize / padding and has the normalisation fused into
+the stem's im2col.  In training mode the call runs the fused forward + loss + backward and leaves the gradients in
 `model.engine.flat_g` (use `object_detectors_amd.optim.FlatSGD.for_engine(model.engine)`), returning detached losses.
 """
 import torch
 from torch import nn
 
-from .engine import RetinaNetEngine
+from .engine import IMAGE_MEAN, IMAGE_STD, RetinaNetEngine
 from .postprocess import retinanet_postprocess_detections
+from .transform import GeneralizedRCNNTransform
 
 
 class RetinaNet(nn.Module):
     def __init__(self, num_classes=91, trainable_backbone_layers=3, score_thresh=0.05, nms_thresh=0.5, detections_per_img=300,
-                 topk_candidates=1000, tfidf=None, device=None, seed=0, body="resnet50"):
+                 topk_candidates=1000, tfidf=None, device=None, seed=0, body="resnet50", min_size=800, max_size=1333, image_mean=None,
+                 image_std=None):
         super().__init__()
         self.engine = RetinaNetEngine(num_classes, 9, trainable_backbone_layers, device=device, seed=seed, body=body)
+        self.transform = GeneralizedRCNNTransform(min_size, max_size, image_mean or list(IMAGE_MEAN), image_std or list(IMAGE_STD))   # retinanet.py:383
         self.score_thresh, self.nms_thresh = score_thresh, nms_thresh
         self.detections_per_img, self.topk_candidates = detections_per_img, topk_candidates
         self.tfidf = None if tfidf is None else tfidf["values"].to(self.engine.device).float()
@@ -33,16 +37,7 @@ class RetinaNet(nn.Module):
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
         self.engine.load_reference_state_dict(sd)
 
-    @staticmethod
-    def _batch(images):
-        if isinstance(images, (list, tuple)):
-            if len({tuple(i.shape) for i in images}) != 1:
-                raise NotImplementedError("images of different sizes: resize/pad them to one size first (transform.py:88-118 is not on the GPU path)")
-            images = torch.stack(list(images))
-        return images
-
     def forward(self, images, targets=None):
-        images = self._batch(images)
         if self.training:
             if targets is None:
                 raise ValueError("In training mode, targets should be passed")          # retinanet.py:489-490
@@ -50,6 +45,19 @@ class RetinaNet(nn.Module):
                 b = t["boxes"]
                 if b.dim() != 2 or b.shape[-1] != 4:
                     raise ValueError("Expected target boxes to be a tensor of shape [N, 4], got {:}.".format(b.shape))   # retinanet.py:495-501
+        original_image_sizes = None
+        if isinstance(images, (list, tuple)):
+            original_image_sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]                                # retinanet.py:505-509
+            self.transform.train(self.training)
+            image_list, targets = self.transform(images, targets)                                                        # retinanet.py:512
+            images, shapes = image_list.tensors, image_list.image_sizes
+            self.engine.normalize = False              # the transform normalised BEFORE padding: padded pixels are exact zeros
+        else:
+            shapes = [(images.shape[-2], images.shape[-1])] * images.shape[0]
+            self.engine.normalize = True
+        if self.training:
+            for t in targets:
+                b = t["boxes"]
                 if b.numel() and bool(((b[:, 2:] <= b[:, :2]).any())):
                     raise ValueError("All bounding boxes should have positive height and width.")                        # retinanet.py:515-525
             losses = self.engine.train_step(images, targets, class_scale=self.tfidf)
@@ -58,10 +66,12 @@ class RetinaNet(nn.Module):
         p = self.engine._last_plan
         cls = list(out["cls_logits"].split(p.level_rows, dim=1))
         reg = list(out["bbox_regression"].split(p.level_rows, dim=1))
-        shapes = [(images.shape[-2], images.shape[-1])] * images.shape[0]
-        return retinanet_postprocess_detections(cls, reg, p.anchors_per_level, shapes, tfidf_post=self.tfidf_post, score_thresh=self.score_thresh,
-                                                topk_candidates=self.topk_candidates, nms_thresh=self.nms_thresh,
-                                                detections_per_img=self.detections_per_img)
+        det = retinanet_postprocess_detections(cls, reg, p.anchors_per_level, shapes, tfidf_post=self.tfidf_post, score_thresh=self.score_thresh,
+                                               topk_candidates=self.topk_candidates, nms_thresh=self.nms_thresh,
+                                               detections_per_img=self.detections_per_img)
+        if original_image_sizes is not None:
+            det = self.transform.postprocess(det, shapes, original_image_sizes)                                           # retinanet.py:567
+        return det
 
 
 def retinanet_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=False, trainable_backbone_layers=None, tfidf=None,

@@ -244,11 +244,19 @@ class YoloV3Engine:
         return out
 
     # ------------------------------------------------------------------ plan
+    MAX_PLANS = 4     # a plan owns every activation of its shape (12 GB at batch 32 / 640 px): multi-scale training (train_one_epoch.py:66-70) walks
+                      # through ~10 sizes, so only the most recently used plans are kept; tile choices live in the library, keyed by shape
+
     def plan(self, n, H, W, training):
         key = (n, H, W, bool(training), torch.cuda.current_stream().cuda_stream)
-        if key not in self.plans:
-            self.plans[key] = Plan(self, n, H, W, training, key[-1])
-        return self.plans[key]
+        p = self.plans.pop(key, None)
+        if p is None:
+            while len(self.plans) >= self.MAX_PLANS:
+                torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
+                self.plans.pop(next(iter(self.plans)))
+            p = Plan(self, n, H, W, training, key[-1])
+        self.plans[key] = p                                          # most recently used last
+        return p
 
     def forward(self, images, training=None):
         """images [n,3,H,W] fp32 NCHW on the GPU -> (out0,out1,out2) NCHW-shaped fp32 views [n,A*(5+C),h,w]."""

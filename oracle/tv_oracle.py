@@ -391,3 +391,57 @@ def roi_postprocess_detections(class_logits, box_regression, proposals, image_sh
         keep = batched_nms(boxes, sc, labels, nms_thresh)[:detections_per_img]
         out.append((boxes[keep], sc[keep], labels[keep].astype(np.int64)))
     return out
+
+
+# ---- input-side transform (tvision/transform.py:26-52,88-226,279-293; ATen upsample_bilinear2d, align_corners=False) ---------------------
+def resized_size(h, w, min_size, max_size):
+    # `self_min_size / min_size` with a Python float on the left and a float32 tensor on the right is Tensor.__rtruediv__: reciprocal() * scalar,
+    # i.e. TWO float32 roundings (1/480*800 = 1.6666667, not 1.6666666): this decides 800 vs 799 rows
+    mn, mx = F32(min(h, w)), F32(max(h, w))
+    scale = float(min((F32(1) / mn) * F32(min_size), (F32(1) / mx) * F32(max_size)))
+    return int(math.floor(float(h) * scale)), int(math.floor(float(w) * scale))
+
+
+def bilinear_resize(img, oh, ow):
+    """img [..., h, w] float32 -> [..., oh, ow]; F.interpolate(mode='bilinear', align_corners=False) with the scale taken from the sizes."""
+    img = np.asarray(img, F32)
+    h, w = img.shape[-2:]
+
+    def axis(n_in, n_out):
+        r = F32(n_in) / F32(n_out)
+        src = np.maximum(r * (np.arange(n_out, dtype=F32) + F32(0.5)) - F32(0.5), F32(0))
+        i0 = src.astype(np.int64)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = (src - i0.astype(F32)).astype(F32)
+        return i0, i1, (F32(1) - l1).astype(F32), l1
+    y0, y1, h0, h1 = axis(h, oh)
+    x0, x1, w0, w1 = axis(w, ow)
+    top = w0 * img[..., y0, :][..., x0] + w1 * img[..., y0, :][..., x1]
+    bot = w0 * img[..., y1, :][..., x0] + w1 * img[..., y1, :][..., x1]
+    return (h0[:, None] * top + h1[:, None] * bot).astype(F32)
+
+
+def rcnn_transform(images, min_size=800, max_size=1333, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), size_divisible=32, boxes=None):
+    """GeneralizedRCNNTransform.forward in eval mode -> (batch [N,3,Hp,Wp], image_sizes, resized boxes)."""
+    m, s = np.asarray(mean, F32)[:, None, None], np.asarray(std, F32)[:, None, None]
+    outs, sizes, nb = [], [], []
+    for i, img in enumerate(images):
+        img = np.asarray(img, F32)
+        h, w = img.shape[-2:]
+        oh, ow = resized_size(h, w, min_size, max_size)
+        outs.append(bilinear_resize((img - m) / s, oh, ow))
+        sizes.append((oh, ow))
+        if boxes is not None:
+            nb.append(resize_boxes(boxes[i], (h, w), (oh, ow)))
+    ph = int(math.ceil(max(x[0] for x in sizes) / float(size_divisible)) * size_divisible)
+    pw = int(math.ceil(max(x[1] for x in sizes) / float(size_divisible)) * size_divisible)
+    batch = np.zeros((len(images), outs[0].shape[0], ph, pw), F32)
+    for i, o in enumerate(outs):
+        batch[i, :, :o.shape[1], :o.shape[2]] = o
+    return batch, sizes, nb
+
+
+def resize_boxes(boxes, original_size, new_size):
+    rh, rw = F32(new_size[0]) / F32(original_size[0]), F32(new_size[1]) / F32(original_size[1])
+    b = np.asarray(boxes, F32)
+    return np.stack([b[:, 0] * rw, b[:, 1] * rh, b[:, 2] * rw, b[:, 3] * rh], 1).astype(F32)

@@ -773,6 +773,53 @@ def g13_frcnn():
     np.savez_compressed(os.path.join(OUT, "g13_frcnn.npz"), **d)
 
 
+def g14_transform():
+    """GeneralizedRCNNTransform of the reference (tvision/transform.py:65-257) in eval and train mode on images of different sizes (incl. the
+    non-square case that resizes to 800 x 1216 and one limited by max_size), resize_boxes, transform.postprocess, and the YOLO multi-scale
+    F.interpolate call (yolo/procedures/train_one_epoch.py:69).  Images are regenerated from detrand seeds; outputs are stored on a stride."""
+    stub_torchvision_permissive()
+    sys.modules["torchvision"]._is_tracing = lambda: False
+    from tvision import transform as tr
+    d = {}
+    shapes = [(480, 730), (375, 500), (600, 600), (333, 1000)]
+    d["shapes"] = np.array(shapes, np.int64)
+    imgs = [torch.from_numpy(detrand.uniform(8000 + i, (3, h, w), 0.0, 1.0)) for i, (h, w) in enumerate(shapes)]
+    boxes = []
+    for i, (h, w) in enumerate(shapes):
+        tl = detrand.uniform(8100 + i, (5, 2), 0, 0.5) * np.array([w, h], np.float32)
+        wh = detrand.uniform(8200 + i, (5, 2), 0.05, 0.45) * np.array([w, h], np.float32)
+        boxes.append(np.concatenate([tl, tl + wh], 1).astype(np.float32))
+    t = tr.GeneralizedRCNNTransform(800, 1333, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    t.eval()
+    il, tg = t(imgs, [{"boxes": torch.from_numpy(b)} for b in boxes])
+    d["eval_batch_shape"] = np.array(il.tensors.shape, np.int64)
+    d["eval_image_sizes"] = np.array(il.image_sizes, np.int64)
+    d["eval_batch_sample"] = il.tensors[:, :, ::13, ::17].numpy().copy()
+    d["eval_batch_sum"] = il.tensors.double().sum((1, 2, 3)).numpy()
+    for i in range(len(shapes)):
+        d[f"boxes{i}"], d[f"eval_boxes{i}"] = boxes[i], tg[i]["boxes"].numpy()
+    # postprocess: boxes in the resized frame back to the original frame
+    res = [{"boxes": tg[i]["boxes"].clone()} for i in range(len(shapes))]
+    back = t.postprocess(res, il.image_sizes, shapes)
+    for i in range(len(shapes)):
+        d[f"post_boxes{i}"] = back[i]["boxes"].numpy()
+    # train mode with several min sizes: the size is drawn with torch's global RNG (torch_choice)
+    t2 = tr.GeneralizedRCNNTransform((640, 672, 704, 736, 768, 800), 1333, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    t2.train()
+    torch.manual_seed(77)
+    il2, _ = t2(imgs[:3], None)
+    d["train_image_sizes"] = np.array(il2.image_sizes, np.int64)
+    d["train_batch_shape"] = np.array(il2.tensors.shape, np.int64)
+    d["train_batch_sample"] = il2.tensors[:, :, ::13, ::17].numpy().copy()
+    # YOLO multi-scale: F.interpolate(imgs, size=new_scale, mode='bilinear', align_corners=False) up and down
+    x = torch.from_numpy(detrand.uniform(8300, (2, 3, 416, 416), -2.0, 2.0))
+    for size in (320, 608):
+        y = torch.nn.functional.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        d[f"yolo_ms_{size}_sample"] = y[:, :, ::7, ::11].numpy().copy()
+        d[f"yolo_ms_{size}_sum"] = y.double().sum((1, 2, 3)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g14_transform.npz"), **d)
+
+
 def main():
     """python tools/make_golden.py [fixture ...]   (no argument: all; names = the npz stems, e.g. g8b_network256)"""
     os.makedirs(OUT, exist_ok=True)
@@ -800,6 +847,8 @@ def main():
         g12_retinanet()
     if want("g13_frcnn"):
         g13_frcnn()
+    if want("g14_transform"):
+        g14_transform()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
