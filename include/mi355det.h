@@ -395,6 +395,16 @@ int mi355det_resize_bilinear(const float* in, int32_t planes, int32_t c, int32_t
 int mi355det_resize_boxes(const float* boxes, float* out, int64_t n, int32_t orig_h, int32_t orig_w, int32_t new_h, int32_t new_w,
                           void* stream);
 
+/* ---- output side: detections -> the numbers of the COCO json dicts (csrc/transform_kernels.hip) ----------
+ * yolo/procedures/test_one_epoch.py:41-66 (scale = 1): boxes rows (x1,y1,x2,y2,...) with pitch box_ld in network pixels ->
+ *   bbox_xywh [k,4] = (x1/inp_dim*W, y1/inp_dim*H, w, h) in the original image, area [k] = w*h, category_id [k] from the label column
+ *   (labels_f32 with pitch label_ld, cast like `.long()`, or labels_i64): label_mode 0 = label + 1, 1 = COCO 80 -> 91 map
+ *   (yolo/utilities/helper.py:16-24), 2 = unchanged.
+ * torchvision_models/detection/coco_eval.py:83-105,169-171 (scale = 0, label_mode 2): convert_to_xywh.  area / category_id nullable. */
+int mi355det_coco_rows(const float* boxes, int32_t box_ld, const float* labels_f32, const int64_t* labels_i64, int32_t label_ld,
+                       int64_t k, float inp_dim, float img_h, float img_w, int32_t scale, int32_t label_mode, float* bbox_xywh,
+                       float* area, int64_t* category_id, void* stream);
+
 /* layout / dtype converters at the module boundary */
 int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_t n, int32_t c, int32_t h,
                               int32_t w, float* out, void* stream);

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "mi355det_nhwc_to_nchw_f32": (C.c_int, [vp, C.c_int, i32, i32, i32, i32, i32, vp, vp]),
     "mi355det_resize_bilinear": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mi355det_resize_boxes": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, vp]),
+    "mi355det_coco_rows": (C.c_int, [vp, i32, vp, vp, i32, i64, f32, f32, f32, i32, i32, vp, vp, vp, vp]),
     "mi355det_fastrcnn_loss_workspace": (sz, [i32]),
     "mi355det_fastrcnn_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
 }

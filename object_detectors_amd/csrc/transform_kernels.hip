@@ -72,3 +72,52 @@ int mi355det_resize_boxes(const float* boxes, float* out, int64_t n, int32_t ori
 }
 
 }  // extern "C"
+
+// ---- output side: kept detections -> the numbers of the COCO result dicts -------------------------------------
+// yolo/procedures/test_one_epoch.py:41-66: rows [k,6] = (x1,y1,x2,y2,score,label) in network pixels -> bbox (xmin, ymin, w, h) in the
+// ORIGINAL image's pixels (x / inp_dim * W, y / inp_dim * H), area = w*h, category id (80 -> 91 COCO map, or label + 1).
+// torchvision_models/detection/coco_eval.py:83-105,169-171: convert_to_xywh = the same with inp_dim = W = H = 1 and labels untouched.
+namespace {
+
+__constant__ int c_coco80to91[80] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 31, 32, 33, 34,
+                                     35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63,
+                                     64, 65, 67, 70, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 84, 85, 86, 87, 88, 89, 90};
+
+__global__ void coco_rows_kernel(const float* __restrict__ boxes, int box_ld, const float* __restrict__ labels_f, const long long* __restrict__ labels_i,
+                                 int lab_ld, long long k, float inp_dim, float img_h, float img_w, int scale, int label_mode, float* __restrict__ bbox,
+                                 float* __restrict__ area, long long* __restrict__ cat) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const float* r = boxes + i * box_ld;
+  float xmin = r[0], ymin = r[1], xmax = r[2], ymax = r[3];
+  if (scale) {
+    xmin = xmin / inp_dim * img_w;
+    ymin = ymin / inp_dim * img_h;
+    xmax = xmax / inp_dim * img_w;
+    ymax = ymax / inp_dim * img_h;
+  }
+  const float w = xmax - xmin, h = ymax - ymin;
+  bbox[i * 4 + 0] = xmin;
+  bbox[i * 4 + 1] = ymin;
+  bbox[i * 4 + 2] = w;
+  bbox[i * 4 + 3] = h;
+  if (area) area[i] = w * h;
+  if (cat) {
+    const long long l = labels_i ? labels_i[i * lab_ld] : (long long)labels_f[i * lab_ld];     // (atrbs[:,5]).long()
+    cat[i] = label_mode == 1 ? (long long)c_coco80to91[l < 0 ? 0 : (l > 79 ? 79 : l)] : label_mode == 0 ? l + 1 : l;
+  }
+}
+
+}  // namespace
+
+extern "C" int mi355det_coco_rows(const float* boxes, int32_t box_ld, const float* labels_f32, const int64_t* labels_i64, int32_t label_ld, int64_t k,
+                                  float inp_dim, float img_h, float img_w, int32_t scale, int32_t label_mode, float* bbox_xywh, float* area,
+                                  int64_t* category_id, void* stream) {
+  if (k < 0 || box_ld < 4 || (scale && !(inp_dim > 0.f))) return fail(MI355DET_EINVAL, "%s: bad arguments", "coco_rows");
+  if (label_mode < 0 || label_mode > 2) return fail(MI355DET_EINVAL, "%s: label_mode 0 (+1), 1 (COCO 80->91) or 2 (as is)", "coco_rows");
+  if (category_id && !labels_f32 && !labels_i64) return fail(MI355DET_EINVAL, "%s: category ids need labels", "coco_rows");
+  if (k == 0) return 0;
+  hipLaunchKernelGGL(coco_rows_kernel, dim3((int)((k + 255) / 256)), dim3(256), 0, S(stream), boxes, box_ld, labels_f32, (const long long*)labels_i64,
+                     label_ld, (long long)k, inp_dim, img_h, img_w, scale, label_mode, bbox_xywh, area, (long long*)category_id);
+  return check_launch("coco_rows");
+}

@@ -50,6 +50,30 @@ class FlatSGD(_Flat):
         self.steps += 1
 
 
+    # ---- the reference's checkpoint format (initialize.py:18-25 saves optimizer.state_dict() of torch.optim.SGD over model.parameters())
+    def reference_state_dict(self, engine):
+        g = self.param_groups[0]
+        tensors = engine.reference_parameter_tensors(self.momentum_buf)
+        state = {i: {"momentum_buffer": t} for i, t in enumerate(tensors)} if self.steps > 0 and g["momentum"] != 0 else {}
+        group = {k: g[k] for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")}
+        group["params"] = list(range(len(tensors)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_reference_state_dict(self, engine, sd):
+        g = sd["param_groups"][0]
+        for k in ("lr", "momentum", "dampening", "weight_decay", "nesterov"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+        if sd["state"]:
+            n = len(g["params"])
+            bufs = [sd["state"][i]["momentum_buffer"] for i in range(n)]
+            engine.load_reference_parameter_tensors(bufs, self.momentum_buf)
+            self.steps = max(self.steps, 1)
+        else:
+            self.momentum_buf.zero_()
+            self.steps = 0
+
+
 class FlatAdam(_Flat):
     """torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected moments)."""
 
@@ -66,3 +90,26 @@ class FlatAdam(_Flat):
                                       self.flat_w.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                       float(g["weight_decay"]), float(grad_scale), self.steps, int(zero_grad), _stream())
         check(st, "adam_step")
+
+    def reference_state_dict(self, engine):
+        g = self.param_groups[0]
+        m, v = engine.reference_parameter_tensors(self.exp_avg), engine.reference_parameter_tensors(self.exp_avg_sq)
+        state = {i: {"step": torch.tensor(float(self.steps)), "exp_avg": a, "exp_avg_sq": b} for i, (a, b) in enumerate(zip(m, v))} if self.steps else {}
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+                 "params": list(range(len(m)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_reference_state_dict(self, engine, sd):
+        g = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
+        if sd["state"]:
+            n = len(g["params"])
+            engine.load_reference_parameter_tensors([sd["state"][i]["exp_avg"] for i in range(n)], self.exp_avg)
+            engine.load_reference_parameter_tensors([sd["state"][i]["exp_avg_sq"] for i in range(n)], self.exp_avg_sq)
+            self.steps = int(sd["state"][0]["step"])
+        else:
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            self.steps = 0

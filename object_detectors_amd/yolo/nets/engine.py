@@ -188,9 +188,15 @@ class YoloV3Engine:
                 self.params[b + ".bias"].zero_()
             del w
 
-    def _set_weight_oihw(self, s, t):
+    def flat_views(self, flat):
+        """Per-tensor views (engine layout) of any flat buffer laid out like flat_w: gradients, optimizer state."""
+        if flat.numel() != self.flat_w.numel():
+            raise ValueError("buffer does not have the engine's flat layout")
+        return {name: flat[o:o + n].view(shape) for name, o, n, shape in self.param_order}
+
+    def _set_weight_oihw(self, s, t, dst=None):
         """Load a reference-layout [cout,cin,k,k] tensor into the engine layout."""
-        w = self.params[s.name + ".weight"]
+        w = (dst or self.params)[s.name + ".weight"]
         t = t.to(self.device, torch.float32)
         if s.name == "backbone.conv1":
             w.zero_()
@@ -225,10 +231,35 @@ class YoloV3Engine:
                 if b + ".num_batches_tracked" in sd:
                     self.num_batches_tracked = int(sd[b + ".num_batches_tracked"])
 
-    def reference_state_dict(self, grads=False):
-        """Parameters (or their gradients) under the reference's names, layouts and key order."""
+    def reference_parameter_tensors(self, flat):
+        """A flat buffer with the engine's layout (e.g. an optimizer's momentum) as the list of tensors the reference's
+        `model.parameters()` would pair with it: reference layouts (OIHW), reference order."""
+        sd = self.reference_state_dict(src=self.flat_views(flat), params_only=True)
+        return list(sd.values())
+
+    def load_reference_parameter_tensors(self, tensors, flat):
+        """Inverse of reference_parameter_tensors: fill `flat` from per-parameter tensors in the reference's parameters() order."""
+        dst = self.flat_views(flat)
+        names = list(self.reference_state_dict(params_only=True).keys())
+        if len(names) != len(tensors):
+            raise ValueError(f"expected {len(names)} parameter tensors, got {len(tensors)}")
+        byname = dict(zip(names, tensors))
+        for s in self.specs:
+            self._set_weight_oihw(s, byname[s.name + ".weight"], dst)
+            if s.bias:
+                dst[s.name + ".bias"].copy_(byname[s.name + ".bias"])
+            if s.bn:
+                b = bn_name(s.name)
+                dst[b + ".weight"].copy_(byname[b + ".weight"])
+                dst[b + ".bias"].copy_(byname[b + ".bias"])
+
+    def reference_state_dict(self, grads=False, src=None, params_only=False):
+        """Parameters (or their gradients, or any buffer given as `src` views) under the reference's names, layouts and key order."""
         out = {}
-        src = self.grads if grads else self.params
+        if src is None:
+            src = self.grads if grads else self.params
+        else:
+            grads = True
         for s in self.specs:
             out[s.name + ".weight"] = self._get_weight_oihw(s, src)
             if s.bias:
@@ -237,7 +268,7 @@ class YoloV3Engine:
                 b = bn_name(s.name)
                 out[b + ".weight"] = src[b + ".weight"].clone()
                 out[b + ".bias"] = src[b + ".bias"].clone()
-                if not grads:
+                if not grads and not params_only:
                     for k in (".running_mean", ".running_var"):
                         out[b + k] = self.buffers[b + k].clone()
                     out[b + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked, dtype=torch.int64)

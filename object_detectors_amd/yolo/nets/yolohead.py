@@ -57,3 +57,51 @@ class YoloHead(nn.Module):
     def load_state_dict(self, sd, strict=True):
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
         self.engine.load_reference_state_dict(sd)
+
+    def load_darknet_weights(self, weights_path):
+        """yolohead.py:90-165: a darknet `.weights` file = 5 int32 header words, then float32 values consumed while walking the
+        state dict: for every conv + BN pair `bn.bias, bn.weight, bn.running_mean, bn.running_var, conv.weight`, for a biased conv
+        (the three conv_out layers) `conv.bias, conv.weight`.  (The reference's walk raises on `num_batches_tracked`, a key that
+        did not exist in the torch it was written for; it is skipped here.)  Returns the number of floats consumed."""
+        import numpy as np
+        with open(weights_path, "rb") as fp:
+            np.fromfile(fp, dtype=np.int32, count=5)
+            weights = np.fromfile(fp, dtype=np.float32)
+        sd = self.state_dict()
+        ptr = 0
+        last_bn_weight = last_conv = None
+
+        def take(key):
+            nonlocal ptr
+            n = sd[key].numel()
+            if ptr + n > weights.size:
+                raise ValueError(f"{weights_path}: file ends inside {key} ({weights.size} floats)")
+            sd[key] = torch.from_numpy(weights[ptr:ptr + n].copy()).view_as(sd[key])
+            ptr += n
+        for k in list(sd.keys()):
+            if "bn" in k:
+                if "num_batches_tracked" in k:
+                    continue
+                if "weight" in k:
+                    last_bn_weight = k
+                elif "bias" in k:
+                    take(k)
+                    take(last_bn_weight)
+                    last_bn_weight = None
+                elif "running_mean" in k:
+                    take(k)
+                elif "running_var" in k:
+                    take(k)
+                    take(last_conv)
+                    last_conv = None
+                else:
+                    raise Exception("Error for bn")
+            elif "conv" in k:
+                if "weight" in k:
+                    last_conv = k
+                else:
+                    take(k)
+                    take(last_conv)
+                    last_conv = None
+        self.load_state_dict(sd)
+        return ptr

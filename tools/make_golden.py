@@ -820,6 +820,108 @@ def g14_transform():
     np.savez_compressed(os.path.join(OUT, "g14_transform.npz"), **d)
 
 
+def g15_outputs(helper, custom, yolo_forw, yolohead, darknet):
+    """Output / wire formats and checkpoint formats of the reference:
+      * test_one_epoch (yolo/procedures/test_one_epoch.py:6-67) run AS IS on a stand-in dataloader / model (CPU): the COCO result dicts for
+        the 'coco' (80 -> 91 map) and 'lvis' (label + 1) branches, with an image that yields no detection in the middle (the reference then
+        pairs the later images with the wrong targets entry - pinned, not fixed);
+      * CocoEvaluator.prepare_for_coco_detection (torchvision_models/detection/coco_eval.py:83-105);
+      * YoloHead.load_darknet_weights (yolo/nets/yolohead.py:90-165) on a synthetic .weights stream (darknet_21)."""
+    import importlib
+    import tempfile
+    import types as _t
+    d = {}
+    sys.modules["torchvision.ops"].boxes = sys.modules["torchvision.ops.boxes"]
+    toe = importlib.import_module("procedures.test_one_epoch")
+    C, img, grids, bs = 80, 128, (4, 8, 16), 3
+    heads = synth_heads(7700, bs, 3, C, grids)
+    for h in heads:                      # image 1: objectness logits far below zero -> nothing passes the confidence filter
+        hv = h.reshape(bs, 3, 5 + C, h.shape[2], h.shape[3])
+        hv[1, :, 4] = -20.0
+    d["meta"] = np.array([7700, C, img, bs], np.int64)
+    d["conf"] = np.array([0.02], np.float32)
+    sizes = [(375, 500), (480, 640), (333, 500)]
+    ids = [139, 285, 632]
+    d["img_sizes"], d["image_ids"] = np.array(sizes, np.int64), np.array(ids, np.int64)
+
+    class Model:
+        def eval(self):
+            return self
+
+        def __call__(self, images):
+            return [torch.from_numpy(h) for h in heads]
+
+    class Loader(list):
+        pass
+    real_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and isinstance(a[0], str)) else real_to(self, *a, **k)
+    try:
+        for dset in ("coco", "lvis"):
+            F = make_yoloforw(yolo_forw, custom, COCO_ANCHORS, C, img)
+            targets = [{"img_size": torch.tensor(s), "image_id": torch.tensor(i)} for s, i in zip(sizes, ids)]
+            loader = Loader([(torch.zeros(bs, 3, img, img), targets)])
+            loader.dset_name = dset
+            cfg = _t.SimpleNamespace(yolo=_t.SimpleNamespace(inf_confidence=0.02, inf_iou_threshold=0.6), dataset=_t.SimpleNamespace(inp_dim=img))
+            res = toe.test_one_epoch(loader, Model(), F, cfg)
+            d[f"{dset}_bbox"] = np.array([r["bbox"] for r in res], np.float32)
+            d[f"{dset}_area"] = np.array([r["area"] for r in res], np.float32)
+            d[f"{dset}_category_id"] = np.array([r["category_id"] for r in res], np.int64)
+            d[f"{dset}_score"] = np.array([r["score"] for r in res], np.float32)
+            d[f"{dset}_image_id"] = np.array([r["image_id"] for r in res], np.int64)
+    finally:
+        torch.Tensor.to = real_to
+    # ---- torchvision path
+    stub_torchvision_permissive()
+    for name in ("pycocotools", "pycocotools.mask", "pycocotools.coco", "pycocotools.cocoeval"):
+        sys.modules[name] = _Permissive(name)
+    sys.modules["torch._six"] = _t.ModuleType("torch._six")
+    sys.modules["torch._six"].string_classes = (str,)
+    torch._six = sys.modules["torch._six"]
+    sys.path.insert(0, os.path.join(REF, "torchvision_models"))
+    ce = importlib.import_module("detection.coco_eval")
+    preds = {}
+    for j, iid in enumerate((42, 7, 99)):
+        k = (5, 0, 3)[j]
+        x1 = detrand.uniform(7800 + j, (k, 2), 0, 300)
+        preds[iid] = {"boxes": torch.from_numpy(np.concatenate([x1, x1 + detrand.uniform(7810 + j, (k, 2), 4, 200)], 1).astype(np.float32)),
+                      "scores": torch.from_numpy(detrand.uniform(7820 + j, (k,), 0, 1)),
+                      "labels": torch.from_numpy(detrand.randint(7830 + j, (k,), 1, 91))}
+        d[f"tv_boxes{iid}"], d[f"tv_scores{iid}"], d[f"tv_labels{iid}"] = (preds[iid][q].numpy() for q in ("boxes", "scores", "labels"))
+    out = ce.CocoEvaluator.prepare_for_coco_detection(None, preds)
+    d["tv_out_image_id"] = np.array([r["image_id"] for r in out], np.int64)
+    d["tv_out_category_id"] = np.array([r["category_id"] for r in out], np.int64)
+    d["tv_out_bbox"] = np.array([r["bbox"] for r in out], np.float32)
+    d["tv_out_score"] = np.array([r["score"] for r in out], np.float32)
+    # ---- darknet .weights: the reference's walk over the state dict (the keys torch >= 0.4.1 adds, num_batches_tracked, hidden from it:
+    #      the walk was written before they existed and raises on them)
+    bname = "darknet_21"
+    yolohead.backbone_fn[bname] = lambda path: darknet.darknet21(None)
+    cfgm = {"backbone": {"backbone_name": bname, "backbone_pretrained": ""}, "dataset": {"anchors": COCO_ANCHORS}, "yolo": {"classes": 80},
+            "neck": {"fpn": False, "spp": False, "spp_bottleneck": True, "pyramids": []}}
+    m = yolohead.YoloHead(cfgm)
+    full_sd = m.state_dict
+    from collections import OrderedDict
+    m.state_dict = lambda: OrderedDict((k, v) for k, v in full_sd().items() if "num_batches_tracked" not in k)
+    total = sum(v.numel() for k, v in m.state_dict().items())
+    stream = detrand.uniform(7900, (total + 11,), -1.0, 1.0)       # a few surplus floats, as real files may carry
+    with tempfile.NamedTemporaryFile(suffix=".weights") as f:
+        np.array([0, 2, 0, 32013312, 0], np.int32).tofile(f)
+        stream.tofile(f)
+        f.flush()
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.load_darknet_weights(f.name)
+    d["dw_total"] = np.array([total], np.int64)
+    names, first, sums = [], [], []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        first.append(float(v.reshape(-1)[0]))
+        sums.append(float(v.double().sum()))
+    d["dw_names"], d["dw_first"], d["dw_sum"] = np.array(names), np.array(first, np.float32), np.array(sums, np.float64)
+    np.savez_compressed(os.path.join(OUT, "g15_outputs.npz"), **d)
+
+
 def main():
     """python tools/make_golden.py [fixture ...]   (no argument: all; names = the npz stems, e.g. g8b_network256)"""
     os.makedirs(OUT, exist_ok=True)
@@ -841,6 +943,8 @@ def main():
         g8_network(yolohead, darknet)
     if want("g8b_network256"):
         g8b_network256(yolohead, darknet)
+    if want("g15_outputs"):
+        g15_outputs(helper, custom, yolo_forw, yolohead, darknet)
     if want("g5_7_tvision"):
         g5_7_tvision()
     if want("g12_retinanet"):
