@@ -73,28 +73,40 @@ def pmc_traffic(batch, px):
     return (round(b / n) if n else None), "profiles/r01d_pmc_summary.md", (round(mu, 1) if mu is not None else None)
 
 
-def cpu_baseline(px, sample_bs=2, iters=2):
-    """The CPU restatement (oracle/net_oracle.py torch-fp32 Darknet-53+head and oracle/yolo_oracle.py criterion
-    shapes) on the host cores: one fwd+bwd of `sample_bs` images per iteration.  Baseline only."""
+def cpu_baseline(px, sample_bs=1, warmup=3, iters=10):
+    """SURVEY 8(d) protocol: the CPU restatement of the SAME step - oracle/net_oracle.py (torch-fp32 Darknet-53 + YoloHead, forward and
+    autograd backward) driven by the criterion oracle/yolo_oracle.py:yolo_loss (assignment, six loss terms, head gradients) - on the host
+    cores of this box: `warmup` + `iters` iterations on a bounded sample of the workload (`sample_bs` images of the same size and GT
+    density), median.  Baseline only: a large GPU/CPU ratio says nothing about kernel quality."""
     from oracle import net_oracle
+    from oracle import yolo_oracle as yo
     torch.manual_seed(0)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = torch.get_num_threads()
     sd = net_oracle.det_state("darknet_53", 5000)
     for k, v in sd.items():
         if v.dtype == torch.float32:
             v.requires_grad_(not k.endswith(("running_mean", "running_var")))
-    x = torch.randn(sample_bs, 3, px, px)
+    imgs, targets = synth_batch(sample_bs, px, 0, torch.device("cpu"))
+    tg = [(t["bbox"].numpy(), t["category_id"].numpy()) for t in targets]
+    spec = yo.YoloSpec(ANCHORS, 80, px)
     times = []
-    for it in range(iters + 1):
+    for it in range(warmup + iters):
         t0 = time.perf_counter()
-        outs = net_oracle.forward(sd, x, "darknet_53", training=True)
-        loss = sum((o * o).mean() for o in outs)       # stand-in scalar with dense head gradients
-        loss.backward()
+        outs = net_oracle.forward(sd, imgs, "darknet_53", training=True)
+        res = yo.yolo_loss(spec, [o.detach().numpy() for o in outs], tg, want_grad=True)        # the criterion and its head gradients
+        torch.autograd.backward(list(outs), [torch.from_numpy(g) for g in res["grads"]])
         for v in sd.values():
             v.grad = None
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": round(sample_bs / t, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} timed fwd+bwd iterations of bs={sample_bs} at {px}px (torch-CPU fp32 restatement, median)"}
+    timed = sorted(times[warmup:])
+    t = timed[len(timed) // 2]
+    return {"value": round(sample_bs / t, 4), "unit": "images/s", "cores": cores, "torch_threads": threads, "kind": "port",
+            "sample": f"{warmup} warm-up + {iters} timed iterations of fwd + criterion + bwd on {sample_bs} image(s) at {px}px, 7 GT/img "
+                      f"(oracle/net_oracle.py torch-CPU fp32 + oracle/yolo_oracle.py numpy criterion), median; {sum(times):.0f} s of CPU work"}
 
 
 def main():
@@ -187,7 +199,11 @@ def main():
             if k % ev_every != 0:
                 return orig_run(calls)
             from object_detectors_amd._lib import check
+            from object_detectors_amd.yolo.nets.engine import comm_hook
             for i, (fn, a) in enumerate(calls):
+                if fn is comm_hook:
+                    a[0](*a[1:])
+                    continue
                 if i in idx:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -240,7 +256,7 @@ def main():
                     "launches": len(events), "avg_launch_us": round(1000.0 * tot_ms / len(events), 2),
                     "gflop_per_launch": round(tot_fl / len(events) / 1e9, 3)}
         line = {
-            "metric": "images/sec (fwd+bwd) YOLOv3 640px bs=32", "value": round(value, 2), "unit": "images/s",
+            "metric": f"images/sec (fwd+bwd) YOLOv3 {args.px}px bs={args.batch}", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+loss+bwd{'+grad all-reduce' if world > 1 else ''}+SGD step), "

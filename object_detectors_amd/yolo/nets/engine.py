@@ -96,8 +96,12 @@ def bn_name(conv_name):
 
 
 class YoloV3Engine:
-    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0):
+    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0, sync_bn=False, process_group=None):
+        """sync_bn: the `batch_norm_sync` switch of the reference (yolo/procedures/initialize.py:31-32, apex convert_syncbn_model): every
+        BatchNorm layer normalises with the statistics of the GLOBAL batch - one all-reduce of the per-channel (sum, sum of squares) in
+        forward and one of (sum dy, sum dy*xhat) in backward per layer (2C floats each: latency-bound, 72 layers)."""
         lib()   # fail loudly if the HIP library is missing
+        self.sync_bn, self.process_group = bool(sync_bn), process_group
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.backbone, self.na, self.nc = backbone, num_anchors, num_classes
         self.head_c = num_anchors * (5 + num_classes)
@@ -351,6 +355,21 @@ class Plan:
         self.head_grads = [torch.zeros((n, g[0], g[1], eng.head_ld), device=dev, dtype=bf) for g in (g5, g4, g3)]
         self.ops = []   # forward-ordered op records for the backward builder
 
+        import torch.distributed as dist
+        world = dist.get_world_size(eng.process_group) if (eng.sync_bn and training and dist.is_available() and dist.is_initialized()) else 1
+        self.sync_world = world
+
+        def sync_sum(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=eng.process_group)
+
+        def sync_avg(t):
+            # backward sums: the apply pass divides by the LOCAL element count, so the rank average gives the global mean (equal shards);
+            # dgamma / dbeta then hold global / world on every rank, which the gradient all-reduce (an average) leaves unchanged - what
+            # apex SyncBN + DDP produce
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=eng.process_group)
+            t.div_(world)
+        self._sync_avg = sync_avg
+
         # ---- forward graph
         def conv_bn(name, x, out=None, res=None):
             s = eng.by_name[name]
@@ -384,10 +403,22 @@ class Plan:
             stats = torch.zeros((rows + 64, 2, cp), device=dev, dtype=torch.float32)
             self.keep += [shp, z, stats, ss]
             self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp), x.ptr, _vp(wf), None, _vp(z), 0, _vp(stats), cp, self.stream)))
-            self.fwd.append((L.mi355det_bn_finalize, (_vp(stats), rows, shp.cout, cp, pixels, _vp(eng.params[b + ".weight"]),
-                                                      _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
-                                                      _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
-                                                      _vp(ss), self.stream)))
+            if world > 1:
+                # SyncBN: fold the partial rows into ONE row [sum | sum of squares] (the generic row reduction), all-reduce it, and
+                # finalise from that row with the global element count
+                row = torch.zeros((1, 2, cp), device=dev, dtype=torch.float32)
+                self.keep.append(row)
+                self.fwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(stats), rows, cp, cp, _vp(row), self.stream)))
+                self.fwd.append((comm_hook, (sync_sum, row)))
+                self.fwd.append((L.mi355det_bn_finalize, (_vp(row), 1, shp.cout, cp, pixels * world, _vp(eng.params[b + ".weight"]),
+                                                          _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
+                                                          _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
+                                                          _vp(ss), self.stream)))
+            else:
+                self.fwd.append((L.mi355det_bn_finalize, (_vp(stats), rows, shp.cout, cp, pixels, _vp(eng.params[b + ".weight"]),
+                                                          _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
+                                                          _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
+                                                          _vp(ss), self.stream)))
             self.fwd.append((L.mi355det_bn_act_fwd, (_vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE, res.ptr if res else None,
                                                      res.ld if res else 0, a.ptr, a.ld, self.stream)))
             self.dz_elems = max(self.dz_elems, pixels * shp.cout)
@@ -566,12 +597,15 @@ class Plan:
                 di = flip[0]
                 flip[0] ^= 1
                 dzb = self.dz2[di]
+                rec["dz_index"] = di
                 if "bn_partials" in rec:      # the dgrad that produced g already accumulated the per-channel partial sums
                     part, prows, cpad = rec["bn_partials"]
                     self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), prows, shp.cout, cpad, _vp(sums), self.stream)))
                 else:
                     self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
                                                                     _vp(sums), self.stream)))
+                if self.sync_world > 1:
+                    py(self._sync_avg, sums)              # SyncBN backward: (sum dy, sum dy*xhat) of the global batch
                 if wg_done[di] is not None:
                     py(main.wait_event, wg_done[di])      # the wgrad that last read this dz buffer has finished
                 self.bwd.append((L.mi355det_bn_act_bwd_apply, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), _vp(sums), None, shp.cout,

@@ -29,7 +29,9 @@ class YoloHead(nn.Module):
         cfgb = config["backbone"]
         na = len(config["dataset"]["anchors"][0])
         nc = config["yolo"]["classes"]
-        self.engine = YoloV3Engine(cfgb.get("backbone_name", "darknet_53"), na, nc)
+        # `batch_norm_sync` is the reference's switch for apex SyncBN (yolo/procedures/initialize.py:31-32; yolo/hydra/config.yaml)
+        sync = bool(config.get("batch_norm_sync", False)) if hasattr(config, "get") else bool(getattr(config, "batch_norm_sync", False))
+        self.engine = YoloV3Engine(cfgb.get("backbone_name", "darknet_53"), na, nc, sync_bn=sync)
         self.layers_out_filters = [64, 128, 256, 512, 1024]
         # parameters are views into the engine's flat master buffer (conv weights in OHWI layout)
         self._pnames, self._plist = [], nn.ParameterList()
