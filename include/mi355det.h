@@ -207,6 +207,11 @@ int mi355det_roi_align_nhwc(const void* const* feats, const int32_t* hs, const i
  * (the "> score_thresh" filter).  idx_out/val_out [rows,k], count_out [rows] = number selected; k <= 16384. */
 int mi355det_topk(const float* x, int32_t rows, int64_t n, int64_t row_stride, int32_t k, float min_value,
                   int64_t* idx_out, float* val_out, int32_t* count_out, void* stream);
+/* the same for LONG rows (n >= 65536: several workgroups per row, 3 histogram launches + collect + sort); shorter rows are forwarded to
+ * mi355det_topk.  workspace: mi355det_topk_workspace(rows) bytes. */
+size_t mi355det_topk_workspace(int32_t rows);
+int mi355det_topk_ws(const float* x, int32_t rows, int64_t n, int64_t row_stride, int32_t k, float min_value, int64_t* idx_out,
+                     float* val_out, int32_t* count_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution path (yolo/nets/backbone/darknet.py:13-20,41-43,64-66; yolo/nets/yolohead.py:41-61):

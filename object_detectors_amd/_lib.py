@@ -110,6 +110,8 @@ PROTOTYPES = {
     "mi355det_upsample2x_bwd": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mi355det_nchw_f32_to_nhwc": (C.c_int, [vp, i32, i32, i32, i32, vp, C.c_int, i32, vp]),
     "mi355det_nhwc_to_nchw_f32": (C.c_int, [vp, C.c_int, i32, i32, i32, i32, i32, vp, vp]),
+    "mi355det_topk_workspace": (sz, [i32]),
+    "mi355det_topk_ws": (C.c_int, [vp, i32, i64, i64, i32, C.c_float, vp, vp, vp, vp, sz, vp]),
     "mi355det_resize_bilinear": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mi355det_resize_boxes": (C.c_int, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "mi355det_coco_rows": (C.c_int, [vp, i32, vp, vp, i32, i64, f32, f32, f32, i32, i32, vp, vp, vp, vp]),

@@ -515,19 +515,21 @@ __device__ __forceinline__ void sfl(float x, float t, float alpha, float gamma, 
 }
 
 // TGT_MODE 0: dense target tensor t; 1: target from Matcher output (matched>=0 -> class gt_labels[matched])
-template <int TGT_MODE>
-__global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x, const float* __restrict__ t, const long long* __restrict__ matched,
+#define FOCAL_THREADS 1024     // 16 waves fold their sums through LDS: ONE atomic per workgroup on the loss word, <= 512 workgroups (atomics to
+                               // one address retire at ~90 per microsecond: 2048 of them were 23 of the kernel's 56 us at K = 91)
+template <int TGT_MODE, int NT = FOCAL_THREADS>
+__global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, const float* __restrict__ t, const long long* __restrict__ matched,
                                                     const long long* __restrict__ gt_labels, const float* __restrict__ scale,
                                                     const unsigned char* __restrict__ valid, long long rows, int k, float alpha, float gamma,
                                                     float gscale, float* __restrict__ loss_sum, float* __restrict__ grad,
                                                     const float* __restrict__ nfg = nullptr, long long rows_per_image = 0,
                                                     const int* __restrict__ gt_off = nullptr, float inv_images = 1.f) {
-  __shared__ float red[4];
+  __shared__ float red[NT / WAVE];
   const long long total = rows * k;
   const bool vec = (total & 3) == 0;      // 4 consecutive elements per lane: 16-byte loads/stores of logits and gradients
   float acc = 0.f;
   const long long nvec = vec ? total / 4 : total;
-  for (long long q = blockIdx.x * 256ll + threadIdx.x; q < nvec; q += (long long)gridDim.x * 256) {
+  for (long long q = blockIdx.x * (long long)NT + threadIdx.x; q < nvec; q += (long long)gridDim.x * NT) {
     const long long i0 = vec ? q * 4 : q;
     long long r = total < (1ll << 31) ? (long long)((unsigned)i0 / (unsigned)k) : i0 / k;
     int c = (int)(i0 - r * k);
@@ -589,7 +591,12 @@ __global__ __launch_bounds__(256) void focal_kernel(const float* __restrict__ x,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss_sum, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / WAVE; ++w) t += red[w];
+    atomicAdd(loss_sum, t);
+  }
 }
 
 // ---- RetinaNet head losses for a whole batch (retinanet.py:56-62,107-143,196-223) ---------------------------------
@@ -752,13 +759,27 @@ int mi355det_anchor_grid(const float* cell, int32_t a, int32_t gh, int32_t gw, i
   return check_launch("anchor_grid");
 }
 
+// Launch geometry of the focal kernels.  Small problems (K = 91: 11 M elements, 87 MB) finish in a few iterations per thread, and the ONE
+// atomic each workgroup adds to the loss word then matters (atomics to one address retire at ~90 per microsecond): 512 workgroups of 1024
+// threads.  Large ones (K = 1204: 145 M elements) are bandwidth / VALU bound and balance better over many small workgroups.
+#define FOCAL_LAUNCH(MODE, total_elems, ...)                                                                                                   \
+  do {                                                                                                                                         \
+    const long long q4_ = (total_elems) / 4 + 1;                                                                                               \
+    if ((total_elems) >= (64ll << 20)) {                                                                                                       \
+      const int blocks_ = (int)min((long long)256 * 32, (q4_ + 255) / 256);                                                                    \
+      hipLaunchKernelGGL((focal_kernel<MODE, 256>), dim3(blocks_), dim3(256), 0, __VA_ARGS__);                                                 \
+    } else {                                                                                                                                   \
+      const int blocks_ = (int)min((long long)512, (q4_ + FOCAL_THREADS - 1) / FOCAL_THREADS);                                                 \
+      hipLaunchKernelGGL((focal_kernel<MODE, FOCAL_THREADS>), dim3(blocks_), dim3(FOCAL_THREADS), 0, __VA_ARGS__);                             \
+    }                                                                                                                                          \
+  } while (0)
+
 int mi355det_sigmoid_focal_loss(const float* x, const float* t, const float* scale, const uint8_t* valid, int64_t rows, int32_t k, float alpha,
                                 float gamma, float grad_scale, float* loss_sum, float* grad, void* stream) {
   if (rows < 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "sigmoid_focal_loss");
   if (rows == 0) return 0;
-  const int blocks = (int)min((long long)256 * 8, (long long)((rows * k + 255) / 256));
-  hipLaunchKernelGGL(focal_kernel<0>, dim3(blocks), dim3(256), 0, S(stream), x, t, (const long long*)nullptr, (const long long*)nullptr, scale,
-                     valid, (long long)rows, k, alpha, gamma, grad_scale, loss_sum, grad);
+  FOCAL_LAUNCH(0, (long long)rows * k, S(stream), x, t, (const long long*)nullptr, (const long long*)nullptr, scale, valid, (long long)rows, k, alpha,
+               gamma, grad_scale, loss_sum, grad, (const float*)nullptr, 0ll, (const int*)nullptr, 1.f);
   return check_launch("sigmoid_focal_loss");
 }
 
@@ -766,10 +787,9 @@ int mi355det_retina_cls_loss(const float* logits, const int64_t* matched, const 
                              float alpha, float gamma, float grad_scale, float* loss_sum, float* grad, void* stream) {
   if (rows < 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "retina_cls_loss");
   if (rows == 0) return 0;
-  const int blocks = (int)min((long long)256 * 8, (long long)((rows * k + 255) / 256));
-  hipLaunchKernelGGL(focal_kernel<1>, dim3(blocks), dim3(256), 0, S(stream), logits, (const float*)nullptr, (const long long*)matched,
-                     (const long long*)gt_labels, scale, (const unsigned char*)nullptr, (long long)rows, k, alpha, gamma, grad_scale, loss_sum,
-                     grad);
+  FOCAL_LAUNCH(1, (long long)rows * k, S(stream), logits, (const float*)nullptr, (const long long*)matched, (const long long*)gt_labels, scale,
+               (const unsigned char*)nullptr, (long long)rows, k, alpha, gamma, grad_scale, loss_sum, grad, (const float*)nullptr, 0ll,
+               (const int*)nullptr, 1.f);
   return check_launch("retina_cls_loss");
 }
 
@@ -786,10 +806,9 @@ int mi355det_retina_loss(const float* cls_logits, const float* bbox_regression, 
   hipLaunchKernelGGL(count_fg_kernel, dim3((int)min((long long)64, (long long)((rows_per_image + 255) / 256)), n_images), dim3(256), 0, st,
                      (const long long*)matched, (long long)rows_per_image, num_fg);
   const long long rows = (long long)n_images * rows_per_image;
-  const int blocks = (int)min((long long)256 * 8, (long long)((rows * k + 255) / 256));
-  hipLaunchKernelGGL(focal_kernel<1>, dim3(blocks), dim3(256), 0, st, cls_logits, (const float*)nullptr, (const long long*)matched,
-                     (const long long*)gt_labels, class_scale, (const unsigned char*)nullptr, rows, k, alpha, gamma, grad_scale, losses, grad_logits,
-                     (const float*)num_fg, (long long)rows_per_image, (const int*)gt_offsets, 1.0f / (float)n_images);
+  FOCAL_LAUNCH(1, rows * k, st, cls_logits, (const float*)nullptr, (const long long*)matched, (const long long*)gt_labels, class_scale,
+               (const unsigned char*)nullptr, rows, k, alpha, gamma, grad_scale, losses, grad_logits, (const float*)num_fg, (long long)rows_per_image,
+               (const int*)gt_offsets, 1.0f / (float)n_images);
   hipLaunchKernelGGL(retina_reg_kernel, dim3((int)min((long long)2048, (rows + 255) / 256)), dim3(256), 0, st, bbox_regression, anchors,
                      (const long long*)matched, gt_boxes, (const int*)gt_offsets, (const float*)num_fg, n_images, (long long)rows_per_image, 1.f, 1.f,
                      1.f, 1.f, grad_scale, losses + 1, grad_regression);

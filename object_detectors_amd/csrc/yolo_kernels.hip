@@ -601,6 +601,311 @@ __global__ __launch_bounds__(256) void yolo_decode_cl_kernel(mi355det_yolo_geom 
   }
 }
 
+
+// Channels-last decode, wave-per-pixel form (pixels with up to 64*KCH channels: COCO 3 x 85 = 255 -> KCH 4).  The LDS-tile form above
+// gives each (pixel, anchor) row to ONE thread, which walks the 80 classes three times through LDS: 192 busy threads per workgroup and
+// long dependent chains (1.5 TB/s, 19 % of the HBM roof).  Here a wave owns a pixel: lane l holds channels l, l+64, ..; every load and
+// store instruction of the wave is one contiguous 256-byte segment; softmax max / first-argmax / sum per anchor are masked wave reductions;
+// the largest class probability of a softmax row is exactly 1 * (1/sum) (its exponent is 0), so score and label need no second pass.
+// Full-wave reductions on the DPP path (no LDS crossbar: a __shfl_xor butterfly is six dependent ds_bpermute round trips, ~600 cycles; the
+// decode needs nine reductions per pixel).  Rows of 16 lanes by quad_perm / row_ror, then row_bcast15 / row_bcast31 carry the row totals
+// to lane 63, which is read back as a scalar.  `idn` is the operation's identity (lanes a DPP step does not write keep it).
+#define DPP_STEP(T, v, idn, op, ctrl, rmask)                                                                                                  \
+  v = op(v, __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, idn), __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false)))
+#define DPP_WAVE_REDUCE(T, v, idn, op)                                                                                                         \
+  do {                                                                                                                                         \
+    DPP_STEP(T, v, idn, op, 0xB1, 0xF);  /* quad_perm [1,0,3,2] */                                                                             \
+    DPP_STEP(T, v, idn, op, 0x4E, 0xF);  /* quad_perm [2,3,0,1] */                                                                             \
+    DPP_STEP(T, v, idn, op, 0x124, 0xF); /* row_ror:4 */                                                                                       \
+    DPP_STEP(T, v, idn, op, 0x128, 0xF); /* row_ror:8  -> every lane: its row's total */                                                      \
+    DPP_STEP(T, v, idn, op, 0x142, 0xA); /* row_bcast15: rows 1, 3 += last lane of rows 0, 2 */                                                \
+    DPP_STEP(T, v, idn, op, 0x143, 0xC); /* row_bcast31: rows 2, 3 += lane 31 -> lane 63 holds the wave's total */                             \
+  } while (0)
+__device__ __forceinline__ float op_max_f(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float op_add_f(float a, float b) { return a + b; }
+__device__ __forceinline__ int op_min_i(int a, int b) { return min(a, b); }
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  const float idn = -INFINITY;
+  DPP_WAVE_REDUCE(float, v, idn, op_max_f);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  const float idn = 0.0f;
+  DPP_WAVE_REDUCE(float, v, idn, op_add_f);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  const int idn = 0x7FFFFFFF;
+  DPP_WAVE_REDUCE(int, v, idn, op_min_i);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int KCH>
+__global__ __launch_bounds__(256) void yolo_decode_px_kernel(mi355det_yolo_geom geom, mi355det_head_view hv, int scale, const float* __restrict__ idf,
+                                                             int softmax_cls, float* __restrict__ out, float* __restrict__ score_out,
+                                                             int* __restrict__ label_out, int n_total, int bs) {
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int W = geom.grid[scale], hw = W * W, na = geom.na, C = geom.num_classes, attrs = C + 5, chans = na * attrs;
+  const int pitch = (int)hv.sp, off_scale = geom.off[scale];
+  const float gridf = (float)W, stride = geom.img_size / gridf;
+  // the role of this lane's channels is the same for every pixel
+  int an[KCH], at[KCH];
+  float mul[KCH], anc[KCH];
+  bool live[KCH];
+#pragma unroll
+  for (int k = 0; k < KCH; ++k) {
+    const int c = lane + 64 * k;
+    live[k] = c < chans;
+    an[k] = live[k] ? c / attrs : 0;
+    at[k] = live[k] ? c - an[k] * attrs : 0;
+    mul[k] = (live[k] && at[k] >= 5 && idf) ? idf[at[k] - 5] : 1.0f;
+    anc[k] = at[k] == 2 ? geom.anchor_w[scale][an[k]] : geom.anchor_h[scale][an[k]];
+  }
+  const unsigned npix = (unsigned)bs * (unsigned)hw;                     // < 2^31 (checked by the host)
+  const unsigned pstep = gridDim.x * 4;
+  unsigned p = blockIdx.x * 4 + wid;
+  float vn[KCH];                                                         // the NEXT pixel's channels: its loads fly while this pixel is decoded
+  auto load_px = [&](unsigned q) {
+    const unsigned bq = q / (unsigned)hw, pq = q - bq * (unsigned)hw;
+    const float* src = (const float*)hv.ptr + (long long)bq * hv.sb + (long long)pq * pitch;
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) vn[k] = (live[k] && q < npix) ? src[lane + 64 * k] : 0.0f;
+  };
+  load_px(p);
+  for (; p < npix; p += pstep) {
+    const int b = (int)(p / (unsigned)hw), pix = (int)(p - (unsigned)b * (unsigned)hw);
+    const int y = pix / W, x = pix - y * W;
+    float v[KCH], o[KCH];
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) v[k] = vn[k];
+    load_px(p + pstep);
+    const float cx = ((float)x + 0.5f) / gridf, cy = ((float)y + 0.5f) / gridf;
+#pragma unroll
+    for (int k = 0; k < KCH; ++k) {
+      const int t = at[k];
+      if (t >= 5) {
+        o[k] = mul[k] * v[k];                                    // class logit (tf-idf scaled), finished below
+      } else if (t == 2 || t == 3) {
+        o[k] = __expf(v[k]) * anc[k] * gridf * stride;
+      } else {
+        const float sg = 1.0f / (1.0f + __expf(-v[k]));
+        o[k] = t == 4 ? sg : (sg + (t == 0 ? cx : cy) * gridf - 0.5f) * stride;
+      }
+    }
+    float my_score = 0.0f;
+    int my_label = 0;
+    for (int a = 0; a < na; ++a) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < KCH; ++k)
+        if (live[k] && an[k] == a && at[k] >= 5) m = fmaxf(m, o[k]);
+      m = wave_max_dpp(m);
+      int idx = 0x7FFFFFFF;
+#pragma unroll
+      for (int k = 0; k < KCH; ++k)
+        if (live[k] && an[k] == a && at[k] >= 5 && o[k] == m) idx = min(idx, at[k] - 5);
+      idx = wave_min_i(idx);                                       // first maximum, as torch.max
+      float best;
+      if (softmax_cls) {
+        float se = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+          if (live[k] && an[k] == a && at[k] >= 5) {
+            o[k] = __expf(o[k] - m);
+            se += o[k];
+          }
+        se = wave_sum_dpp(se);
+        const float inv = 1.0f / se;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+          if (live[k] && an[k] == a && at[k] >= 5) o[k] *= inv;
+        best = 1.0f * inv;                                         // exp(m - m) * inv
+      } else {
+#pragma unroll
+        for (int k = 0; k < KCH; ++k)
+          if (live[k] && an[k] == a && at[k] >= 5) o[k] = 1.0f / (1.0f + __expf(-o[k]));
+        best = 1.0f / (1.0f + __expf(-m));
+      }
+      if (score_out) {
+        const int c4 = a * attrs + 4;
+        float cand = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) cand = (c4 >> 6) == k ? o[k] : cand;
+        const float conf = __shfl(cand, c4 & 63, WAVE);
+        if (lane == a) {
+          my_score = conf * best;
+          my_label = idx;
+        }
+      }
+    }
+    const long long row0 = (long long)b * n_total + off_scale + (long long)pix * na;
+    float* dst = out + row0 * attrs;
+#pragma unroll
+    for (int k = 0; k < KCH; ++k)
+      if (live[k]) dst[lane + 64 * k] = o[k];
+    if (score_out && lane < na) {
+      score_out[row0 + lane] = my_score;
+      label_out[row0 + lane] = my_label;
+    }
+  }
+}
+
+
+// Channels-last decode, half-wave-per-row form (attrs <= 32 * E): a wave decodes TWO (pixel, anchor) rows, lane i of each half holds attributes
+// i, i+32, .. of its row.  Every attribute costs one exponential (the sign / offset of its argument depends on its role), the softmax maximum,
+// first arg-max and sum are 32-lane DPP reductions, and the role of a lane never changes, so nothing in the loop branches.  (The
+// wave-per-pixel form above needed per-anchor masked loops: ~550 vector instructions per pixel, issue-bound at 1.8 TB/s.)
+__device__ __forceinline__ float half_bcast(float v, int half) {      // totals sit in lanes 31 / 63 after the row_bcast15 step
+  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return half ? hi : lo;
+}
+#define DPP_HALF_REDUCE(T, v, idn, op)                                                                                                         \
+  do {                                                                                                                                         \
+    DPP_STEP(T, v, idn, op, 0xB1, 0xF);                                                                                                        \
+    DPP_STEP(T, v, idn, op, 0x4E, 0xF);                                                                                                        \
+    DPP_STEP(T, v, idn, op, 0x124, 0xF);                                                                                                       \
+    DPP_STEP(T, v, idn, op, 0x128, 0xF);                                                                                                       \
+    DPP_STEP(T, v, idn, op, 0x142, 0xA); /* lanes 31 / 63: totals of lanes 0-31 / 32-63 */                                                     \
+  } while (0)
+
+struct DecDiv {
+  unsigned mul, shift;
+};
+static DecDiv make_decdiv(unsigned d) {
+  DecDiv f;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned ddiv(unsigned n, const DecDiv f) { return (__umulhi(f.mul, n) + n) >> f.shift; }    // n < 2^31
+
+template <int E>
+__global__ __launch_bounds__(256) void yolo_decode_row_kernel(mi355det_yolo_geom geom, mi355det_head_view hv, int scale, const float* __restrict__ idf,
+                                                              int softmax_cls, float* __restrict__ out, float* __restrict__ score_out,
+                                                              int* __restrict__ label_out, int n_total, int rows_per_image, DecDiv dna, DecDiv dW) {
+  __shared__ float s_anc[2][MI355DET_MAX_ANCHORS];
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int half = lane >> 5, li = lane & 31;
+  const int W = geom.grid[scale], na = geom.na, C = geom.num_classes, attrs = C + 5;
+  if (threadIdx.x < MI355DET_MAX_ANCHORS) {
+    s_anc[0][threadIdx.x] = geom.anchor_w[scale][threadIdx.x];
+    s_anc[1][threadIdx.x] = geom.anchor_h[scale][threadIdx.x];
+  }
+  __syncthreads();
+  const int pitch = (int)hv.sp, off_scale = geom.off[scale];
+  const float gridf = (float)W, stride = geom.img_size / gridf;
+  const int b = blockIdx.y;
+  const float* src_img = (const float*)hv.ptr + (long long)b * hv.sb;
+  float* out_img = out + ((long long)b * n_total + off_scale) * attrs;
+  // lane roles never change: element j of lane li is attribute li + 32 j; only element 0 can be a box attribute
+  float mul[E];
+  bool live[E], cls[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int t = li + 32 * j;
+    live[j] = t < attrs;
+    cls[j] = live[j] && t >= 5;
+    mul[j] = (cls[j] && idf) ? idf[t - 5] : 1.0f;
+  }
+  const bool is_wh = li == 2 || li == 3, is_x = li == 0, is_conf = li == 4;
+  const float sign0 = (cls[0] || !is_wh) ? -1.0f : 1.0f;           // exp argument of element 0 when it is a box attribute: v for w, h; -v otherwise
+  const unsigned nrows = (unsigned)rows_per_image;
+  const unsigned rstep = gridDim.x * 8;
+  unsigned r = (blockIdx.x * 4 + wid) * 2 + half;
+  float vn[E];
+  auto load_row = [&](unsigned q) {
+    const unsigned qq = min(q, nrows - 1);                             // past the end: a valid (unused) row, no branch
+    const unsigned pix = ddiv(qq, dna), a = qq - pix * (unsigned)na;
+    const float* src = src_img + (long long)pix * pitch + a * attrs;
+#pragma unroll
+    for (int j = 0; j < E; ++j) vn[j] = src[min(li + 32 * j, attrs - 1)];
+  };
+  load_row(r);
+  for (unsigned r0 = (blockIdx.x * 4 + wid) * 2; r0 < nrows; r0 += rstep, r += rstep) {     // r0: wave-uniform loop bound
+    const bool row_ok = r < nrows;
+    const unsigned rr = min(r, nrows - 1);
+    const unsigned pix = ddiv(rr, dna), a = rr - pix * (unsigned)na;
+    const unsigned y = ddiv(pix, dW), x = pix - y * (unsigned)W;
+    float v[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] = vn[j];
+    load_row(r + rstep);
+    // ---- class logits, their maximum and first arg-max over the row (32-lane reductions)
+    float z[E];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      z[j] = mul[j] * v[j];
+      m = fmaxf(m, cls[j] ? z[j] : -INFINITY);
+    }
+    {
+      const float idn = -INFINITY;
+      DPP_HALF_REDUCE(float, m, idn, op_max_f);
+    }
+    m = half_bcast(m, half);
+    int idx = 0x7FFFFFFF;
+#pragma unroll
+    for (int j = 0; j < E; ++j) idx = min(idx, (cls[j] && z[j] == m) ? li + 32 * j - 5 : 0x7FFFFFFF);
+    {
+      const int idn = 0x7FFFFFFF;
+      DPP_HALF_REDUCE(int, idx, idn, op_min_i);
+    }
+    const int idx_lo = __builtin_amdgcn_readlane(idx, 31), idx_hi = __builtin_amdgcn_readlane(idx, 63);
+    // ---- ONE exponential per attribute: class exp(z - m) (softmax) or exp(-z) (sigmoid); w, h exp(v); x, y, conf exp(-v)
+    float e[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const float carg = softmax_cls ? z[j] - m : -z[j];
+      const float arg = (j == 0 && !cls[0]) ? sign0 * v[0] : carg;
+      e[j] = __expf(arg);
+    }
+    float inv = 1.0f;
+    if (softmax_cls) {                                             // wave-uniform
+      float se = 0.0f;
+#pragma unroll
+      for (int j = 0; j < E; ++j) se += cls[j] ? e[j] : 0.0f;
+      {
+        const float idn = 0.0f;
+        DPP_HALF_REDUCE(float, se, idn, op_add_f);
+      }
+      inv = __builtin_amdgcn_rcpf(half_bcast(se, half));
+    }
+    float o[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+      const float sg = __builtin_amdgcn_rcpf(1.0f + e[j]);
+      o[j] = softmax_cls ? e[j] * inv : sg;                        // class attribute
+      if (j == 0) {                                                // box attributes live in element 0 only: selects, no branches
+        const float cgrid = ((float)(is_x ? x : y) + 0.5f) / gridf;
+        const float xy = (sg + cgrid * gridf - 0.5f) * stride;
+        const float wh = e[0] * s_anc[li == 3 ? 1 : 0][a] * gridf * stride;
+        const float box = is_wh ? wh : (is_conf ? sg : xy);
+        o[0] = cls[0] ? o[0] : box;
+      }
+    }
+    float* dst = out_img + (long long)rr * attrs;
+    if (row_ok) {
+#pragma unroll
+      for (int j = 0; j < E; ++j)
+        if (live[j]) dst[li + 32 * j] = o[j];
+    }
+    if (score_out) {                                               // wave-uniform
+      // conf sits in element 0 of lane 4 / 36; the largest class probability of a softmax row is exp(m - m) * inv
+      const float conf_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o[0]), 4));
+      const float conf_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o[0]), 36));
+      const float best = softmax_cls ? 1.0f * inv : __builtin_amdgcn_rcpf(1.0f + __expf(-m));
+      if (li == 0 && row_ok) {
+        const long long row = (long long)b * n_total + off_scale + rr;
+        score_out[row] = (half ? conf_hi : conf_lo) * best;
+        label_out[row] = half ? idx_hi : idx_lo;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // test_one_epoch.py:24-35 — score = conf*max(cls) (first maximum, as torch.max), one wave per row;
 // then per image an ORDERED compaction (the reference's boolean-mask order) of rows with score>thr.
@@ -768,6 +1073,43 @@ int mi355det_yolo_decode(const mi355det_yolo_geom* geom, const mi355det_head_vie
   bool channels_last = true;
   for (int k = 0; k < geom->num_scales; ++k)
     channels_last = channels_last && heads[k].sc == 1 && heads[k].sp >= geom->na * (geom->num_classes + 5) && heads[k].sp <= 4096 / 4 * 4;
+  const int chans = geom->na * (geom->num_classes + 5);
+  if (channels_last && geom->num_classes + 5 <= 128) {
+    // half a wave per (pixel, anchor) row
+    const int attrs = geom->num_classes + 5;
+    for (int k = 0; k < geom->num_scales; ++k) {
+      const long long nrows = (long long)geom->grid[k] * geom->grid[k] * geom->na;      // rows of one image at this scale
+      if (nrows >= (1ll << 30)) return fail(MI355DET_EINVAL, "%s: too many rows", "yolo_decode");
+      const int blocks = (int)max((long long)1, min((long long)(256 * 8 + bs - 1) / bs, (nrows + 7) / 8));
+      const DecDiv dna = make_decdiv((unsigned)geom->na), dW = make_decdiv((unsigned)geom->grid[k]);
+#define LAUNCH_ROW(E)                                                                                                                          \
+  hipLaunchKernelGGL(yolo_decode_row_kernel<E>, dim3(blocks, bs), dim3(256), 0, S(stream), *geom, heads[k], k, idf, softmax_cls, out, score_out, \
+                     (int*)label_out, N, (int)nrows, dna, dW)
+      if (attrs <= 32) LAUNCH_ROW(1);
+      else if (attrs <= 64) LAUNCH_ROW(2);
+      else if (attrs <= 96) LAUNCH_ROW(3);
+      else LAUNCH_ROW(4);
+#undef LAUNCH_ROW
+    }
+    return check_launch("yolo_decode");
+  }
+  if (channels_last && chans <= 512 && geom->na <= 64) {
+    // one wave per pixel: lanes over the pixel's channels
+    for (int k = 0; k < geom->num_scales; ++k) {
+      const long long npix = (long long)bs * geom->grid[k] * geom->grid[k];
+      if (npix >= (1ll << 31)) return fail(MI355DET_EINVAL, "%s: too many pixels", "yolo_decode");
+      const int blocks = (int)min((long long)256 * 8, (npix + 3) / 4);
+#define LAUNCH_PX(KCH)                                                                                                                         \
+  hipLaunchKernelGGL(yolo_decode_px_kernel<KCH>, dim3(blocks), dim3(256), 0, S(stream), *geom, heads[k], k, idf, softmax_cls, out, score_out, \
+                     (int*)label_out, N, bs)
+      if (chans <= 64) LAUNCH_PX(1);
+      else if (chans <= 128) LAUNCH_PX(2);
+      else if (chans <= 256) LAUNCH_PX(4);
+      else LAUNCH_PX(8);
+#undef LAUNCH_PX
+    }
+    return check_launch("yolo_decode");
+  }
   if (channels_last) {
     for (int k = 0; k < geom->num_scales; ++k) {
       const int hw = geom->grid[k] * geom->grid[k];

@@ -330,6 +330,11 @@ def topk_rows(x, k, min_value=float("-inf")):
     idx = torch.zeros((rows, k), device=x.device, dtype=torch.int64)
     val = torch.zeros((rows, k), device=x.device, dtype=torch.float32)
     cnt = torch.empty(rows, device=x.device, dtype=torch.int32)
+    if n >= 65536:          # long rows (flattened HWA x K score maps): several workgroups per row
+        wsb = lib().mi355det_topk_workspace(rows)
+        ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+        check(lib().mi355det_topk_ws(ptr(x), rows, n, x.stride(0), k, float(min_value), ptr(idx), ptr(val), ptr(cnt), ptr(ws), wsb, stream_ptr()), "topk")
+        return val, idx, cnt
     check(lib().mi355det_topk(ptr(x), rows, n, x.stride(0), k, float(min_value), ptr(idx), ptr(val), ptr(cnt), stream_ptr()), "topk")
     return val, idx, cnt
 

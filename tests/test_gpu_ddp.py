@@ -267,22 +267,19 @@ def _worker_rccl(rank, world, port, q):
         assert sync.use_avg
         sync.install(eng.plan(2, 128, 128, True))
         opt = FlatSGD.for_engine(eng, lr=1e-3, momentum=0.9, weight_decay=5e-4)
-        errs = []
-        for _ in range(3):
+        eng.train_step(x, tg, crit)
+        sync.wait()
+        torch.cuda.synchronize()
+        err = float((eng.flat_g - want).abs().max()) / (float(want.abs().max()) + 1e-30)
+        for _ in range(3):                                       # a few optimizer steps on the averaged gradients
+            opt.step()
             eng.train_step(x, tg, crit)
             sync.wait()
-            torch.cuda.synchronize()
-            errs.append(float((eng.flat_g - want).abs().max()) / (float(want.abs().max()) + 1e-30))
-            want = None if len(errs) > 1 else want
-            opt.step()
-            if want is None:
-                break
-            want = None
         torch.cuda.synchronize()
         w = eng.flat_w.clone()
         ref = w.clone()
         dist.broadcast(ref, 0)
-        q.put((rank, len(sync.buckets), errs[0], bool(torch.equal(w, ref))))
+        q.put((rank, len(sync.buckets), err, bool(torch.equal(w, ref))))
     except Exception as e:  # noqa: BLE001
         import traceback
         q.put((rank, -1, repr(e) + traceback.format_exc(), False))

@@ -179,3 +179,32 @@ def test_roi_align_channels_last_matches_nchw():
         want = a.grad.permute(0, 2, 3, 1)
         assert b.grad.dtype == torch.bfloat16
         assert float((b.grad.float() - want).abs().max()) <= 1e-2 * float(want.abs().max()) + 1e-6
+
+
+def test_topk_long_rows_multi_workgroup():
+    """mi355det_topk_ws (several workgroups per row) against a numpy selection: random rows, a threshold that cuts the candidates,
+    fewer valid elements than k, and rows of heavily repeated values (ties at the threshold, incl. the overflow fallback)."""
+    from object_detectors_amd import ops
+    rng = np.random.default_rng(3)
+
+    def ref_topk(row, k, min_value):
+        order = np.lexsort((np.arange(row.size), -row.astype(np.float64)))        # descending value, ties -> lower index
+        order = order[row[order] > min_value][:k]
+        return order
+
+    cases = [
+        (rng.standard_normal((2, 300000)).astype(np.float32), 2000, -np.inf),
+        (rng.standard_normal((3, 70001)).astype(np.float32), 1000, 1.5),            # threshold leaves more than k
+        (rng.standard_normal((1, 200000)).astype(np.float32), 1000, 3.9),           # fewer than k valid
+        (np.round(rng.standard_normal((2, 150000)) * 4).astype(np.float32) / 4, 3000, -np.inf),    # many exact ties at the cut
+        (np.zeros((1, 100000), np.float32), 500, -1.0),                              # everything ties: candidate list overflows -> exact redo
+        (np.concatenate([np.full((1, 90000), 2.0, np.float32), rng.standard_normal((1, 10000)).astype(np.float32)], 1), 700, -np.inf),
+    ]
+    for x, k, mv in cases:
+        val, idx, cnt = ops.topk_rows(torch.from_numpy(x).to("cuda:0"), k, min_value=float(mv) if np.isfinite(mv) else float("-inf"))
+        val, idx, cnt = val.cpu().numpy(), idx.cpu().numpy(), cnt.cpu().numpy()
+        for r in range(x.shape[0]):
+            want = ref_topk(x[r], k, mv)
+            assert cnt[r] == want.size, (x.shape, k, r, cnt[r], want.size)
+            assert np.array_equal(idx[r, :cnt[r]], want), (x.shape, k, r)
+            assert np.array_equal(val[r, :cnt[r]], x[r][want])

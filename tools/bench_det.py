@@ -74,6 +74,10 @@ for K in (91, 1204):
     report(f"retina_cls_loss fused fwd+bwd N=120087 K={K}", timeit(lambda: ops.retina_cls_loss_sum(lg, m2, lab, 0.25, 2.0), 10), 2 * Nr * K * 4)
 x = torch.randn(1, 120000 * 3, device=dev)
 report("topk rows=1 n=360000 k=2000", timeit(lambda: ops.topk_rows(x, 2000), 10), 360000 * 4 * 4, "4 passes over the row")
+x8 = torch.randn(1, 90000 * 91, device=dev)
+report("topk rows=1 n=8.19M (RetinaNet level 0: 90000 anchors x 91) k=1000", timeit(lambda: ops.topk_rows(x8, 1000, min_value=-2.944), 10), x8.numel() * 4 * 4, "4 passes over the row")
+x16 = torch.randn(16, 90000 * 91, device=dev)
+report("topk rows=16 n=8.19M k=1000", timeit(lambda: ops.topk_rows(x16, 1000, min_value=-2.944), 5), x16.numel() * 4 * 4, "4 passes over the rows")
 from object_detectors_amd.tvision.roi_align import MultiScaleRoIAlign
 feats = {str(i): torch.randn(2, 256, 800 // s, 800 // s, device=dev) for i, s in enumerate((4, 8, 16, 32))}
 props = [torch.cat([torch.rand(512, 2, device=dev) * 500, torch.rand(512, 2, device=dev) * 280 + 520], 1) for _ in range(2)]
