@@ -68,6 +68,8 @@ typedef struct {
   float alpha, gamma;          /* custom.FocalLoss (yolo/utilities/custom.py:40-67) */
   float grad_scale;            /* multiplies every gradient (1/sum(M) is applied internally) */
   int32_t grad_is_bf16;        /* grad views hold bf16 (engine) instead of fp32 */
+  const float* class_weights;  /* device [C] or NULL: nn.CrossEntropyLoss(weight=..., reduction='sum') class weights
+                                  (yolo_forw.py:50-62,72: tf-idf / effective-number re-weighting) */
 } mi355det_yolo_loss_cfg;
 
 /* helper.bbox_iou (yolo/utilities/helper.py:221-277), broadcast form [M,1,4] x [1,N,4] -> [M,N]

@@ -28,7 +28,7 @@ class HeadView(C.Structure):
 class YoloLossCfg(C.Structure):
     _fields_ = [("lambda_iou", f32), ("lambda_xy", f32), ("lambda_wh", f32), ("lambda_conf", f32),
                 ("lambda_no_conf", f32), ("lambda_cls", f32), ("alpha", f32), ("gamma", f32),
-                ("grad_scale", f32), ("grad_is_bf16", i32)]
+                ("grad_scale", f32), ("grad_is_bf16", i32), ("class_weights", vp)]
 
 
 class ConvShape(C.Structure):

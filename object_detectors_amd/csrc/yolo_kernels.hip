@@ -413,7 +413,8 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
     ser = wave_sum(ser);
     zl = wave_sum(zl);
     rl = wave_sum(rl);
-    acc[4] += cfg.lambda_cls * ((m + __logf(se)) - zl);
+    const float wy = cfg.class_weights ? cfg.class_weights[label] : 1.0f;       // CrossEntropyLoss(weight=w, reduction='sum'): w[y] * nll
+    acc[4] += cfg.lambda_cls * wy * ((m + __logf(se)) - zl);
     acc[7] += __expf(rl - mr) / ser;   // softmax(raw)[label] (transform_pred :222, get_stats :243)
     if (has_grad) {
       const mi355det_head_view gv = grads.h[an.scale];
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
         const float w = idf ? idf[c] : 1.0f;
         const float z = w * raw;
         float gr = __expf(z - m) / se - (c == label ? 1.0f : 0.0f);
-        grad_add<BF16>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * w * gr * gs);
+        grad_add<BF16>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * wy * w * gr * gs);
       }
     }
   }

@@ -37,7 +37,7 @@ class _YoloLossFn(torch.autograd.Function):
 
 
 class YOLOForw(nn.Module):
-    def __init__(self, config=None, *, anchors=None, num_classes=None, img_size=None, idf_logits=None, **kw):
+    def __init__(self, config=None, *, anchors=None, num_classes=None, img_size=None, idf_logits=None, class_weights=None, idf=None, **kw):
         """Either pass the reference's hydra-style `config` (config.yolo.*, config.dataset.anchors) or
         keyword arguments.  Defaults follow hydra/yolo/head.yaml:4-17."""
         super().__init__()
@@ -66,6 +66,38 @@ class YOLOForw(nn.Module):
             raise NotImplementedError("only reduction='sum' with class_loss=1 (CrossEntropy), the reference defaults "
                                       "(hydra/yolo/head.yaml:14-15), are on the accelerated path")
         self.device = torch.device("cuda")
+        # ---- class re-weighting (yolo_forw.py:33-67): `tfidf` = [weights switch, logits switch]; weights switch 1 = CrossEntropyLoss class
+        #      weights from the idf table, 2 = effective-number weights (beta 0.9999 on instance_freq); logits switch 1 = the idf row
+        #      multiplies the class logits in loss and decode; `tfidf_norm` p-normalises either; `tfidf_batch` recomputes the logits row
+        #      from every training batch (IDFTransformer.forward)
+        tf = opt("tfidf", [0, 0])
+        variant = opt("tfidf_variant", "smooth")
+        self.tfidf_norm = opt("tfidf_norm", 0)
+        self.tfidf_batch = bool(opt("tfidf_batch", False))
+        self.idf = idf
+        if self.idf is None and (tf[0] or tf[1]):
+            from ..utilities.custom import IDFTransformer
+            self.idf = IDFTransformer(_get(dcfg, "train_annotations"), _get(dcfg, "dset_name", "coco"), device="cpu")
+        if self.idf is None and self.tfidf_batch:
+            from ..utilities.custom import IDFTransformer
+            self.idf = IDFTransformer(num_classes=self.num_classes, device="cpu")
+        if class_weights is None and tf[0] == 1:
+            class_weights = self.idf.idf_weights[variant].float()
+            if self.tfidf_norm != 0:
+                class_weights = class_weights / torch.norm(class_weights, p=self.tfidf_norm)
+        elif class_weights is None and tf[0] == 2:
+            import numpy as np
+            freq = self.idf.idf_weights["instance_freq"].cpu().numpy()
+            w = (1.0 - 0.9999) / (1.0 - np.power(0.9999, freq))
+            class_weights = torch.from_numpy((w / np.sum(w) * len(freq)).astype("float32"))
+        if idf_logits is None and tf[1] == 1:
+            idf_logits = self.idf.idf_weights[variant].float()
+            if self.tfidf_norm != 0:
+                idf_logits = idf_logits / torch.norm(idf_logits, p=self.tfidf_norm)
+        if class_weights is None:
+            self.class_weights = None
+        else:
+            self.register_buffer("class_weights", torch.as_tensor(class_weights, dtype=torch.float32))
         # idf_logits (yolo_forw.py:38,63-67): scalar 1 or a [C] vector multiplying the class logits
         if idf_logits is None:
             self.idf_logits = None
@@ -103,6 +135,11 @@ class YOLOForw(nn.Module):
         G = boxes.shape[0]
         if G == 0:
             raise ValueError("YOLOForw: batch without any ground-truth box")
+        if self.tfidf_batch:                                  # yolo_forw.py:87-91: the logits row of THIS batch (kept for later decodes, as there)
+            row = self.idf(targets).float()
+            if self.tfidf_norm != 0:
+                row = row / torch.norm(row, p=self.tfidf_norm)
+            self.idf_logits = row.to(dev)
         obj_idx, tgt, noobj = ops.yolo_assign(geom, boxes, off, bs, counts)
         grads = None
         gv = None
@@ -111,8 +148,10 @@ class YOLOForw(nn.Module):
         elif want_grad:
             grads = [torch.zeros_like(t) for t in keep]
             gv, _ = ops.head_views(grads, attrs_total)
+        cw = None if self.class_weights is None else self.class_weights.to(device=dev, dtype=torch.float32).contiguous()
         cfg = _lib.YoloLossCfg(self.lambda_iou, self.lambda_xy, self.lambda_wh, self.lambda_conf, self.lambda_no_conf,
-                               self.lambda_cls, self.alpha, self.gamma, grad_scale, int(grad_is_bf16))
+                               self.lambda_cls, self.alpha, self.gamma, grad_scale, int(grad_is_bf16), None if cw is None else cw.data_ptr())
+        self._cw_keep = cw
         out12 = ops.yolo_loss(geom, cfg, hv, gv, off, labels, obj_idx, tgt, noobj, self._idf(dev), bs, G)
         self.last_assignment = (obj_idx, tgt, noobj, counts)
         return out12, grads

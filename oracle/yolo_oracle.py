@@ -132,7 +132,7 @@ class YoloSpec:
 
     def __init__(self, anchors, num_classes, img_size, iou_type=1, ignore_thr=0.5, lambda_iou=1.0,
                  lambda_xy=2.5, lambda_wh=2.5, lambda_conf=1.0, lambda_no_conf=0.1, lambda_cls=1.0,
-                 alpha=0.5, gamma=1.0, idf_logits=None):
+                 alpha=0.5, gamma=1.0, idf_logits=None, class_weights=None):
         self.anchors = [[(float(w), float(h)) for w, h in s] for s in anchors]
         self.na = len(self.anchors[0])
         self.C = num_classes
@@ -144,6 +144,7 @@ class YoloSpec:
         self.l_conf, self.l_noconf, self.l_cls = lambda_conf, lambda_no_conf, lambda_cls
         self.alpha, self.gamma = alpha, gamma
         self.idf = None if idf_logits is None else np.asarray(idf_logits, F32)
+        self.cw = None if class_weights is None else np.asarray(class_weights, F32)      # CrossEntropyLoss(weight=...) (yolo_forw.py:50-62,72)
 
 
 def anchor_table(spec, grids):
@@ -254,7 +255,8 @@ def yolo_loss(spec, heads, targets, want_grad=True):
     m = logits.max(-1, keepdims=True)
     lse = m[:, 0] + np.log(np.exp(logits - m).sum(-1))
     ce = lse - logits[np.arange(nG), labels]
-    cls_loss = spec.l_cls * ce.astype(f64).sum()
+    wy = np.ones(nG, F32) if spec.cw is None else spec.cw[labels]
+    cls_loss = spec.l_cls * (wy.astype(f64) * ce.astype(f64)).sum()
     iou_loss = spec.l_iou * (1 - iou.astype(f64)).sum()
     sub = np.array([loss_xy, loss_wh, iou_loss, pos_conf, neg_conf, cls_loss], f64)
     loss = sub.sum() / nG
@@ -289,7 +291,7 @@ def yolo_loss(spec, heads, targets, want_grad=True):
             dl[labels[i]] -= 1
             if spec.idf is not None:
                 dl = dl * spec.idf
-            g[b, a, 5:] += spec.l_cls * dl * inv
+            g[b, a, 5:] += spec.l_cls * float(wy[i]) * dl * inv
         out["grad_flat"] = g.astype(F32)
         out["grads"] = unflatten_grads(spec, g.astype(F32), heads)
     return out
@@ -380,3 +382,13 @@ def postprocess(pred, conf_thr=0.1, nms_thr=0.6):
         fin, _ = nms_majority(cand, nms_thr)
         out.append((cand, fin))
     return out
+
+
+def minibatch_idf(label_lists, num_classes, norm=0):
+    """IDFTransformer.forward (yolo/utilities/custom.py:257-262) + the optional p-normalisation of yolo_forw.py:87-91."""
+    t = np.stack([np.bincount(np.asarray(l, np.int64), minlength=num_classes) for l in label_lists])
+    df = (t > 0).sum(0).astype(np.float64)
+    w = np.log((len(label_lists) + 1) / (df + 1)) + 1
+    if norm != 0:
+        w = w / np.linalg.norm(w, ord=norm)
+    return w.astype(F32)

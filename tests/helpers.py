@@ -5,8 +5,8 @@ from oracle import detrand
 from oracle.yolo_oracle import YoloSpec
 
 YOLO_CASES = ["coco128", "coco128_idf", "coco128_iou", "coco128_diou", "coco128_ciou", "lvis96_a6",
-              "coco416", "coco640"]
-YOLO_FULL = YOLO_CASES[:6]
+              "coco416", "coco640", "coco128_cw", "coco128_batchidf"]
+YOLO_FULL = YOLO_CASES[:6] + YOLO_CASES[8:]
 
 
 def synth_targets(seed, ms, num_classes):
@@ -30,9 +30,12 @@ def yolo_case(g3, name):
     ms = [int(v) for v in g3[name + "_ms"]]
     anchors = g3[name + "_anchors"].tolist()
     idf = g3[name + "_idf"] if (name + "_idf") in g3.files else None
+    if (name + "_batch_idf") in g3.files:        # tfidf_batch: the row the reference computed from this batch (IDFTransformer.forward, p-normalised)
+        idf = g3[name + "_batch_idf"]
+    cw = g3[name + "_cw"] if (name + "_cw") in g3.files else None
     heads = synth_heads(seed, bs, na, C, grids)
     targets = synth_targets(seed + 50, ms, C)
     if name == "coco128":
         targets[0][0][1] = targets[0][0][0] + np.float32(1e-3)
-    spec = YoloSpec(anchors, C, img, iou_type=iou_type, idf_logits=idf)
+    spec = YoloSpec(anchors, C, img, iou_type=iou_type, idf_logits=idf, class_weights=cw)
     return spec, heads, targets

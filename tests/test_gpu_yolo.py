@@ -1,5 +1,7 @@
 """GPU parity: HIP YOLO criterion / NMS kernels (through the C ABI) vs the CPU oracle and the
 reference-generated golden fixtures.  Run with -m gpu on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,7 +21,7 @@ def dev():
 def make_module(spec):
     from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
     return YOLOForw(anchors=spec.anchors, num_classes=spec.C, img_size=spec.img_size, iou_type=spec.iou_type,
-                    idf_logits=spec.idf).to(dev())
+                    idf_logits=spec.idf, class_weights=spec.cw).to(dev())
 
 
 def to_targets(targets):
@@ -187,3 +189,35 @@ def test_postprocess_gpu(golden):
         assert fin.shape == g[f"final{e}"].shape
         np.testing.assert_allclose(fin[:, :5], g[f"final{e}"][:, :5], rtol=1e-4, atol=1e-4)
         assert np.array_equal(fin[:, 5], g[f"final{e}"][:, 5])
+
+
+def test_per_batch_idf_and_config_class_weights(golden, tmp_path):
+    """The research knobs of the reference's config (hydra/yolo/head.yaml:18-21): `tfidf_batch` recomputes the logits row from the batch
+    (yolo_forw.py:87-91) - same loss as the reference run of that mode (fixture coco128_batchidf) - and `tfidf: [1, 1]` reads class weights
+    and the logits row from the cached idf table."""
+    from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
+    from object_detectors_amd.yolo.utilities.custom import IDFTransformer
+    g3 = golden("g3_yolo_forw")
+    spec, heads, targets = yolo_case(g3, "coco128_batchidf")
+    mod = YOLOForw(anchors=spec.anchors, num_classes=spec.C, img_size=spec.img_size, tfidf_batch=True, tfidf_norm=2).to(dev())
+    loss, sub, stats = mod([torch.from_numpy(h).to(dev()) for h in heads], to_targets(targets))
+    np.testing.assert_allclose(mod.idf_logits.cpu().numpy(), g3["coco128_batchidf_batch_idf"], rtol=1e-6)
+    np.testing.assert_allclose(float(loss), float(g3["coco128_batchidf_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(sub.cpu().numpy(), g3["coco128_batchidf_sub_losses"], rtol=1e-4, atol=1e-6)
+    # tfidf = [1, 1] from a cached table
+    csvp = os.path.join(tmp_path, "idf.csv")
+    w = detrand.uniform(5, (80,), 0.5, 2.0)
+    with open(csvp, "w") as f:
+        f.write("name,smooth,instance_freq\n" + "\n".join(f"c{i},{w[i]:.8f},{100 + i}" for i in range(80)) + "\n")
+    idf = IDFTransformer(csv_path=csvp, device="cpu")
+    assert idf.num_classes == 80 and set(idf.idf_weights) == {"smooth", "instance_freq"}
+    m2 = YOLOForw(anchors=spec.anchors, num_classes=80, img_size=spec.img_size, idf=idf, tfidf=[1, 1], tfidf_norm=0).to(dev())
+    np.testing.assert_allclose(m2.class_weights.cpu().numpy(), w, rtol=1e-6)
+    np.testing.assert_allclose(m2.idf_logits.cpu().numpy(), w, rtol=1e-6)
+    l2, _s, _t = m2([torch.from_numpy(h).to(dev()) for h in heads], to_targets(targets))
+    ref = yo.yolo_loss(yo.YoloSpec(spec.anchors, 80, spec.img_size, idf_logits=w, class_weights=w), heads, targets, want_grad=False)
+    np.testing.assert_allclose(float(l2), float(ref["loss"]), rtol=2e-4)
+    m3 = YOLOForw(anchors=spec.anchors, num_classes=80, img_size=spec.img_size, idf=idf, tfidf=[2, 0]).to(dev())
+    freq = 100.0 + np.arange(80)
+    we = (1.0 - 0.9999) / (1.0 - np.power(0.9999, freq))
+    np.testing.assert_allclose(m3.class_weights.cpu().numpy(), we / we.sum() * 80, rtol=1e-5)

@@ -218,6 +218,9 @@ def g3_yolo(helper, custom, yolo_forw):
         ("lvis96_a6", LVIS_ANCHORS, 20, 96, (3, 6, 12), (6, 2, 9), 1, None, True),
         ("coco416", COCO_ANCHORS, 80, 416, (13, 26, 52), (7, 12), 1, None, False),
         ("coco640", COCO_ANCHORS, 80, 640, (20, 40, 80), (7, 20), 1, None, False),
+        # CrossEntropyLoss class weights (tfidf[0] = 1: yolo_forw.py:50-54,72) and the per-batch idf row (tfidf_batch: :87-91)
+        ("coco128_cw", COCO_ANCHORS, 80, 128, (4, 8, 16), (6, 3), 1, "cw", True),
+        ("coco128_batchidf", COCO_ANCHORS, 80, 128, (4, 8, 16), (4, 5), 1, "batch", True),
     ]
     d = {}
     for i, (name, anchors, C, img, grids, ms, iou_type, idfv, full) in enumerate(cfgs):
@@ -227,14 +230,28 @@ def g3_yolo(helper, custom, yolo_forw):
         targets = synth_targets(seed + 50, ms, C)
         if name == "coco128":   # force a duplicate assignment: two GTs of image 0 share a best anchor
             targets[0][0][1] = targets[0][0][0] + np.float32(1e-3)
+        mode = idfv if isinstance(idfv, str) else None
+        if mode:
+            idfv = None
         F = make_yoloforw(yolo_forw, custom, anchors, C, img, iou_type, idfv)
+        if mode == "cw":
+            cw = detrand.uniform(seed + 77, (C,), 0.5, 2.0)
+            F.class_loss = nn.CrossEntropyLoss(reduction="sum", weight=torch.from_numpy(cw))
+            d[name + "_cw"] = cw
+        if mode == "batch":
+            F.tfidf_batch, F.tfidf_norm = True, 2
+            F.idf = custom.IDFTransformer.__new__(custom.IDFTransformer)       # forward() only needs num_classes
+            nn.Module.__init__(F.idf)
+            F.idf.num_classes = C
         r = run_yolo_train(F, heads, targets)
+        if mode == "batch":
+            d[name + "_batch_idf"] = F.idf_logits.detach().numpy().astype(np.float32)
         meta = np.array([seed, C, img, iou_type, na, len(ms)], np.int64)
         d[name + "_meta"] = meta
         d[name + "_grids"] = np.array(grids, np.int64)
         d[name + "_ms"] = np.array(ms, np.int64)
         d[name + "_anchors"] = np.array(anchors, np.float64)
-        if idfv is not None:
+        if idfv is not None and not isinstance(idfv, str):
             d[name + "_idf"] = idfv
         for k in ("loss", "sub_losses", "stats", "tgt", "obj_idx", "noobj_bits"):
             d[f"{name}_{k}"] = r[k]
