@@ -60,7 +60,7 @@ def pmc_traffic(batch, px):
     """HBM bytes per forward-conv launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).
     PMC counters cannot be read from inside the process, so the figure is the one measured for bs=32 / 640 px."""
-    path = os.path.join(ROOT, "profiles", "r01d_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     if batch != 32 or px != 640 or not os.path.exists(path):
         return None, None, None
     d = json.load(open(path))
@@ -70,7 +70,7 @@ def pmc_traffic(batch, px):
             n += d[fam]["launches_per_step"]
             b += d[fam]["launches_per_step"] * (d[fam]["read_MB_per_launch"] + d[fam]["write_MB_per_launch"]) * 1e6
     mu = d.get("igemm fwd (BN partial stats)", {}).get("mfma_util_pct")
-    return (round(b / n) if n else None), "profiles/r01d_pmc_summary.md", (round(mu, 1) if mu is not None else None)
+    return (round(b / n) if n else None), "profiles/r02_pmc_summary.md", (round(mu, 1) if mu is not None else None)
 
 
 def cpu_baseline(px, sample_bs=1, warmup=3, iters=10):
@@ -148,8 +148,11 @@ def main():
     # the step's dependency chain (forward, loss, BN backward, dgrad) runs on a HIGH-priority stream; the engine's side stream
     # (weight gradients, gradient all-reduce) keeps the default priority and fills what the chain leaves free: the HBM-bound BN
     # backward of a layer then overlaps the previous layer's weight-gradient GEMM instead of waiting for it (+1 % measured, same box)
-    # Single GPU only: with RCCL in the picture the all-reduce kernels would sit BELOW the chain too, which could not be measured here.
-    if world == 1:
+    # Default: single GPU only - with RCCL in the picture the all-reduce kernels would rank below the chain too, which could not be
+    # measured on the one-GPU boxes of this pool; MI355DET_STEP_PRIORITY=1 / 0 forces it on / off for an A/B run on a multi-GPU node
+    # (MI355DET_GRADSYNC=rs_ag and MI355DET_BUCKET_MB=<MiB> select the collective and the bucket size the same way, parallel.py).
+    prio = os.environ.get("MI355DET_STEP_PRIORITY")
+    if (world == 1 and prio != "0") or prio == "1":
         from object_detectors_amd.parallel import step_stream
         torch.cuda.set_stream(step_stream(dev))
     from object_detectors_amd.optim import FlatSGD
@@ -252,7 +255,7 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch", "traffic_source": tsrc,
                     "mfma_util_counter_pct": mfma_util,
-                    "kernel": "igemm_kernel (conv forward, all 75 launches/step)",
+                    "kernel": "conv forward implicit GEMM, all 75 launches/step (igemm8_kernel / igemm_dx_kernel / igemm_kernel as autotuned per shape)",
                     "launches": len(events), "avg_launch_us": round(1000.0 * tot_ms / len(events), 2),
                     "gflop_per_launch": round(tot_fl / len(events) / 1e9, 3)}
         line = {

@@ -69,7 +69,13 @@ typedef struct {
   float grad_scale;            /* multiplies every gradient (1/sum(M) is applied internally) */
   int32_t grad_is_bf16;        /* grad views hold bf16 (engine) instead of fp32 */
   const float* class_weights;  /* device [C] or NULL: nn.CrossEntropyLoss(weight=..., reduction='sum') class weights
-                                  (yolo_forw.py:50-62,72: tf-idf / effective-number re-weighting) */
+                                  (yolo_forw.py:50-62,72: tf-idf / effective-number re-weighting); for class_loss 0 / 2 the same
+                                  row is BCEWithLogitsLoss's pos_weight (yolo_forw.py:70-71,74-75) */
+  int32_t class_loss;          /* cfg.class_loss (yolo_forw.py:69-77): 0 BCEWithLogitsLoss, 1 CrossEntropyLoss (the default), 2 custom.EQLoss */
+  int32_t reduction_mean;      /* cfg.reduction: 0 'sum' (every term / sum(M), yolo_forw.py:158-160), 1 'mean' (each loss over its own
+                                  element count, no final division) */
+  const float* eq_mask;        /* device [C], class_loss 2 only: custom.EQLoss.eq_mask (custom.py:79-80, 1.0 where the class's image-frequency
+                                  share is below 0.0045) */
 } mi355det_yolo_loss_cfg;
 
 /* helper.bbox_iou (yolo/utilities/helper.py:221-277), broadcast form [M,1,4] x [1,N,4] -> [M,N]
@@ -277,8 +283,9 @@ int mi355det_bn_bwd_sum_partials(const float* partials, int32_t rows, int32_t c,
                                  void* stream);
 
 /* Weight gradient: dw[cout][k*k*cin] fp32 += x^T dy.  Split over the pixel axis; partial 128x128 tiles go to
- * `workspace` with plain stores and are summed into dw in a fixed order (deterministic, no atomics).
- * dbias != NULL: dbias[cout] += sum_pixels dy. */
+ * `workspace` with plain stores and are summed into dw in a fixed order: dw is bit-reproducible from run to run.
+ * dbias != NULL: dbias[cout] += sum_pixels dy - this column sum ends in one fp32 atomicAdd per workgroup and channel,
+ * so dbias (the three YOLO head biases, the RetinaNet / RPN head biases) is reproducible only to fp32 rounding order. */
 size_t mi355det_conv_wgrad_workspace(const mi355det_conv_shape* s);
 /* plan-build helper (synchronises; not part of the step): times the candidate split counts for this shape on the
  * caller's buffers and remembers the fastest.  Returns the chosen split count; dw is clobbered. */
@@ -311,7 +318,15 @@ int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* 
  *   bn_finalize: stats -> scale/shift (+ running stats update, momentum 0.1, unbiased var).
  *   bn_act_fwd: a = lrelu(z*scale+shift) [+ residual]   (bf16 in/out, vectorised)
  *   bn_act_bwd_reduce: per-channel sums of dy and dy*xhat where dy = (g1[+g2]) * lrelu'(.)
- *   bn_act_bwd_apply: dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat))  (bf16)            */
+ *   bn_act_bwd_apply: dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat))  (bf16)
+ * Limits and reproducibility:
+ *   - c must be a multiple of 8 everywhere; bn_act_bwd_reduce additionally needs c/8 to be a power of two <= 256
+ *     (c in {8, 16, 32, ..., 2048}: every Darknet / YoloHead layer) and returns MI355DET_EINVAL otherwise;
+ *   - bn_act_bwd_reduce finishes every workgroup with one fp32 atomicAdd per channel into `sums`, so the two sums - and through them
+ *     dz, dgamma, dbeta and everything upstream - differ from run to run in the last bits (measured ~6e-4 of max on the final
+ *     gradient of a 75-layer step).  Ranks stay in sync (the all-reduce result is the same on every rank).  The plain-store
+ *     alternative is mi355det_conv_dgrad_bn + mi355det_bn_bwd_sum_partials (fixed order, ~2.5 % slower on the step;
+ *     the engine selects it with MI355DET_BN_FUSION=1). */
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count,
                          const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var,
@@ -373,6 +388,18 @@ int mi355det_sgd_step(float* w, float* g, float* momentum_buf, int64_t n, float 
 int mi355det_adam_step(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, float grad_scale, int32_t step, int zero_grad,
                        void* stream);
+/* The amp half of that row (apex `amp.scale_loss` + dynamic loss scaling around `optimizer.step()`, yolo/procedures/initialize.py:44-45,
+ * train_one_epoch.py:88-96): grad_nonfinite sets *flag (device int32, zeroed by the caller) to 1 when any gradient is inf / nan (one read
+ * pass); the *_guarded steps read *skip_flag on the device and leave parameters and optimizer state untouched when it is non-zero (the
+ * gradients are still cleared when zero_grad is set), so an overflowing step is skipped without a host round trip.  skip_flag NULL = the
+ * plain step. */
+int mi355det_grad_nonfinite(const float* g, int64_t n, int32_t* flag, void* stream);
+int mi355det_sgd_step_guarded(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                              float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad,
+                              const int32_t* skip_flag, void* stream);
+int mi355det_adam_step_guarded(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float grad_scale, int32_t step, int zero_grad,
+                               const int32_t* skip_flag, void* stream);
 
 
 /* ---- Fast R-CNN box-head loss (csrc/frcnn_kernels.hip) ------------------------------------------------------------------

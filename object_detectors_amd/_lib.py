@@ -28,7 +28,8 @@ class HeadView(C.Structure):
 class YoloLossCfg(C.Structure):
     _fields_ = [("lambda_iou", f32), ("lambda_xy", f32), ("lambda_wh", f32), ("lambda_conf", f32),
                 ("lambda_no_conf", f32), ("lambda_cls", f32), ("alpha", f32), ("gamma", f32),
-                ("grad_scale", f32), ("grad_is_bf16", i32), ("class_weights", vp)]
+                ("grad_scale", f32), ("grad_is_bf16", i32), ("class_weights", vp), ("class_loss", i32), ("reduction_mean", i32),
+                ("eq_mask", vp)]
 
 
 class ConvShape(C.Structure):
@@ -102,6 +103,9 @@ PROTOTYPES = {
     "mi355det_cast_rows_bf16": (C.c_int, [vp, i64, i64, i32, i64, i32, C.c_float, vp, i32, vp]),
     "mi355det_sgd_step": (C.c_int, [vp, vp, vp, i64] + [C.c_float] * 5 + [C.c_int] * 3 + [vp]),
     "mi355det_adam_step": (C.c_int, [vp, vp, vp, vp, i64] + [C.c_float] * 6 + [i32, C.c_int, vp]),
+    "mi355det_sgd_step_guarded": (C.c_int, [vp, vp, vp, i64] + [C.c_float] * 5 + [C.c_int] * 3 + [vp, vp]),
+    "mi355det_adam_step_guarded": (C.c_int, [vp, vp, vp, vp, i64] + [C.c_float] * 6 + [i32, C.c_int, vp, vp]),
+    "mi355det_grad_nonfinite": (C.c_int, [vp, i64, vp, vp]),
     "mi355det_add_bf16": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, i32, vp]),
     "mi355det_bn_act_fwd": (C.c_int, [vp, i32, vp, i32, i64, f32, vp, i32, vp, i32, vp]),
     "mi355det_bn_act_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, f32, vp, vp]),

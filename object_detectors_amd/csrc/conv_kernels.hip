@@ -1057,6 +1057,7 @@ int mi355det_debug_set(int key, int value) {
   if (key == 0) g_tune = value;
   if (key == 1) g_wgrad_general = value;
   if (key == 2) g_dgrad_s2_off = value;
+  if (key == 3) igemm8_set_dbg_mode(value);      // 1 = phase stamps, 2 = k-step starts only (tools/prof_ig8.py)
   return 0;
 }
 

@@ -486,8 +486,13 @@ inline int grid_for(long long total) { return (int)min((long long)256 * 16, (tot
 // {w, g, state}: 16-B accesses, grid-stride.  HBM bound: 20 B/param (SGD), 28 B/param (Adam).
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ mom, long long n4, long long n,
                                                    float lr, float momentum, float dampening, float wd, float gscale, int nesterov, int first,
-                                                   int zero_grad) {
+                                                   int zero_grad, const int* __restrict__ skip) {
   const long long stride = (long long)gridDim.x * blockDim.x;
+  if (skip && *skip) {      // amp overflow (train_one_epoch.py:88-96 under apex dynamic loss scaling): the step is skipped, gradients still cleared
+    if (zero_grad)
+      for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = 0.f;
+    return;
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 wv = ((const float4*)w)[i], gv = ((const float4*)g)[i], mv = ((const float4*)mom)[i];
     float* wp = (float*)&wv; float* gp = (float*)&gv; float* mp = (float*)&mv;
@@ -518,8 +523,13 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
                                                     float lr, float b1, float b2, float eps, float wd, float gscale, float bc1, float bc2_sqrt,
-                                                    int zero_grad) {
+                                                    int zero_grad, const int* __restrict__ skip) {
   const long long stride = (long long)gridDim.x * blockDim.x;
+  if (skip && *skip) {
+    if (zero_grad)
+      for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] = 0.f;
+    return;
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float wi = w[i];
     const float d = g[i] * gscale + wd * wi;
@@ -531,6 +541,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
     w[i] = wi - (lr / bc1) * (mi / denom);
     if (zero_grad) g[i] = 0.f;
   }
+}
+
+// amp overflow check (apex LossScaler.update_scale's `_has_overflow`): flag = 1 when any gradient is inf / nan.  One read pass, 4 B/param.
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, long long n4, long long n, int* __restrict__ flag) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = ((const float4*)g)[i];
+    // (x - x) is 0 for finite x and nan for inf / nan
+    const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+    bad |= !(t == 0.f);
+  }
+  for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) bad |= !((g[i] - g[i]) == 0.f);
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *flag = 1;      // every writer stores the same value: no atomic needed
 }
 
 extern "C" {
@@ -664,24 +688,42 @@ int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_
   return check_launch("nhwc_to_nchw_f32");
 }
 
-int mi355det_sgd_step(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening, float weight_decay,
-                      float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
+int mi355det_sgd_step_guarded(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening, float weight_decay,
+                              float grad_scale, int nesterov, int first_step, int zero_grad, const int32_t* skip_flag, void* stream) {
   if (n <= 0) return MI355DET_OK;
   if (((uintptr_t)w | (uintptr_t)g | (uintptr_t)momentum_buf) & 15) return fail(MI355DET_EINVAL, "%s: buffers must be 16-byte aligned", "sgd_step");
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, S(stream), w, g, momentum_buf, (long long)(n / 4), (long long)n, lr, momentum,
-                     dampening, weight_decay, grad_scale, nesterov, first_step, zero_grad);
+                     dampening, weight_decay, grad_scale, nesterov, first_step, zero_grad, (const int*)skip_flag);
   return check_launch("sgd_step");
 }
 
-int mi355det_adam_step(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, float grad_scale, int32_t step, int zero_grad, void* stream) {
+int mi355det_sgd_step(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening, float weight_decay,
+                      float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
+  return mi355det_sgd_step_guarded(w, g, momentum_buf, n, lr, momentum, dampening, weight_decay, grad_scale, nesterov, first_step, zero_grad, nullptr,
+                                   stream);
+}
+
+int mi355det_adam_step_guarded(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float grad_scale, int32_t step, int zero_grad, const int32_t* skip_flag, void* stream) {
   if (n <= 0) return MI355DET_OK;
   if (step < 1) return fail(MI355DET_EINVAL, "%s: step counts from 1", "adam_step");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, S(stream), w, g, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps,
-                     weight_decay, grad_scale, bc1, bc2s, zero_grad);
+                     weight_decay, grad_scale, bc1, bc2s, zero_grad, (const int*)skip_flag);
   return check_launch("adam_step");
+}
+
+int mi355det_adam_step(float* w, float* g, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float grad_scale, int32_t step, int zero_grad, void* stream) {
+  return mi355det_adam_step_guarded(w, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale, step, zero_grad, nullptr, stream);
+}
+
+int mi355det_grad_nonfinite(const float* g, int64_t n, int32_t* flag, void* stream) {
+  if (n <= 0 || !g || !flag) return fail(MI355DET_EINVAL, "%s: bad arguments", "grad_nonfinite");
+  if ((uintptr_t)g & 15) return fail(MI355DET_EINVAL, "%s: buffer must be 16-byte aligned", "grad_nonfinite");
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, S(stream), g, (long long)(n / 4), (long long)n, (int*)flag);
+  return check_launch("grad_nonfinite");
 }
 
 }  // extern "C"

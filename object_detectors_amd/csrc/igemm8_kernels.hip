@@ -57,7 +57,7 @@ __device__ __forceinline__ void bar() {
   asm volatile("" ::: "memory");
 }
 
-template <int EPI, bool SK, bool PROF = false>
+template <int EPI, bool SK, int PROF = 0>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const SkParams sk) {
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 
   int stamp_i = 0;
   auto stamp = [&](int tag) {
-    if (PROF && SK && sk.dbg && threadIdx.x == 0 && stamp_i < 15) {
+    if (PROF == 1 && SK && sk.dbg && threadIdx.x == 0 && stamp_i < 15) {
       sk.dbg[(size_t)bid * 16 + stamp_i] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00FFFFFFFFFFFFFFull);
       ++stamp_i;
     }
@@ -266,50 +266,104 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       __builtin_amdgcn_s_setprio(0);
     };
 
+    // ---- diagnostic build (PROF, non-stream-K): s_memtime around the four segments of every phase - (A) fragment reads + LDS-DMA
+    //      issue, (B) counted vmcnt wait + barrier, (C) the 16 MFMAs, (D) trailing barrier - summed over the tile per wave, plus the 17
+    //      absolute stamps of ONE k-step, so the timelines of the two waves of a SIMD can be laid side by side (tools/prof_ig8.py).
+    //      Each stamp drains lgkmcnt, i.e. segment A includes the LDS read latency that the release build leaves in flight.
+    constexpr bool PH = PROF == 1 && !SK;      // PROF == 2: only the start of 16 consecutive k-steps (near-release timing)
+    constexpr bool PK = PROF == 2 && !SK;
+    unsigned ph_sum[4] = {0, 0, 0, 0}, ph_cap[17], ph_prev = 0;      // low 32 bits of the counter: spans are far below 2^32 cycles
+    unsigned long long ph_now = 0;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) ph_cap[i] = 0;
+    const int ph_t = k0 + 6;
+#define PH_STAMP(seg, capi)                                                                                     \
+  do {                                                                                                          \
+    if (PH) {                                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_now)::"memory");                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                        \
+      if ((seg) >= 0) ph_sum[(seg) < 0 ? 0 : (seg)] += (unsigned)ph_now - ph_prev;                               \
+      if (t == ph_t) ph_cap[capi] = (unsigned)ph_now;                                                           \
+      ph_prev = (unsigned)ph_now;                                                                               \
+    }                                                                                                           \
+  } while (0)
     int buf = 0;
     for (int t = k0; t < k1; ++t) {
+      PH_STAMP(-1, 0);
+      if (PK && (unsigned)(t - ph_t) < 16u) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_now)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ph_cap[t - ph_t] = (unsigned)ph_now;
+      }
       // ---- phase 1
       read_w(0);
       __builtin_amdgcn_sched_barrier(0);
       read_x(0);
       issue_w(s1, 1, buf ^ 1);
+      PH_STAMP(0, 1);
       wait_vm<8>();
       bar();
+      PH_STAMP(1, 2);
       __builtin_amdgcn_sched_barrier(0);
       mfma_q(0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      PH_STAMP(2, 3);
       bar();
+      PH_STAMP(3, 4);
       // ---- phase 2
       read_w(1);
       issue_x(s1, 1, buf ^ 1);
+      PH_STAMP(0, 5);
       wait_vm<8>();
       bar();
+      PH_STAMP(1, 6);
       __builtin_amdgcn_sched_barrier(0);
       mfma_q(1, 0);
       __builtin_amdgcn_sched_barrier(0);
+      PH_STAMP(2, 7);
       bar();
+      PH_STAMP(3, 8);
       // ---- phase 3
       read_x(1);
       issue_x(s2, 0, buf);
+      PH_STAMP(0, 9);
       wait_vm<8>();
       bar();
+      PH_STAMP(1, 10);
       __builtin_amdgcn_sched_barrier(0);
       mfma_q(1, 1);
       __builtin_amdgcn_sched_barrier(0);
+      PH_STAMP(2, 11);
       bar();
+      PH_STAMP(3, 12);
       // ---- phase 4
       issue_w(s2, 0, buf);
+      PH_STAMP(0, 13);
       wait_vm<8>();
       bar();
+      PH_STAMP(1, 14);
       __builtin_amdgcn_sched_barrier(0);
       mfma_q(0, 1);
       __builtin_amdgcn_sched_barrier(0);
+      PH_STAMP(2, 15);
       bar();
+      PH_STAMP(3, 16);
       s1 = s2;
       s2 = next_slot();
       buf ^= 1;
       xrd ^= kSTAGE;
       wrd ^= kSTAGE;
+    }
+#undef PH_STAMP
+    if ((PH || PK) && sk.dbg && lane == 0 && bid < 64) {
+      unsigned long long* d = sk.dbg + ((size_t)bid * 8 + wid) * 24;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = ph_sum[i];
+      d[4] = (unsigned long long)(k1 - k0);
+#pragma unroll
+      for (int i = 0; i < 17; ++i) d[5 + i] = ph_cap[i];
     }
     stamp(2);
     if (wm == 0) bar();             // re-align the two halves
@@ -349,6 +403,7 @@ struct SkWorkspace {
   unsigned epoch = 0;
 };
 unsigned long long* g_sk_dbg = nullptr;
+int g_sk_dbg_mode = 1;
 std::unordered_map<void*, SkWorkspace> g_sk_ws;       // per stream: launches on one stream are ordered, so they may share slabs
 constexpr int kNWG = 256;                             // one persistent workgroup per CU
 constexpr size_t kSlabFloats = 8 * 32 * 64 * 4;       // 256 KB of fp32 per workgroup
@@ -392,6 +447,19 @@ int launch8(const IgemmParams& p, hipStream_t st, bool streamk) {
     hipLaunchKernelGGL(k, dim3(kNWG), dim3(512), kLDS, st, p, sk);
     return check_launch("igemm8_sk");
   }
+  if (EPI == EPI_STATS && g_sk_dbg) {
+    // diagnostic builds (tools/prof_ig8.py): [64 workgroups][8 waves][24] u64; mode 1 = phase stamps, 2 = k-step starts only
+    sk.dbg = g_sk_dbg;
+    static bool attr_done_p = false;
+    if (!attr_done_p) {
+      (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+      (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+      attr_done_p = true;
+    }
+    if (g_sk_dbg_mode == 2) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 2>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+    else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 1>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+    return check_launch("igemm8_prof");
+  }
   auto k = igemm8_kernel<EPI, false>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -411,6 +479,7 @@ bool igemm8_applicable(const IgemmParams& p) {
 }
 
 void igemm8_set_dbg(unsigned long long* ptr) { g_sk_dbg = ptr; }
+void igemm8_set_dbg_mode(int mode) { g_sk_dbg_mode = mode; }
 
 // streamk: one persistent workgroup per CU over (tile, k-step) units instead of one workgroup per tile
 int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk) {

@@ -62,6 +62,7 @@ enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4, EPI_
 bool igemm8_applicable(const IgemmParams& p);
 int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk);
 void igemm8_set_dbg(unsigned long long* ptr);
+void igemm8_set_dbg_mode(int mode);
 
 namespace {
 

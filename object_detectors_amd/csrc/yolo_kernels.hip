@@ -219,6 +219,34 @@ __device__ __forceinline__ void focal_bce(float x, float t, float alpha, float g
   prob = p;
 }
 
+// nn.BCEWithLogitsLoss(pos_weight=pw) on one element (ATen: (1-y)*x + (1+(pw-1)*y) * softplus(-x)), optionally inside custom.EQLoss
+// (custom.py:83-99: * alpha_factor * (1-p_t)^gamma * clamp(eq_mask + y, 0, 1)); value and d/dx
+__device__ __forceinline__ void bce_class(float x, float y, float pw, bool eql, float eq_mask, float alpha, float gamma, float& loss,
+                                          float& grad) {
+  const float e = __expf(-fabsf(x));
+  const float lw = 1.0f + (pw - 1.0f) * y;
+  const float bce = (1.0f - y) * x + lw * (log1pf(e) + fmaxf(-x, 0.0f));
+  const float p = x >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+  const float dbce = (1.0f - y) - lw * (1.0f - p);
+  if (!eql) {
+    loss = bce;
+    grad = dbce;
+    return;
+  }
+  const float p_t = y * p + (1.0f - y) * (1.0f - p);
+  const float af = y * alpha + (1.0f - y) * (1.0f - alpha);
+  const float q = 1.0f - p_t;
+  const float mf = (gamma == 1.0f) ? q : (gamma == 2.0f ? q * q : powf(q, gamma));
+  const float dpt = (2.0f * y - 1.0f) * p * (1.0f - p);
+  float dmf;
+  if (gamma == 1.0f) dmf = -dpt;
+  else if (gamma == 2.0f) dmf = -2.0f * q * dpt;
+  else dmf = q > 0.0f ? -gamma * powf(q, gamma - 1.0f) * dpt : 0.0f;
+  const float w = fminf(fmaxf(eq_mask + y, 0.0f), 1.0f);
+  loss = bce * (af * mf) * w;
+  grad = w * af * (dbce * mf + bce * dmf);
+}
+
 template <bool BF16>
 __device__ __forceinline__ void grad_store(void* base, long long off, float v) {
   if (BF16) ((bf16_t*)base)[off] = f2bf(v);
@@ -234,6 +262,21 @@ struct Views {
   mi355det_head_view h[MI355DET_MAX_SCALES];
 };
 
+// reduction='mean' only: number of no-object elements of the batch (yolo_forw.py:148 `neg_conf_loss.mean()`), one workgroup, integer sum
+__global__ __launch_bounds__(1024) void yolo_noobj_count_kernel(const unsigned char* __restrict__ noobj, long long n, int* __restrict__ count) {
+  __shared__ int red[1024 / WAVE];
+  int c = 0;
+  for (long long i = threadIdx.x; i < n; i += 1024) c += noobj[i] ? 1 : 0;
+  float cf = wave_sum((float)c);                             // <= 64 * n/1024 per wave: exact in fp32 up to 2^24 per wave
+  if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = (int)cf;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 1024 / WAVE; ++w) t += red[w];
+    *count = t;
+  }
+}
+
 // No-object confidence term (yolo_forw.py:131-133,144): one thread per (image, anchor), lanes run
 // over pixels within an anchor plane.  Per-block partials {loss, sum sigmoid, count}.
 #define DENSE_THREADS 256
@@ -241,10 +284,11 @@ template <bool BF16>
 __global__ __launch_bounds__(DENSE_THREADS) void yolo_noobj_kernel(mi355det_yolo_geom geom, Views heads, Views grads, int has_grad,
                                                                     const unsigned char* __restrict__ noobj, float alpha,
                                                                     float gamma, float gscale, float* __restrict__ partials,
-                                                                    int n_total) {
+                                                                    int n_total, const int* __restrict__ noobj_count) {
   __shared__ Geom g;
   __shared__ float red[DENSE_THREADS / WAVE][3];
   load_geom(g, geom);
+  if (noobj_count) gscale /= (float)max(*noobj_count, 1);   // reduction='mean': the no-object term is averaged over its own element count
   const int b = blockIdx.y;
   const int t = blockIdx.x * DENSE_THREADS + threadIdx.x;   // plane-major index: scale, anchor a, pixel
   float l = 0.f, s = 0.f, c = 0.f;
@@ -337,14 +381,15 @@ __device__ __forceinline__ D4 iou_metric_dual(const DBox a, const DBox b, int io
 
 // Positive terms (yolo_forw.py:123-150 + transform_pred + get_stats): one wave per image walks its
 // GTs in order (duplicate anchor assignments accumulate, like the reference's gather/scatter).
-// partial layout per image: xy, wh, iou_loss, pos_conf, cls, iou_sum, pconf_sum, pcls_sum
-#define POS_NP 8
+// partial layout per image: xy, wh, iou_loss, pos_conf, cls, iou_sum, pconf_sum, pcls_sum, sum of sigmoid(raw) over all classes
+// (class_loss 0/2 statistics), sum of the target class weights (CrossEntropyLoss(weight, 'mean') divisor)
+#define POS_NP 10
 template <bool BF16>
 __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom, mi355det_yolo_loss_cfg cfg, Views heads, Views grads,
                                                          int has_grad, const int* __restrict__ gt_off,
                                                          const long long* __restrict__ gt_label,
                                                          const long long* __restrict__ obj_idx, const float* __restrict__ tgt,
-                                                         const float* __restrict__ idf, float inv_ng,
+                                                         const float* __restrict__ idf, float inv_ng, int bs,
                                                          float* __restrict__ pos_partials) {
   __shared__ Geom g;
   load_geom(g, geom);
@@ -353,7 +398,22 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
   float acc[POS_NP];
 #pragma unroll
   for (int i = 0; i < POS_NP; ++i) acc[i] = 0.f;
+  // gradient scales per term.  reduction='sum': every term / sum(M) (yolo_forw.py:158-160).  'mean': MSELoss over [G,2] elements,
+  // FocalLoss / (1 - iou) over G, class term over its own divisor (CrossEntropyLoss: summed target weights; BCE forms: G*C)
+  const bool mean = cfg.reduction_mean != 0;
+  const float gs_xy = cfg.grad_scale * inv_ng * (mean ? 0.5f : 1.0f);
   const float gs = cfg.grad_scale * inv_ng;
+  float gs_cls = gs;
+  if (mean) {
+    if (cfg.class_loss == 1) {
+      float ws = 0.f;
+      const int total = gt_off[bs];
+      for (int i = lane; i < total; i += WAVE) ws += cfg.class_weights ? cfg.class_weights[(int)gt_label[i]] : 1.0f;
+      gs_cls = cfg.grad_scale / wave_sum(ws);
+    } else {
+      gs_cls = gs / (float)C;
+    }
+  }
   for (int i = gt_off[b]; i < gt_off[b + 1]; ++i) {
     const int n = (int)obj_idx[i];
     const Anchor an = anchor_at(g, n);
@@ -413,27 +473,53 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
     ser = wave_sum(ser);
     zl = wave_sum(zl);
     rl = wave_sum(rl);
-    const float wy = cfg.class_weights ? cfg.class_weights[label] : 1.0f;       // CrossEntropyLoss(weight=w, reduction='sum'): w[y] * nll
-    acc[4] += cfg.lambda_cls * wy * ((m + __logf(se)) - zl);
-    acc[7] += __expf(rl - mr) / ser;   // softmax(raw)[label] (transform_pred :222, get_stats :243)
+    const float wy = cfg.class_weights ? cfg.class_weights[label] : 1.0f;       // CrossEntropyLoss(weight=w): w[y] * nll
+    if (cfg.class_loss == 1) {
+      acc[4] += cfg.lambda_cls * wy * ((m + __logf(se)) - zl);
+      acc[7] += __expf(rl - mr) / ser;   // softmax(raw)[label] (transform_pred :222, get_stats :243)
+      acc[9] += wy;
+    } else {
+      // class_loss 0: BCEWithLogitsLoss(pos_weight) on the one-hot row; 2: the same inside custom.EQLoss (custom.py:83-99: focal factors and
+      // the (rare-class mask + target) weights).  Statistics use sigmoid(raw) (transform_pred :223)
+      float ls = 0.f, ss = 0.f;
+      for (int c = lane; c < C; c += WAVE) {
+        const float raw = hp[(ch0 + 5 + c) * hv.sc];
+        const float w = idf ? idf[c] : 1.0f;
+        const float y = c == label ? 1.0f : 0.0f;
+        float l, gr;
+        bce_class(w * raw, y, cfg.class_weights ? cfg.class_weights[c] : 1.0f, cfg.class_loss == 2, cfg.eq_mask ? cfg.eq_mask[c] : 0.0f,
+                  cfg.alpha, cfg.gamma, l, gr);
+        ls += l;
+        ss += 1.0f / (1.0f + __expf(-raw));
+        if (has_grad) {
+          const mi355det_head_view gv = grads.h[an.scale];
+          grad_add<BF16>(gv.ptr, b * gv.sb + (long long)an.pix * gv.sp + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * w * gr * gs_cls);
+        }
+      }
+      acc[4] += cfg.lambda_cls * wave_sum(ls);
+      acc[7] += 1.0f / (1.0f + __expf(-rl));
+      acc[8] += wave_sum(ss);
+    }
     if (has_grad) {
       const mi355det_head_view gv = grads.h[an.scale];
       const long long gb0 = b * gv.sb + (long long)an.pix * gv.sp;
       if (lane < 5) {
         float gr;
-        if (lane == 0) gr = cfg.lambda_xy * 2.0f * dxy0 * sx * (1 - sx) - cfg.lambda_iou * iou.d[0];
-        else if (lane == 1) gr = cfg.lambda_xy * 2.0f * dxy1 * sy * (1 - sy) - cfg.lambda_iou * iou.d[1];
-        else if (lane == 2) gr = cfg.lambda_wh * 2.0f * dwh0 - cfg.lambda_iou * iou.d[2];
-        else if (lane == 3) gr = cfg.lambda_wh * 2.0f * dwh1 - cfg.lambda_iou * iou.d[3];
-        else gr = cfg.lambda_conf * pg;
-        grad_add<BF16>(gv.ptr, gb0 + (ch0 + lane) * gv.sc, gr * gs);
+        if (lane == 0) gr = cfg.lambda_xy * 2.0f * dxy0 * sx * (1 - sx) * gs_xy - cfg.lambda_iou * iou.d[0] * gs;
+        else if (lane == 1) gr = cfg.lambda_xy * 2.0f * dxy1 * sy * (1 - sy) * gs_xy - cfg.lambda_iou * iou.d[1] * gs;
+        else if (lane == 2) gr = cfg.lambda_wh * 2.0f * dwh0 * gs_xy - cfg.lambda_iou * iou.d[2] * gs;
+        else if (lane == 3) gr = cfg.lambda_wh * 2.0f * dwh1 * gs_xy - cfg.lambda_iou * iou.d[3] * gs;
+        else gr = cfg.lambda_conf * pg * gs;
+        grad_add<BF16>(gv.ptr, gb0 + (ch0 + lane) * gv.sc, gr);
       }
-      for (int c = lane; c < C; c += WAVE) {
-        const float raw = hp[(ch0 + 5 + c) * hv.sc];
-        const float w = idf ? idf[c] : 1.0f;
-        const float z = w * raw;
-        float gr = __expf(z - m) / se - (c == label ? 1.0f : 0.0f);
-        grad_add<BF16>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * wy * w * gr * gs);
+      if (cfg.class_loss == 1) {
+        for (int c = lane; c < C; c += WAVE) {
+          const float raw = hp[(ch0 + 5 + c) * hv.sc];
+          const float w = idf ? idf[c] : 1.0f;
+          const float z = w * raw;
+          float gr = __expf(z - m) / se - (c == label ? 1.0f : 0.0f);
+          grad_add<BF16>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * wy * w * gr * gs_cls);
+        }
       }
     }
   }
@@ -442,7 +528,8 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
 
 // Final reduction in a fixed order (deterministic): out12 = loss, sub_losses[6], stats[5]
 __global__ void yolo_reduce_kernel(const float* __restrict__ dense_partials, int n_dense, const float* __restrict__ pos_partials,
-                                   int bs, float lambda_no_conf, float ng, int num_classes, float* __restrict__ out12) {
+                                   int bs, float lambda_no_conf, float ng, int num_classes, int class_loss, int reduction_mean,
+                                   float* __restrict__ out12) {
   __shared__ double sh[256][3];
   double a[3] = {0, 0, 0};
   for (int i = threadIdx.x; i < n_dense; i += blockDim.x)
@@ -458,16 +545,26 @@ __global__ void yolo_reduce_kernel(const float* __restrict__ dense_partials, int
     for (int b = 0; b < bs; ++b)
       for (int k = 0; k < POS_NP; ++k) p[k] += (double)pos_partials[(size_t)b * POS_NP + k];
     const double neg = lambda_no_conf * d[0];
-    const double sub[6] = {p[0], p[1], p[2], p[3], neg, p[4]};
+    double sub[6] = {p[0], p[1], p[2], p[3], neg, p[4]};
+    if (reduction_mean) {
+      // every term averaged over its own element count, no final / sum(M) (yolo_forw.py:143-160 with reduction != 'sum')
+      const double dcls = class_loss == 1 ? p[9] : ng * (double)num_classes;
+      const double div[6] = {2.0 * ng, 2.0 * ng, ng, ng, d[2] > 0 ? d[2] : NAN, dcls};
+      for (int k = 0; k < 6; ++k) sub[k] /= div[k];
+    } else {
+      for (int k = 0; k < 6; ++k) sub[k] /= ng;
+    }
     double loss = 0;
     for (int k = 0; k < 6; ++k) loss += sub[k];
-    out12[0] = (float)(loss / ng);
-    for (int k = 0; k < 6; ++k) out12[1 + k] = (float)(sub[k] / ng);
+    out12[0] = (float)loss;
+    for (int k = 0; k < 6; ++k) out12[1 + k] = (float)sub[k];
     out12[7] = (float)(p[5] / ng);                         // avg_iou
     out12[8] = (float)(p[6] / ng);                         // pos_conf
     out12[9] = (float)(d[2] > 0 ? d[1] / d[2] : NAN);      // no_obj_conf (mean of empty = nan, like torch)
     out12[10] = (float)(p[7] / ng);                        // pos_class
-    out12[11] = (float)((ng - p[7]) / (ng * (double)(num_classes - 1)));   // neg_class
+    // neg_class: mean of the class probabilities off the label; softmax rows sum to 1, sigmoid rows are summed explicitly
+    const double off_label = class_loss == 1 ? ng - p[7] : p[8] - p[7];
+    out12[11] = (float)(off_label / (ng * (double)(num_classes - 1)));
   }
 }
 
@@ -1028,7 +1125,7 @@ int mi355det_yolo_assign(const mi355det_yolo_geom* geom, const float* gt_box, co
 
 size_t mi355det_yolo_loss_workspace(int32_t bs, int64_t n_anchors) {
   const size_t dense_blocks = (size_t)bs * ((n_anchors + DENSE_THREADS - 1) / DENSE_THREADS);
-  return (dense_blocks * 3 + (size_t)bs * POS_NP) * sizeof(float);
+  return (dense_blocks * 3 + (size_t)bs * POS_NP + 4) * sizeof(float);      // + the no-object element count of reduction='mean'
 }
 
 int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_cfg* cfg, const mi355det_head_view* heads,
@@ -1048,21 +1145,28 @@ int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_
   const int dblocks = (N + DENSE_THREADS - 1) / DENSE_THREADS;
   float* dense_p = (float*)workspace;
   float* pos_p = dense_p + (size_t)bs * dblocks * 3;
+  if (cfg->class_loss < 0 || cfg->class_loss > 2) return fail(MI355DET_EINVAL, "%s: class_loss must be 0 (bce), 1 (ce) or 2 (eql)", "yolo_loss");
+  if (cfg->class_loss == 2 && !cfg->eq_mask) return fail(MI355DET_EINVAL, "%s: class_loss 2 (EQLoss) needs eq_mask", "yolo_loss");
+  const bool mean = cfg->reduction_mean != 0;
+  int* count_p = (int*)(pos_p + (size_t)bs * POS_NP);
+  if (mean) hipLaunchKernelGGL(yolo_noobj_count_kernel, dim3(1), dim3(1024), 0, S(stream), noobj, (long long)bs * N, count_p);
+  // 'sum': every gradient / sum(M); 'mean': each term over its own element count (the kernels apply the rest)
   const float inv_ng = 1.0f / (float)num_gt;
-  const float gscale = cfg->lambda_no_conf * cfg->grad_scale * inv_ng;
+  const float gscale = cfg->lambda_no_conf * cfg->grad_scale * (mean ? 1.0f : inv_ng);
+  const int* cnt = mean ? count_p : nullptr;
   if (cfg->grad_is_bf16) {
     hipLaunchKernelGGL(yolo_noobj_kernel<true>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,
-                       cfg->alpha, cfg->gamma, gscale, dense_p, N);
+                       cfg->alpha, cfg->gamma, gscale, dense_p, N, cnt);
     hipLaunchKernelGGL(yolo_pos_kernel<true>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,
-                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, pos_p);
+                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, bs, pos_p);
   } else {
     hipLaunchKernelGGL(yolo_noobj_kernel<false>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,
-                       cfg->alpha, cfg->gamma, gscale, dense_p, N);
+                       cfg->alpha, cfg->gamma, gscale, dense_p, N, cnt);
     hipLaunchKernelGGL(yolo_pos_kernel<false>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,
-                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, pos_p);
+                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, bs, pos_p);
   }
   hipLaunchKernelGGL(yolo_reduce_kernel, dim3(1), dim3(256), 0, S(stream), dense_p, bs * dblocks, pos_p, bs, cfg->lambda_no_conf,
-                     (float)num_gt, geom->num_classes, out12);
+                     (float)num_gt, geom->num_classes, cfg->class_loss, cfg->reduction_mean, out12);
   return check_launch("yolo_loss");
 }
 

@@ -41,11 +41,13 @@ class FlatSGD(_Flat):
         self.momentum_buf = torch.zeros_like(flat_w)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, zero_grad=False):
+    def step(self, closure=None, grad_scale=1.0, zero_grad=False, skip_flag=None):
+        """skip_flag: device int32 tensor; non-zero = leave parameters and momentum untouched (amp overflow, see DynamicLossScaler)."""
         g = self.param_groups[0]
-        st = lib().mi355det_sgd_step(self.flat_w.data_ptr(), self.flat_g.data_ptr(), self.momentum_buf.data_ptr(), self.flat_w.numel(),
-                                     float(g["lr"]), float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"]), float(grad_scale),
-                                     int(bool(g["nesterov"])), int(self.steps == 0), int(zero_grad), _stream())
+        st = lib().mi355det_sgd_step_guarded(self.flat_w.data_ptr(), self.flat_g.data_ptr(), self.momentum_buf.data_ptr(), self.flat_w.numel(),
+                                             float(g["lr"]), float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"]),
+                                             float(grad_scale), int(bool(g["nesterov"])), int(self.steps == 0), int(zero_grad),
+                                             None if skip_flag is None else skip_flag.data_ptr(), _stream())
         check(st, "sgd_step")
         self.steps += 1
 
@@ -83,12 +85,13 @@ class FlatAdam(_Flat):
         self.exp_avg_sq = torch.zeros_like(flat_w)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, zero_grad=False):
+    def step(self, closure=None, grad_scale=1.0, zero_grad=False, skip_flag=None):
         g = self.param_groups[0]
         self.steps += 1
-        st = lib().mi355det_adam_step(self.flat_w.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                      self.flat_w.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                      float(g["weight_decay"]), float(grad_scale), self.steps, int(zero_grad), _stream())
+        st = lib().mi355det_adam_step_guarded(self.flat_w.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                              self.flat_w.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                              float(g["weight_decay"]), float(grad_scale), self.steps, int(zero_grad),
+                                              None if skip_flag is None else skip_flag.data_ptr(), _stream())
         check(st, "adam_step")
 
     def reference_state_dict(self, engine):
@@ -113,3 +116,60 @@ class FlatAdam(_Flat):
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
             self.steps = 0
+
+
+class DynamicLossScaler:
+    """apex amp's dynamic loss scaling around the optimizer step (yolo/procedures/initialize.py:44-45 `amp.initialize(..., opt_level)`,
+    train_one_epoch.py:88-96 `with amp.scale_loss(loss, optimizer) as scaled_loss: scaled_loss.backward(); optimizer.step()`), on the
+    flat buffers:
+
+        scaler = DynamicLossScaler()
+        out12 = engine.train_step(imgs, targets, criterion, grad_scale=scaler.loss_scale)     # gradients of loss * scale
+        sync.wait()                                                                           # (multi-GPU: after the all-reduce)
+        scaler.step(optimizer)                                                                # unscale + inf/nan check + guarded step + update
+
+    apex's defaults: initial scale 2^16, x2 after 2000 clean steps, /2 (and the step skipped) on overflow, ceiling 2^24.  The overflow
+    check and the skip run on the device (`mi355det_grad_nonfinite`, `mi355det_*_step_guarded`); `step` then reads the 4-byte flag to
+    update the scale, the same host synchronisation apex performs.  With the engine's bf16 activations the scale is not needed for range
+    (bf16 has fp32's exponent); the class exists so that a reference recipe that enables amp keeps its semantics (skipped steps included)."""
+
+    def __init__(self, init_scale=2.0 ** 16, scale_factor=2.0, scale_window=2000, min_loss_scale=None, max_loss_scale=2.0 ** 24, enabled=True):
+        self.loss_scale = float(init_scale) if enabled else 1.0
+        self.scale_factor, self.scale_window = float(scale_factor), int(scale_window)
+        self.min_loss_scale, self.max_loss_scale = min_loss_scale, max_loss_scale
+        self.enabled = enabled
+        self.unskipped = 0
+        self.skipped_steps = 0
+        self._flag = None
+
+    def step(self, optimizer, zero_grad=False):
+        """-> True when the step was applied, False when it was skipped for an inf / nan gradient."""
+        if not self.enabled:
+            optimizer.step(zero_grad=zero_grad)
+            return True
+        g = optimizer.flat_g
+        if self._flag is None or self._flag.device != g.device:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=g.device)
+        self._flag.zero_()
+        check(lib().mi355det_grad_nonfinite(g.data_ptr(), g.numel(), self._flag.data_ptr(), _stream()), "grad_nonfinite")
+        optimizer.step(grad_scale=1.0 / self.loss_scale, zero_grad=zero_grad, skip_flag=self._flag)
+        overflow = bool(self._flag.item())
+        if overflow:
+            optimizer.steps -= 1                 # the guarded kernel left parameters and state as they were
+            self.skipped_steps += 1
+            self.loss_scale = self.loss_scale / self.scale_factor
+            if self.min_loss_scale is not None:
+                self.loss_scale = max(self.loss_scale, self.min_loss_scale)
+            self.unskipped = 0
+        else:
+            self.unskipped += 1
+            if self.unskipped == self.scale_window:
+                self.loss_scale = min(self.max_loss_scale, self.loss_scale * self.scale_factor)
+                self.unskipped = 0
+        return not overflow
+
+    def state_dict(self):
+        return {"loss_scale": self.loss_scale, "unskipped": self.unskipped}
+
+    def load_state_dict(self, sd):
+        self.loss_scale, self.unskipped = float(sd["loss_scale"]), int(sd["unskipped"])

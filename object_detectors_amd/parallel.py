@@ -34,7 +34,16 @@ def plan_buckets(marks, total, bucket_elems):
 
 
 class GradSync:
-    def __init__(self, flat_grad, process_group=None, bucket_mb=64):
+    """algo: "all_reduce" (default; RCCL picks ring / tree per message size) or "rs_ag" (explicit reduce-scatter + all-gather of every
+    bucket: the two halves of a ring all-reduce as separate collectives, selectable so that the first multi-GPU run can compare them on
+    the xGMI mesh).  Environment overrides for A/B runs without code changes: MI355DET_GRADSYNC=all_reduce|rs_ag, MI355DET_BUCKET_MB=<MiB>."""
+
+    def __init__(self, flat_grad, process_group=None, bucket_mb=64, algo="all_reduce"):
+        import os
+        algo = os.environ.get("MI355DET_GRADSYNC", algo)
+        bucket_mb = float(os.environ.get("MI355DET_BUCKET_MB", bucket_mb))
+        if algo not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"GradSync: unknown algo {algo!r}")
         self.flat = flat_grad
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -43,6 +52,9 @@ class GradSync:
         self.side_stream = None
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self.use_avg = backend == "nccl"
+        self.ordered = backend == "nccl"          # RCCL runs a group's collectives in issue order on its own stream; gloo's worker threads do not
+        self.algo = algo
+        self._shards = {}
 
     def reduce_slice(self, lo, hi):
         if self.world == 1:
@@ -56,11 +68,32 @@ class GradSync:
             self._reduce(lo, hi)
 
     def _reduce(self, lo, hi):
+        if self.algo == "rs_ag":
+            return self._reduce_rs_ag(lo, hi)
         t = self.flat[lo:hi]
         if self.use_avg:
             self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:
             self.handles.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True), t))
+
+    def _reduce_rs_ag(self, lo, hi):
+        """Bucket [lo, hi) as reduce-scatter into a per-rank shard + all-gather back in place; the (< world) elements that do not divide
+        evenly ride on a tiny all-reduce."""
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        n = hi - lo
+        main = n - n % self.world
+        if main:
+            t = self.flat[lo:lo + main]
+            shard = self._shards.get((lo, hi))
+            if shard is None:
+                shard = self._shards[(lo, hi)] = torch.empty(main // self.world, dtype=t.dtype, device=t.device)
+            h = dist.reduce_scatter_tensor(shard, t, op=op, group=self.group, async_op=True)
+            if not self.ordered:
+                h.wait()
+            self.handles.append((dist.all_gather_into_tensor(t, shard, group=self.group, async_op=True), None if self.use_avg else t))
+        if n - main:
+            t = self.flat[lo + main:hi]
+            self.handles.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), None if self.use_avg else t))
 
     def wait(self):
         for h, t in self.handles:

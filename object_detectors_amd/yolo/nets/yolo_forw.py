@@ -37,7 +37,8 @@ class _YoloLossFn(torch.autograd.Function):
 
 
 class YOLOForw(nn.Module):
-    def __init__(self, config=None, *, anchors=None, num_classes=None, img_size=None, idf_logits=None, class_weights=None, idf=None, **kw):
+    def __init__(self, config=None, *, anchors=None, num_classes=None, img_size=None, idf_logits=None, class_weights=None, idf=None,
+                 img_freq=None, **kw):
         """Either pass the reference's hydra-style `config` (config.yolo.*, config.dataset.anchors) or
         keyword arguments.  Defaults follow hydra/yolo/head.yaml:4-17."""
         super().__init__()
@@ -62,9 +63,13 @@ class YOLOForw(nn.Module):
         self.iou_type = opt("iou_type", 1)
         self.alpha, self.gamma = opt("alpha", 0.5), opt("gamma", 1)
         self.class_loss = opt("class_loss", 1)
-        if self.reduction != "sum" or self.class_loss != 1:
-            raise NotImplementedError("only reduction='sum' with class_loss=1 (CrossEntropy), the reference defaults "
-                                      "(hydra/yolo/head.yaml:14-15), are on the accelerated path")
+        # class_loss (yolo_forw.py:69-77): 0 BCEWithLogitsLoss(pos_weight), 1 CrossEntropyLoss(weight) [head.yaml default], 2 custom.EQLoss over
+        # the BCE form; reduction 'sum' [default] or 'mean' (any other string behaves like 'mean' in the reference's `== "sum"` tests only for
+        # the iou / no-object terms and is rejected by torch's loss constructors, so it is rejected here too)
+        if self.class_loss not in (0, 1, 2):
+            raise ValueError(f"YOLOForw: class_loss must be 0 (bce), 1 (ce) or 2 (eql), got {self.class_loss!r}")
+        if self.reduction not in ("sum", "mean"):
+            raise ValueError(f"YOLOForw: {self.reduction!r} is not a valid value for reduction")
         self.device = torch.device("cuda")
         # ---- class re-weighting (yolo_forw.py:33-67): `tfidf` = [weights switch, logits switch]; weights switch 1 = CrossEntropyLoss class
         #      weights from the idf table, 2 = effective-number weights (beta 0.9999 on instance_freq); logits switch 1 = the idf row
@@ -98,6 +103,17 @@ class YOLOForw(nn.Module):
             self.class_weights = None
         else:
             self.register_buffer("class_weights", torch.as_tensor(class_weights, dtype=torch.float32))
+        # custom.EQLoss.eq_mask (custom.py:79-80): classes whose share of the image frequencies is below 0.0045
+        if self.class_loss != 2:
+            self.eq_mask = None
+        else:
+            if img_freq is None:
+                if self.idf is None:
+                    from ..utilities.custom import IDFTransformer
+                    self.idf = IDFTransformer(_get(dcfg, "train_annotations"), _get(dcfg, "dset_name", "coco"), device="cpu")
+                img_freq = self.idf.idf_weights["img_freq"]
+            img_freq = torch.as_tensor(img_freq, dtype=torch.float32)
+            self.register_buffer("eq_mask", ((img_freq / img_freq.sum()) < 0.0045).float())
         # idf_logits (yolo_forw.py:38,63-67): scalar 1 or a [C] vector multiplying the class logits
         if idf_logits is None:
             self.idf_logits = None
@@ -149,9 +165,11 @@ class YOLOForw(nn.Module):
             grads = [torch.zeros_like(t) for t in keep]
             gv, _ = ops.head_views(grads, attrs_total)
         cw = None if self.class_weights is None else self.class_weights.to(device=dev, dtype=torch.float32).contiguous()
+        eq = None if self.eq_mask is None else self.eq_mask.to(device=dev, dtype=torch.float32).contiguous()
         cfg = _lib.YoloLossCfg(self.lambda_iou, self.lambda_xy, self.lambda_wh, self.lambda_conf, self.lambda_no_conf,
-                               self.lambda_cls, self.alpha, self.gamma, grad_scale, int(grad_is_bf16), None if cw is None else cw.data_ptr())
-        self._cw_keep = cw
+                               self.lambda_cls, self.alpha, self.gamma, grad_scale, int(grad_is_bf16), None if cw is None else cw.data_ptr(),
+                               int(self.class_loss), int(self.reduction == "mean"), None if eq is None else eq.data_ptr())
+        self._cw_keep = (cw, eq)
         out12 = ops.yolo_loss(geom, cfg, hv, gv, off, labels, obj_idx, tgt, noobj, self._idf(dev), bs, G)
         self.last_assignment = (obj_idx, tgt, noobj, counts)
         return out12, grads
@@ -164,7 +182,7 @@ class YOLOForw(nn.Module):
         grids = [int(h.shape[2]) for h in heads]
         geom = self._geom(grids)
         hv, keep = ops.head_views(heads, len(self.anchors[0]) * self.bbox_attrs)
-        out, score, label = ops.yolo_decode(geom, hv, self._idf(keep[0].device), keep[0].shape[0], softmax_cls=True, want_scores=True)
+        out, score, label = ops.yolo_decode(geom, hv, self._idf(keep[0].device), keep[0].shape[0], softmax_cls=self.class_loss == 1, want_scores=True)
         # conf*max(cls) / arg-max from the same pass (channels-last heads), picked up by procedures.test_one_epoch.postprocess
         # keyed on the tensor OBJECT (weak reference) and its version counter, not on its address: the caching allocator hands a freed block's
         # address to the next tensor of the same size, which would otherwise match a stale entry

@@ -132,7 +132,7 @@ class YoloSpec:
 
     def __init__(self, anchors, num_classes, img_size, iou_type=1, ignore_thr=0.5, lambda_iou=1.0,
                  lambda_xy=2.5, lambda_wh=2.5, lambda_conf=1.0, lambda_no_conf=0.1, lambda_cls=1.0,
-                 alpha=0.5, gamma=1.0, idf_logits=None, class_weights=None):
+                 alpha=0.5, gamma=1.0, idf_logits=None, class_weights=None, class_loss=1, reduction="sum", eq_mask=None):
         self.anchors = [[(float(w), float(h)) for w, h in s] for s in anchors]
         self.na = len(self.anchors[0])
         self.C = num_classes
@@ -144,7 +144,10 @@ class YoloSpec:
         self.l_conf, self.l_noconf, self.l_cls = lambda_conf, lambda_no_conf, lambda_cls
         self.alpha, self.gamma = alpha, gamma
         self.idf = None if idf_logits is None else np.asarray(idf_logits, F32)
-        self.cw = None if class_weights is None else np.asarray(class_weights, F32)      # CrossEntropyLoss(weight=...) (yolo_forw.py:50-62,72)
+        self.cw = None if class_weights is None else np.asarray(class_weights, F32)      # CrossEntropyLoss(weight=...) / pos_weight (yolo_forw.py:50-62,70-77)
+        self.class_loss = class_loss       # 0 BCEWithLogits(pos_weight) | 1 CrossEntropy(weight) | 2 EQLoss over BCE (yolo_forw.py:69-77)
+        self.reduction = reduction         # 'sum' (then / nG, yolo_forw.py:158-160) | 'mean'
+        self.eq_mask = None if eq_mask is None else np.asarray(eq_mask, F32)             # custom.py:79-80 (img_freq share < 0.0045)
 
 
 def anchor_table(spec, grids):
@@ -219,10 +222,37 @@ def decode(spec, heads):
     box = decode_rows(spec, raw[..., :4], cx[None], np.broadcast_to(inw[None], raw.shape[:2]))
     conf = _sigmoid(raw[..., 4:5])
     logits = raw[..., 5:] if spec.idf is None else spec.idf[None, None, :] * raw[..., 5:]
-    m = logits.max(-1, keepdims=True)
-    e = np.exp(logits - m)
-    cls = e / e.sum(-1, keepdims=True)
+    if spec.class_loss == 1:
+        m = logits.max(-1, keepdims=True)
+        e = np.exp(logits - m)
+        cls = e / e.sum(-1, keepdims=True)
+    else:
+        cls = _sigmoid(logits)                                # yolo_forw.py:171-173
     return np.concatenate([box, conf, cls], -1).astype(F32)
+
+
+def bce_class_loss(spec, logits, onehot):
+    """class_loss 0 / 2 (yolo_forw.py:70-77): BCEWithLogitsLoss(pos_weight) elementwise, for 2 wrapped in custom.EQLoss (custom.py:83-99).
+    -> (loss [nG,C] f32, d loss / d logits f64)."""
+    x = logits.astype(np.float64)
+    y = onehot.astype(np.float64)
+    pw = np.ones(spec.C) if spec.cw is None else spec.cw.astype(np.float64)
+    lw = 1 + (pw[None, :] - 1) * y
+    sp = np.log1p(np.exp(-np.abs(x))) + np.maximum(-x, 0)               # softplus(-x)
+    bce = (1 - y) * x + lw * sp
+    sig = 1 / (1 + np.exp(-x))
+    dbce = (1 - y) - lw * (1 - sig)
+    if spec.class_loss == 0:
+        return bce.astype(F32), dbce
+    p_t = y * sig + (1 - y) * (1 - sig)
+    af = y * spec.alpha + (1 - y) * (1 - spec.alpha)
+    q = 1 - p_t
+    w = np.clip(spec.eq_mask.astype(np.float64)[None, :] + y, 0.0, 1.0)
+    mf = q ** spec.gamma
+    dpt = (2 * y - 1) * sig * (1 - sig)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dmf = np.where(q > 0, -spec.gamma * q ** (spec.gamma - 1) * dpt, 0.0)
+    return (bce * af * mf * w).astype(F32), w * af * (dbce * mf + bce * dmf)
 
 
 def yolo_loss(spec, heads, targets, want_grad=True):
@@ -244,54 +274,74 @@ def yolo_loss(spec, heads, targets, want_grad=True):
     iou = bbox_iou(pbox, gbox, spec.iou_type)
     sxy = _sigmoid(final[:, :2])
     f64 = np.float64
-    loss_xy = spec.l_xy * ((sxy - tgt[:, :2]).astype(f64) ** 2).sum()
-    loss_wh = spec.l_wh * ((final[:, 2:4] - tgt[:, 2:4]).astype(f64) ** 2).sum()
-    pl, pg = focal_loss(final[:, 4], np.ones(nG, F32), spec.gamma, spec.alpha)
-    pos_conf = spec.l_conf * pl.astype(f64).sum()
+    mean = spec.reduction != "sum"
     no_obj = raw[..., 4][noobj]
-    nl, ng = focal_loss(no_obj, np.zeros_like(no_obj), spec.gamma, spec.alpha)
-    neg_conf = spec.l_noconf * nl.astype(f64).sum()
-    logits = final[:, 5:] if spec.idf is None else spec.idf[None, :] * final[:, 5:]
-    m = logits.max(-1, keepdims=True)
-    lse = m[:, 0] + np.log(np.exp(logits - m).sum(-1))
-    ce = lse - logits[np.arange(nG), labels]
-    wy = np.ones(nG, F32) if spec.cw is None else spec.cw[labels]
-    cls_loss = spec.l_cls * (wy.astype(f64) * ce.astype(f64)).sum()
-    iou_loss = spec.l_iou * (1 - iou.astype(f64)).sum()
-    sub = np.array([loss_xy, loss_wh, iou_loss, pos_conf, neg_conf, cls_loss], f64)
-    loss = sub.sum() / nG
-    # stats (yolo_forw.py:233-248): true_pred classes = softmax of RAW logits (no idf), transform_pred :222
-    rm = final[:, 5:].max(-1, keepdims=True)
-    pe = np.exp(final[:, 5:] - rm)
-    pcls = pe / pe.sum(-1, keepdims=True)
     onehot = np.zeros((nG, spec.C), bool)
     onehot[np.arange(nG), labels] = True
+    # per-term divisors: 'sum' -> everything / nG at the end (yolo_forw.py:158-160); 'mean' -> each loss its own element count
+    # (MSELoss over [nG,2]; FocalLoss / iou over nG; no-object term over its element count; class term below)
+    d_xy = 2.0 * nG if mean else 1.0
+    d_box = float(nG) if mean else 1.0
+    d_no = float(max(no_obj.size, 1)) if mean else 1.0
+    loss_xy = spec.l_xy * ((sxy - tgt[:, :2]).astype(f64) ** 2).sum() / d_xy
+    loss_wh = spec.l_wh * ((final[:, 2:4] - tgt[:, 2:4]).astype(f64) ** 2).sum() / d_xy
+    pl, pg = focal_loss(final[:, 4], np.ones(nG, F32), spec.gamma, spec.alpha)
+    pos_conf = spec.l_conf * pl.astype(f64).sum() / d_box
+    nl, ng = focal_loss(no_obj, np.zeros_like(no_obj), spec.gamma, spec.alpha)
+    neg_conf = spec.l_noconf * nl.astype(f64).sum() / d_no
+    logits = final[:, 5:] if spec.idf is None else spec.idf[None, :] * final[:, 5:]
+    m = logits.max(-1, keepdims=True)
+    wy = np.ones(nG, F32) if spec.cw is None else spec.cw[labels]
+    if spec.class_loss == 1:
+        lse = m[:, 0] + np.log(np.exp(logits - m).sum(-1))
+        ce = lse - logits[np.arange(nG), labels]
+        d_cls = float(wy.astype(f64).sum()) if mean else 1.0          # CrossEntropyLoss(weight, 'mean') divides by the summed target weights
+        cls_loss = spec.l_cls * (wy.astype(f64) * ce.astype(f64)).sum() / d_cls
+    else:
+        bl, dbl = bce_class_loss(spec, logits, onehot)
+        d_cls = float(nG * spec.C) if mean else 1.0
+        cls_loss = spec.l_cls * bl.astype(f64).sum() / d_cls
+    iou_loss = spec.l_iou * (1 - iou.astype(f64)).sum() / d_box
+    sub = np.array([loss_xy, loss_wh, iou_loss, pos_conf, neg_conf, cls_loss], f64)
+    final_div = 1.0 if mean else float(nG)
+    loss = sub.sum() / final_div
+    # stats (yolo_forw.py:233-248): true_pred classes = softmax (CE) / sigmoid (BCE forms) of RAW logits (no idf), transform_pred :220-223
+    if spec.class_loss == 1:
+        rm = final[:, 5:].max(-1, keepdims=True)
+        pe = np.exp(final[:, 5:] - rm)
+        pcls = pe / pe.sum(-1, keepdims=True)
+    else:
+        pcls = _sigmoid(final[:, 5:])
     stats = np.array([iou.astype(f64).mean(), _sigmoid(final[:, 4]).astype(f64).mean(),
                       _sigmoid(no_obj).astype(f64).mean(), pcls[onehot].astype(f64).mean(),
                       pcls[~onehot].astype(f64).mean()], f64)
-    out = {"loss": F32(loss), "sub_losses": (sub / nG).astype(F32), "stats": stats.astype(F32),
+    out = {"loss": F32(loss), "sub_losses": (sub / final_div).astype(F32), "stats": stats.astype(F32),
            "tgt": tgt, "obj_idx": obj_idx, "noobj": noobj}
     if want_grad:
         g = np.zeros((bs, N, A), f64)
-        inv = 1.0 / nG
+        inv = 1.0 / final_div
         conf = raw[..., 4]
         _, gall = focal_loss(conf, np.zeros_like(conf), spec.gamma, spec.alpha)
-        g[..., 4] = np.where(noobj, spec.l_noconf * gall.astype(f64) * inv, 0.0)
+        g[..., 4] = np.where(noobj, spec.l_noconf * gall.astype(f64) * inv / d_no, 0.0)
         giou = _iou_grad_fd(spec, final[:, :4], tgt, cxs, inws)
         e = np.exp(logits - m)
         sm = e / e.sum(-1, keepdims=True)
         for i in range(nG):                                  # duplicates accumulate
             b, a = bidx[i], aidx[i]
             s = sxy[i].astype(f64)
-            g[b, a, 0:2] += spec.l_xy * 2 * (s - tgt[i, :2]) * s * (1 - s) * inv
-            g[b, a, 2:4] += spec.l_wh * 2 * (final[i, 2:4].astype(f64) - tgt[i, 2:4]) * inv
-            g[b, a, 0:4] += -spec.l_iou * giou[i] * inv
-            g[b, a, 4] += spec.l_conf * pg[i] * inv
-            dl = sm[i].astype(f64).copy()
-            dl[labels[i]] -= 1
+            g[b, a, 0:2] += spec.l_xy * 2 * (s - tgt[i, :2]) * s * (1 - s) * inv / d_xy
+            g[b, a, 2:4] += spec.l_wh * 2 * (final[i, 2:4].astype(f64) - tgt[i, 2:4]) * inv / d_xy
+            g[b, a, 0:4] += -spec.l_iou * giou[i] * inv / d_box
+            g[b, a, 4] += spec.l_conf * pg[i] * inv / d_box
+            if spec.class_loss == 1:
+                dl = sm[i].astype(f64).copy()
+                dl[labels[i]] -= 1
+                dl = dl * float(wy[i])
+            else:
+                dl = dbl[i].copy()
             if spec.idf is not None:
                 dl = dl * spec.idf
-            g[b, a, 5:] += spec.l_cls * float(wy[i]) * dl * inv
+            g[b, a, 5:] += spec.l_cls * dl * inv / d_cls
         out["grad_flat"] = g.astype(F32)
         out["grads"] = unflatten_grads(spec, g.astype(F32), heads)
     return out

@@ -5,7 +5,8 @@ from oracle import detrand
 from oracle.yolo_oracle import YoloSpec
 
 YOLO_CASES = ["coco128", "coco128_idf", "coco128_iou", "coco128_diou", "coco128_ciou", "lvis96_a6",
-              "coco416", "coco640", "coco128_cw", "coco128_batchidf"]
+              "coco416", "coco640", "coco128_cw", "coco128_batchidf", "coco128_bce", "coco128_eql", "coco128_mean", "coco128_bce_mean"]
+YOLO_CLASS_LOSS = {"coco128_bce": 0, "coco128_eql": 2, "coco128_bce_mean": 0}          # class_loss of the case (default 1 = CrossEntropy)
 YOLO_FULL = YOLO_CASES[:6] + YOLO_CASES[8:]
 
 
@@ -37,5 +38,8 @@ def yolo_case(g3, name):
     targets = synth_targets(seed + 50, ms, C)
     if name == "coco128":
         targets[0][0][1] = targets[0][0][0] + np.float32(1e-3)
-    spec = YoloSpec(anchors, C, img, iou_type=iou_type, idf_logits=idf, class_weights=cw)
+    eq_mask = g3[name + "_eq_mask"] if (name + "_eq_mask") in g3.files else None
+    spec = YoloSpec(anchors, C, img, iou_type=iou_type, idf_logits=idf, class_weights=cw, class_loss=YOLO_CLASS_LOSS.get(name, 1),
+                    reduction="mean" if name.endswith("mean") else "sum", eq_mask=eq_mask)
+    spec.img_freq = g3[name + "_img_freq"] if (name + "_img_freq") in g3.files else None     # what custom.EQLoss derives eq_mask from
     return spec, heads, targets

@@ -315,3 +315,53 @@ def test_flat_optimizers_match_torch():
             theirs.step()
             assert float(g.abs().max()) == 0.0
         torch.testing.assert_close(w, ref.detach(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_dynamic_loss_scaler_skips_overflow_steps():
+    """apex amp semantics on the flat buffers (initialize.py:44-45, train_one_epoch.py:88-96): an inf / nan gradient skips the step, leaves
+    parameters and optimizer state untouched and halves the scale; clean steps equal torch.optim with the unscaled gradient; the scale
+    doubles after `scale_window` clean steps."""
+    from object_detectors_amd.optim import DynamicLossScaler, FlatAdam, FlatSGD
+    torch.manual_seed(1)
+    n = 50001
+    w0 = torch.randn(n, device="cuda")
+    grads = [torch.randn(n, device="cuda") for _ in range(5)]
+    for kind in ("sgd", "adam"):
+        w = w0.clone()
+        g = torch.zeros_like(w)
+        ref = w0.clone().requires_grad_(True)
+        if kind == "adam":
+            mine, theirs = FlatAdam(w, g, lr=1e-2), torch.optim.Adam([ref], lr=1e-2)
+        else:
+            mine, theirs = FlatSGD(w, g, lr=1e-2, momentum=0.9), torch.optim.SGD([ref], lr=1e-2, momentum=0.9)
+        scaler = DynamicLossScaler(init_scale=1024.0, scale_window=2)
+        applied = []
+        for it, gi in enumerate(grads):
+            g.copy_(gi * scaler.loss_scale)
+            if it in (0, 3):                                  # overflow on the very first step (SGD's first-step flag) and later
+                g[it * 7 + 5] = float("inf") if it == 0 else float("nan")
+            before = w.clone()
+            ok = scaler.step(mine, zero_grad=True)
+            applied.append(ok)
+            assert float(g.abs().max()) == 0.0               # cleared either way
+            if ok:
+                ref.grad = gi.clone()
+                theirs.step()
+            else:
+                assert torch.equal(w, before)
+        assert applied == [False, True, True, False, True]
+        torch.testing.assert_close(w, ref.detach(), rtol=2e-5, atol=2e-6)
+        # 1024 -> 512 (overflow) -> 2 clean steps -> 1024 -> overflow -> 512 -> one clean step
+        assert scaler.loss_scale == 512.0 and scaler.skipped_steps == 2 and mine.steps == 3
+    # odd length / unaligned tail of the check kernel
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    from object_detectors_amd._lib import check, lib
+    v = torch.zeros(1027, device="cuda")
+    v[1026] = float("-inf")
+    check(lib().mi355det_grad_nonfinite(v.data_ptr(), v.numel(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream), "grad_nonfinite")
+    assert int(flag.item()) == 1
+    flag.zero_()
+    v[1026] = 3.0e38
+    check(lib().mi355det_grad_nonfinite(v.data_ptr(), v.numel(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream), "grad_nonfinite")
+    assert int(flag.item()) == 0

@@ -21,7 +21,8 @@ def dev():
 def make_module(spec):
     from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
     return YOLOForw(anchors=spec.anchors, num_classes=spec.C, img_size=spec.img_size, iou_type=spec.iou_type,
-                    idf_logits=spec.idf, class_weights=spec.cw).to(dev())
+                    idf_logits=spec.idf, class_weights=spec.cw, class_loss=spec.class_loss, reduction=spec.reduction,
+                    img_freq=getattr(spec, "img_freq", None)).to(dev())
 
 
 def to_targets(targets):

@@ -30,7 +30,7 @@ def test_plan_buckets_cover_buffer_once():
     assert one == [(marks[-1][0], 0, 10000)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algo="all_reduce"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -54,7 +54,7 @@ def _worker(rank, world, port, q):
         return f
     plan.bwd = [(make_layer(i), ()) for i in reversed(range(n_layers))]
     plan.bwd_marks = [(k + 1, (n_layers - 1 - k) * per) for k in range(n_layers)]
-    sync = GradSync(flat, bucket_mb=per * 4 * 3 / (1 << 20))          # ~3 layers per bucket
+    sync = GradSync(flat, bucket_mb=per * 4 * 3 / (1 << 20), algo=algo)          # ~3 layers per bucket (3 * 777 elements: odd, so rs_ag has a remainder)
     sync.install(plan)
     hooks = sum(1 for fn, _a in plan.bwd if fn is comm_hook)
     for fn, args in plan.bwd:
@@ -70,11 +70,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradsync_world2_gloo():
+@pytest.mark.parametrize("algo", ["all_reduce", "rs_ag"])
+def test_gradsync_world2_gloo(algo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + (7 if algo == "rs_ag" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algo)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -221,6 +221,11 @@ def g3_yolo(helper, custom, yolo_forw):
         # CrossEntropyLoss class weights (tfidf[0] = 1: yolo_forw.py:50-54,72) and the per-batch idf row (tfidf_batch: :87-91)
         ("coco128_cw", COCO_ANCHORS, 80, 128, (4, 8, 16), (6, 3), 1, "cw", True),
         ("coco128_batchidf", COCO_ANCHORS, 80, 128, (4, 8, 16), (4, 5), 1, "batch", True),
+        # the other class-loss forms (class_loss 0 = BCEWithLogits(pos_weight), 2 = EQLoss: yolo_forw.py:69-77, custom.py:69-106) and reduction='mean'
+        ("coco128_bce", COCO_ANCHORS, 80, 128, (4, 8, 16), (5, 6), 1, "bce", True),
+        ("coco128_eql", COCO_ANCHORS, 80, 128, (4, 8, 16), (7, 2), 1, "eql", True),
+        ("coco128_mean", COCO_ANCHORS, 80, 128, (4, 8, 16), (3, 8), 1, "mean", True),
+        ("coco128_bce_mean", COCO_ANCHORS, 80, 128, (4, 8, 16), (6, 4), 2, "bce_mean", True),
     ]
     d = {}
     for i, (name, anchors, C, img, grids, ms, iou_type, idfv, full) in enumerate(cfgs):
@@ -238,6 +243,25 @@ def g3_yolo(helper, custom, yolo_forw):
             cw = detrand.uniform(seed + 77, (C,), 0.5, 2.0)
             F.class_loss = nn.CrossEntropyLoss(reduction="sum", weight=torch.from_numpy(cw))
             d[name + "_cw"] = cw
+        if mode in ("bce", "eql", "mean", "bce_mean"):
+            red = "mean" if mode.endswith("mean") else "sum"
+            cw = detrand.uniform(seed + 77, (C,), 0.5, 2.0)
+            d[name + "_cw"] = cw
+            F.reduction = red
+            F.wh_loss, F.xy_loss = nn.MSELoss(reduction=red), nn.MSELoss(reduction=red)
+            F.pobj_loss = custom.FocalLoss(nn.BCEWithLogitsLoss(reduction=red), gamma=1.0, alpha=0.5)
+            if mode == "mean":
+                F.class_loss = nn.CrossEntropyLoss(reduction=red, weight=torch.from_numpy(cw))
+            else:
+                F.class_loss = nn.BCEWithLogitsLoss(reduction=red, pos_weight=torch.from_numpy(cw))
+            if mode == "eql":
+                img_freq = np.exp(detrand.uniform(seed + 78, (C,), -4.0, 2.0)).astype(np.float32)
+                F.class_loss = custom.EQLoss(F.class_loss, img_freq=torch.from_numpy(img_freq), gamma=1.0, alpha=0.5)
+                d[name + "_img_freq"] = img_freq
+                d[name + "_eq_mask"] = F.class_loss.eq_mask.numpy().astype(np.float32)
+            if mode == "bce_mean":
+                F.idf_logits = torch.from_numpy(idf)
+                d[name + "_idf"] = idf
         if mode == "batch":
             F.tfidf_batch, F.tfidf_norm = True, 2
             F.idf = custom.IDFTransformer.__new__(custom.IDFTransformer)       # forward() only needs num_classes

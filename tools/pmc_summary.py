@@ -24,7 +24,8 @@ def family(name):
     m = re.match(r"(igemm\w*)<([^>]*)>", name)
     if m:
         a = [x.strip() for x in m.group(2).split(",")]
-        e = a[6] if m.group(1) == "igemm_kernel" else (a[4] if m.group(1) == "igemm_dx_kernel" else a[5])
+        kind = m.group(1)
+        e = a[0] if kind == "igemm8_kernel" else a[6] if kind == "igemm_kernel" else (a[4] if kind == "igemm_dx_kernel" else a[5])
         return "igemm " + {"0": "fwd (BN partial stats)", "1": "fwd (fp32 head)", "2": "dgrad (+skip)", "3": "dgrad", "4": "fwd (affine)"}.get(e, e)
     return name.split("(")[0].split("<")[0][:60]
 

@@ -1,0 +1,97 @@
+"""Phase stamps of the phase-staggered 256x256x64 conv kernel (diagnostic build igemm8_kernel<EPI_STATS, false, true>):
+
+    python tools/prof_ig8.py > profiles/r02_igemm8_phase_stamps.txt
+
+Per wave and k-step the loop has four phases, each (A) fragment reads + LDS-DMA issue, (B) counted vmcnt wait + barrier, (C) 16 MFMAs,
+(D) trailing barrier.  Waves 0-3 (pixel half 0) and 4-7 (pixel half 1) share the four SIMDs pairwise (wave w and w+4) and run one barrier
+apart, so one wave's (C) should coincide with its partner's (D)+(A)+(B).  The table prints the summed segments and the absolute stamps of one
+k-step for the two waves of SIMD 0 of a few workgroups."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detectors_amd import ops  # noqa: E402
+from object_detectors_amd._lib import lib  # noqa: E402
+
+dev = torch.device("cuda:0")
+for (n, h, w, cin, cout, k, s) in [(32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (32, 80, 80, 128, 256, 3, 1)]:
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s)
+    x = torch.randn(n, h, w, cin, device=dev).bfloat16()
+    wt = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    wf, wd = ops.pack_weights(shape, wt)
+    y = torch.empty(n, shape.ho, shape.wo, cout, device=dev, dtype=torch.bfloat16)
+    stats = torch.zeros(ops.conv_stats_rows(shape) + 64, 2, ops.cout_pad_of(cout), device=dev)
+    flops = 2.0 * n * shape.ho * shape.wo * cout * cin * k * k
+    lib().mi355det_debug_set(0, 40)
+
+    def timed():
+        for _ in range(3):
+            ops.conv_fwd(shape, x, wf, y, stats=stats)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.conv_fwd(shape, x, wf, y, stats=stats)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 100
+    us = timed()
+    dbg = torch.zeros(64 * 8 * 24, dtype=torch.int64, device=dev)
+    # ---- mode 2: one stamp per k-step (start of 16 consecutive k-steps of every wave): near-release timing
+    lib().mi355det_debug_set(3, 2)
+    lib().mi355det_debug_ptr(1, dbg.data_ptr())
+    us_k = timed()
+    lib().mi355det_debug_ptr(1, None)
+    dk = dbg.cpu().numpy().astype(np.int64).reshape(64, 8, 24)
+    caps = (dk[:, :, 5:21] & 0xFFFFFFFF).astype(np.int64)
+    per = np.diff(caps, axis=-1)
+    per = per[(caps[:, :, :1] > 0).repeat(15, -1)].reshape(-1, 15)
+    print(f"== conv {cin}->{cout} {k}x{k} @{shape.ho} bs {n}: release build {us:.1f} us ({flops / us / 1e6:.0f} TFLOP/s)")
+    print(f"   one stamp per k-step ({us_k:.1f} us): k-step period {per.mean():.0f} cycles (min {per.min()} max {per.max()}, median {np.median(per):.0f}); "
+          f"a SIMD issues 2 x 64 MFMAs of 16 cycles = 2048 cycles per k-step -> MFMA pipe busy {100 * 2048 / per.mean():.0f} % inside the loop")
+    off = (caps[:, 4:, 0] - caps[:, :4, 0])
+    off = off[(caps[:, 4:, 0] > 0) & (caps[:, :4, 0] > 0)]
+    print(f"   start of the same k-step, wave w+4 minus wave w (SIMD partners): mean {off.mean():.0f} cycles (min {off.min()} max {off.max()}) = "
+          f"{off.mean() / per.mean():.2f} of a k-step (1/8 = one barrier interval)")
+    # ---- mode 1: phase stamps
+    dbg.zero_()
+    lib().mi355det_debug_set(3, 1)
+    lib().mi355det_debug_ptr(1, dbg.data_ptr())
+    us_p = timed()
+    lib().mi355det_debug_ptr(1, None)
+    lib().mi355det_debug_set(0, 0)
+    d = dbg.cpu().numpy().astype(np.int64).reshape(64, 8, 24)
+    steps = int(d[0, 0, 4])
+    print(f"   phase-stamped build {us_p:.1f} us (17 stamps per k-step, each draining lgkmcnt; its loop also reloads spilled stamp state at the top of "
+          f"every k-step, which shows up as ONE long barrier wait per k-step in the partner half); {steps} k-steps per tile")
+    tot = d[:, :, :4].sum(-1).astype(np.float64)
+    names = ["A reads + LDS-DMA issue", "B vmcnt wait + barrier", "C 16 MFMAs", "D trailing barrier"]
+    for i, nm in enumerate(names):
+        v = d[:, :, i].astype(np.float64) / steps / 4
+        print(f"   {nm:26s} {v.mean():7.0f} cycles per phase  ({100 * d[:, :, i].sum() / tot.sum():4.1f} % of the loop; min {v.min():.0f} max {v.max():.0f})")
+    print(f"   loop total per k-step: {tot.mean() / steps:.0f} cycles = 64 MFMAs; MFMA segment share {100 * d[:, :, 2].sum() / tot.sum():.1f} %")
+    # overlap of the SIMD partners: fraction of wave 0's C segments (captured k-step) during which wave 4 is NOT in a C segment
+    ov = []
+    for wg in range(64):
+        for w0 in range(4):
+            a = d[wg, w0, 5:22] & 0xFFFFFFFF
+            b = d[wg, w0 + 4, 5:22] & 0xFFFFFFFF
+            if a[0] == 0 or b[0] == 0:
+                continue
+            ca = [(a[2 + 4 * q], a[3 + 4 * q]) for q in range(4)]
+            cb = [(b[2 + 4 * q], b[3 + 4 * q]) for q in range(4)]
+            la = sum(e - s_ for s_, e in ca)
+            both = sum(max(0, min(e, e2) - max(s_, s2)) for s_, e in ca for s2, e2 in cb)
+            ov.append(both / max(la, 1))
+    print(f"   SIMD partners (wave w, w+4), captured k-step: {100 * np.mean(ov):.0f} % of a wave's MFMA-segment time coincides with the partner's MFMA "
+          f"segment (0 % = perfectly complementary, n={len(ov)})")
+    for wg in (0, 1):
+        a0 = int(d[wg, 0, 5] & 0xFFFFFFFF)
+        for wv in (0, 4):
+            c = (d[wg, wv, 5:22] & 0xFFFFFFFF) - a0
+            seg = "  ".join(f"P{q + 1}[A {c[1 + 4 * q] - c[4 * q]:4d} B {c[2 + 4 * q] - c[1 + 4 * q]:4d} C {c[3 + 4 * q] - c[2 + 4 * q]:4d} D {c[4 + 4 * q] - c[3 + 4 * q]:4d}]"
+                            for q in range(4))
+            print(f"   wg{wg} wave{wv}: k-step starts at +{c[0]:5d}; {seg}; C segments at " + " ".join(f"{c[2 + 4 * q]}-{c[3 + 4 * q]}" for q in range(4)))

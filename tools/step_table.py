@@ -26,6 +26,8 @@ def family(name):
     if m:
         a = [x.strip() for x in m.group(2).split(",")]
         epi = {"0": "stats(fwd+BN partials)", "1": "f32 head", "2": "residual(dgrad+skip)", "3": "plain(dgrad)", "4": "affine", "5": "dgrad+BN partial sums"}
+        if m.group(1) == "igemm8_kernel":
+            return f"igemm8 256x256x64 phase-staggered{' stream-K' if a[1] == 'true' else ''} epi={epi.get(a[0], a[0])}"
         if m.group(1) == "igemm_kernel":
             return f"igemm {int(a[0]) * int(a[2]) * 16}x{int(a[1]) * int(a[3]) * 16}x{a[4]} ring{a[5]} epi={epi.get(a[6], a[6])}"
         if m.group(1) == "igemm_dx_kernel":
