@@ -175,12 +175,18 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       }
       return s;
     };
+    // (measured and removed: issuing the second piece of every half-tile between the MFMAs of the same phase, with vmcnt(7), is 3-8 %
+    //  slower on every shape - an LDS-DMA piece among MFMAs stalls the matrix pipe for longer than it shortens the load segment)
+    // ablation builds (PROF 3 / 4 / 5, results are garbage, timing only): the loop without its LDS-DMA, without its fragment reads, without
+    // its MFMAs (tools/prof_ig8.py)
     auto issue_x = [&](const Slot& s, int h, int buf) {
+      if (PROF == 3) return;
       char* dst = smem + buf * kSTAGE + h * kHALF + (2 * wid) * 1024;
 #pragma unroll
       for (int i = 0; i < 2; ++i) bufld16(rsrc_x, dst + i * 1024, ((a_valid[h][i] >> s.tap) & 1u) ? a_voff[h][i] : OOB_VOFF, s.soffx);
     };
     auto issue_w = [&](const Slot& s, int h, int buf) {
+      if (PROF == 3) return;
       char* dst = smem + buf * kSTAGE + (2 + h) * kHALF + (2 * wid) * 1024;
 #pragma unroll
       for (int i = 0; i < 2; ++i) bufld16(rsrc_w, dst + i * 1024, s.live ? b_voff[h][i] : OOB_VOFF, s.soffw);
@@ -242,20 +248,43 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     if (wm == 1) bar();             // the second pixel half runs one barrier behind
 
     bf16x8_t xf[2][4][2], wf[2][2][2];    // [half][tile][k-substep]
+    // (measured and removed: software-pipelining the quarters by one phase - phase 1 multiplying the (W1, X1) fragments of the previous
+    //  k-step so that every fragment read has a whole barrier interval to land - keeps all 96 fragment VGPRs live, hits the 256-VGPR cap
+    //  with spills and is equal within noise: fragment-read latency is not what the loop waits for)
     auto read_x = [&](int h) {
+      if (PROF == 4) return;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (xrd ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
     };
     auto read_w = [&](int h) {
+      if (PROF == 4) return;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (wrd ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
     };
     auto mfma_q = [&](int hw, int hx) {
-      __builtin_amdgcn_s_setprio(1);
+      if (PROF == 5) return;
+      if (PROF == 6) {
+        // timing-only ablation: the same FLOPs as 8 v_mfma_f32_32x32x16_bf16 (32 cycles each, the vector issue port held for 8 of them)
+        // instead of 16 v_mfma_f32_16x16x32_bf16 (16 cycles, 8 held); operands and accumulator views are NOT a valid product
+        typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj += 2) {
+              f32x16_t* a16 = (f32x16_t*)&acc[hw * 2 + ii][hx * 4 + (jj & 2) * 2];
+              *a16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hw][ii][ks], xf[hx][jj + ii][ks], *a16, 0, 0, 0);      // every fragment read stays live
+            }
+        __builtin_amdgcn_s_setprio(0);
+        return;
+      }
+      __builtin_amdgcn_s_setprio(1);      // measured: no priority, priority on the load segments instead, or waves 4-7 raised for the whole loop are all within +-1 %
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -270,13 +299,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     //      issue, (B) counted vmcnt wait + barrier, (C) the 16 MFMAs, (D) trailing barrier - summed over the tile per wave, plus the 17
     //      absolute stamps of ONE k-step, so the timelines of the two waves of a SIMD can be laid side by side (tools/prof_ig8.py).
     //      Each stamp drains lgkmcnt, i.e. segment A includes the LDS read latency that the release build leaves in flight.
-    constexpr bool PH = PROF == 1 && !SK;      // PROF == 2: only the start of 16 consecutive k-steps (near-release timing)
+    constexpr bool PH = PROF == 1 && !SK;      // PROF == 2: only the start of 12 consecutive k-steps (near-release timing)
     constexpr bool PK = PROF == 2 && !SK;
     unsigned ph_sum[4] = {0, 0, 0, 0}, ph_cap[17], ph_prev = 0;      // low 32 bits of the counter: spans are far below 2^32 cycles
-    unsigned long long ph_now = 0;
+    unsigned long long ph_now = 0, ph_rt0 = 0, ph_rt1 = 0;
 #pragma unroll
     for (int i = 0; i < 17; ++i) ph_cap[i] = 0;
-    const int ph_t = k0 + 6;
+    const int ph_t = k0 + (PROF == 2 ? 4 : 6);
 #define PH_STAMP(seg, capi)                                                                                     \
   do {                                                                                                          \
     if (PH) {                                                                                                   \
@@ -291,11 +320,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     int buf = 0;
     for (int t = k0; t < k1; ++t) {
       PH_STAMP(-1, 0);
-      if (PK && (unsigned)(t - ph_t) < 16u) {
+      if (PK && (unsigned)(t - ph_t) < 12u) {
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_now)::"memory");
         __builtin_amdgcn_sched_barrier(0);
         ph_cap[t - ph_t] = (unsigned)ph_now;
+        if (t == ph_t) ph_rt0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz wall clock: calibrates the cycle counter under load
+        if (t == ph_t + 11) ph_rt1 = __builtin_amdgcn_s_memrealtime();
       }
       // ---- phase 1
       read_w(0);
@@ -364,6 +395,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       d[4] = (unsigned long long)(k1 - k0);
 #pragma unroll
       for (int i = 0; i < 17; ++i) d[5 + i] = ph_cap[i];
+      d[22] = ph_rt0;
+      d[23] = ph_rt1;
     }
     stamp(2);
     if (wm == 0) bar();             // re-align the two halves
@@ -455,6 +488,21 @@ int launch8(const IgemmParams& p, hipStream_t st, bool streamk) {
       (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
       (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
       attr_done_p = true;
+    }
+    if (g_sk_dbg_mode >= 3) {
+      static bool attr_done_a = false;
+      if (!attr_done_a) {
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        attr_done_a = true;
+      }
+      if (g_sk_dbg_mode == 3) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 3>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 4) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 4>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 6) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 6>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 5>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      return check_launch("igemm8_ablation");
     }
     if (g_sk_dbg_mode == 2) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 2>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
     else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 1>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);

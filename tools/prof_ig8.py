@@ -40,22 +40,34 @@ for (n, h, w, cin, cout, k, s) in [(32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 51
         return e0.elapsed_time(e1) * 100
     us = timed()
     dbg = torch.zeros(64 * 8 * 24, dtype=torch.int64, device=dev)
-    # ---- mode 2: one stamp per k-step (start of 16 consecutive k-steps of every wave): near-release timing
+    # ---- mode 2: one stamp per k-step (start of 12 consecutive k-steps of every wave): near-release timing
     lib().mi355det_debug_set(3, 2)
     lib().mi355det_debug_ptr(1, dbg.data_ptr())
     us_k = timed()
     lib().mi355det_debug_ptr(1, None)
     dk = dbg.cpu().numpy().astype(np.int64).reshape(64, 8, 24)
-    caps = (dk[:, :, 5:21] & 0xFFFFFFFF).astype(np.int64)
-    per = np.diff(caps, axis=-1)
-    per = per[(caps[:, :, :1] > 0).repeat(15, -1)].reshape(-1, 15)
+    caps = (dk[:, :, 5:17] & 0xFFFFFFFF).astype(np.int64)
+    ok = (caps > 0).all(-1)                                  # waves whose tile had at least 16 k-steps
+    per = np.diff(caps[ok], axis=-1)
+    rt = (dk[:, :, 23] - dk[:, :, 22])[ok].astype(np.float64)            # 10 ns ticks over 11 k-steps
+    ghz = (caps[ok][:, 11] - caps[ok][:, 0]) / (rt * 10.0)
     print(f"== conv {cin}->{cout} {k}x{k} @{shape.ho} bs {n}: release build {us:.1f} us ({flops / us / 1e6:.0f} TFLOP/s)")
+    print(f"   cycle counter against the 100 MHz real-time counter over the same 11 k-steps: {ghz.mean():.2f} GHz (min {ghz.min():.2f} max {ghz.max():.2f}) "
+          f"-> the MFMA peak at this clock is {2.5 * ghz.mean() / 2.4:.2f} PFLOP/s")
     print(f"   one stamp per k-step ({us_k:.1f} us): k-step period {per.mean():.0f} cycles (min {per.min()} max {per.max()}, median {np.median(per):.0f}); "
           f"a SIMD issues 2 x 64 MFMAs of 16 cycles = 2048 cycles per k-step -> MFMA pipe busy {100 * 2048 / per.mean():.0f} % inside the loop")
     off = (caps[:, 4:, 0] - caps[:, :4, 0])
-    off = off[(caps[:, 4:, 0] > 0) & (caps[:, :4, 0] > 0)]
+    off = off[ok[:, 4:] & ok[:, :4]]
     print(f"   start of the same k-step, wave w+4 minus wave w (SIMD partners): mean {off.mean():.0f} cycles (min {off.min()} max {off.max()}) = "
           f"{off.mean() / per.mean():.2f} of a k-step (1/8 = one barrier interval)")
+    # ---- ablation builds: the same launch without the loop's LDS-DMA / fragment reads / MFMAs (garbage results, timing only)
+    abl = {}
+    for mode, nm in ((3, "no LDS-DMA"), (4, "no fragment reads"), (5, "no MFMAs"), (6, "32x32x16 MFMAs (same FLOPs)")):
+        lib().mi355det_debug_set(3, mode)
+        lib().mi355det_debug_ptr(1, dbg.data_ptr())
+        abl[nm] = timed()
+        lib().mi355det_debug_ptr(1, None)
+    print("   ablations (whole launch, us): release %.1f | " % us + " | ".join(f"{k_} {v:.1f}" for k_, v in abl.items()))
     # ---- mode 1: phase stamps
     dbg.zero_()
     lib().mi355det_debug_set(3, 1)
