@@ -10,9 +10,11 @@ namespace {
 
 #define NMS_MAX_N 16384
 #define SORT_THREADS 1024
+#define RADIX_MIN_N 4096      // padded sizes from here on are sorted by the radix path of nms_sort_kernel
+#define RADIX_CAP 16384        // = NMS_MAX_N
 
 struct NmsWs {   // per-image workspace carve (all offsets in bytes, 16-B aligned)
-  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, stride;
+  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, diagt, stride;
   int words;
 };
 
@@ -28,6 +30,7 @@ __host__ __device__ inline NmsWs nms_layout(int max_n) {
   w.kept = o;       o = align16(o + sizeof(int) * (size_t)max_n);
   w.remover = o;    o = align16(o + sizeof(int) * (size_t)max_n);
   w.misc = o;       o = align16(o + 64);
+  w.diagt = o;      o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64);   // transposed diagonal blocks: word j = earlier boxes of j's tile that drop j
   w.mask = o;       o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64 * w.words);   // [column block][row padded to 64]
   w.stride = o;
   return w;
@@ -70,28 +73,110 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __r
     off_scale = m + 1.0f;
   }
   __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npad; i += SORT_THREADS) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long a = keys[i], c = keys[ixj];
-          const bool desc = (i & k) == 0;   // descending overall
-          if (desc ? a < c : a > c) {
-            keys[i] = c;
-            keys[ixj] = a;
-          }
+  const bool radix = npad >= RADIX_MIN_N;
+  if (radix) {
+    // ---- LSD radix sort, 4-bit digits, 8 passes, one workgroup.  Position p starts with (key' = ~ordered(score), source index); MODE 1
+    //      starts in index order, MODE 0 in reverse index order, so that the stable sort leaves equal scores in the order the reference's
+    //      argsort does.  Every thread owns a contiguous run of `items` positions, counts its digits (packed 8-bit counters), the
+    //      [digit][thread] count table is scanned once per pass, and the run is scattered in order.  ~25 us for 10 000 boxes against
+    //      ~280 us for the bitonic network below, which is kept for small inputs.
+    unsigned* rk = (unsigned*)keys;                                      // [RADIX_CAP] keys
+    unsigned short* ri = (unsigned short*)(rk + RADIX_CAP);               // [RADIX_CAP] source indices
+    unsigned short* cnt = ri + RADIX_CAP;                                 // [16][SORT_THREADS] digit counts, then exclusive offsets
+    __shared__ unsigned s_wsum[SORT_THREADS / WAVE];
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+    const int items = (n + SORT_THREADS - 1) / SORT_THREADS;              // <= 16
+    const int total = items * SORT_THREADS;
+    for (int p = tid; p < total; p += SORT_THREADS) {
+      unsigned k = 0xFFFFFFFFu;
+      unsigned short src = 0;
+      if (p < n) {
+        const int i = MODE == 0 ? n - 1 - p : p;
+        const float sc = MODE == 0 ? P[(size_t)i * 6 + 4] : scores[i];
+        k = ~f2ord(sc);
+        src = (unsigned short)i;
+      }
+      rk[p] = k;
+      ri[p] = src;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 4 * pass;
+      unsigned k[16];
+      unsigned short ix[16];
+      unsigned long long c0 = 0, c1 = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < items) {
+          k[j] = rk[tid * items + j];
+          ix[j] = ri[tid * items + j];
+          const unsigned d = (k[j] >> shift) & 15u;
+          if (d < 8) c0 += 1ull << (8 * d);
+          else c1 += 1ull << (8 * (d - 8));
         }
+#pragma unroll
+      for (int d = 0; d < 16; ++d) cnt[d * SORT_THREADS + tid] = (unsigned short)(((d < 8 ? c0 >> (8 * d) : c1 >> (8 * (d - 8)))) & 0xFFull);
+      __syncthreads();
+      // exclusive scan of the table in (digit, thread) order: thread t owns 16 consecutive entries
+      unsigned v[16], sum = 0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v[e] = cnt[tid * 16 + e];
+        sum += v[e];
+      }
+      unsigned inc = sum;
+#pragma unroll
+      for (int o = 1; o < WAVE; o <<= 1) {
+        const unsigned up = (unsigned)__shfl_up((int)inc, o, WAVE);
+        if (lane >= o) inc += up;
+      }
+      if (lane == WAVE - 1) s_wsum[wid] = inc;
+      __syncthreads();
+      unsigned run = inc - sum;
+      for (int w = 0; w < wid; ++w) run += s_wsum[w];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        cnt[tid * 16 + e] = (unsigned short)run;
+        run += v[e];
       }
       __syncthreads();
+      // scatter the run in order; the thread's 16 offsets live in its own column of the table
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < items) {
+          const unsigned d = (k[j] >> shift) & 15u;
+          const unsigned pos = cnt[d * SORT_THREADS + tid];
+          cnt[d * SORT_THREADS + tid] = (unsigned short)(pos + 1);
+          rk[pos] = k[j];
+          ri[pos] = ix[j];
+        }
+      __syncthreads();
+    }
+  } else {
+  for (int k = 2; k <= npad; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < npad; i += SORT_THREADS) {
+          const int ixj = i ^ j;
+          if (ixj > i) {
+            const unsigned long long a = keys[i], c = keys[ixj];
+            const bool desc = (i & k) == 0;   // descending overall
+            if (desc ? a < c : a > c) {
+              keys[i] = c;
+              keys[ixj] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
     }
   }
   int* sorted_idx = (int*)(ws + L.sorted_idx);
   float4* sbox = (float4*)(ws + L.sbox);
   int* scls = (int*)(ws + L.scls);
+  const unsigned short* ri_sorted = (const unsigned short*)((const unsigned*)keys + RADIX_CAP);
   for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
     const unsigned tie = (unsigned)(keys[i] & 0xFFFFFFFFull);
-    const int src = MODE == 0 ? (int)tie : (int)(0xFFFFFFFFu - tie);
+    const int src = radix ? (int)ri_sorted[i] : (MODE == 0 ? (int)tie : (int)(0xFFFFFFFFu - tie));
     sorted_idx[i] = src;
     if (MODE == 0) {
       const float* r = P + (size_t)src * 6;
@@ -163,18 +248,45 @@ __global__ __launch_bounds__(WAVE) void nms_mask_kernel(char* __restrict__ ws_ba
     if (drop) bits |= 1ull << c;
   }
   ((unsigned long long*)(ws + L.mask))[(size_t)tj * (L.words * 64) + i] = bits;   // column-block major: [tj][row]
+  if (ti == tj) {
+    // transposed diagonal block for the scan's round-based resolve: lane c collects column c = the earlier boxes of this tile that
+    // drop box c.  Built from the SAME bits by ballots (not recomputed: the quotient is not symmetric in its rounding)
+    unsigned long long col = 0;
+    for (int c = 0; c < cn; ++c) {
+      const unsigned long long rows = __ballot((bits >> c) & 1ull);
+      if (lane == c) col = rows;
+    }
+    ((unsigned long long*)(ws + L.diagt))[i] = col;
+  }
 }
 
 // ---- 3. greedy scan: one workgroup per image ------------------------------------------------------
-// Tile t (64 sorted boxes) needs R_t = OR over all boxes kept so far of their mask word for column block t.  Those loads
-// are independent of each other, so the whole workgroup issues them at once (one memory round trip per tile instead of
-// one per kept row), ORs them with wave shuffles, and wave 0 resolves the 64x64 diagonal block in registers
-// (readlane chain).  The kept list lives in LDS.  Sequential cost: ~2 memory latencies per 64 boxes.
-#define SCAN_THREADS 256
+// Tile t (64 sorted boxes) needs R_t = OR over all boxes kept so far of their mask word for column block t, then a 64-step chain over
+// its 64x64 diagonal block.  Only the chain is serial; everything else is pushed ahead of it:
+//   * wave 0 ("resolver") resolves tile t from R[t] (LDS) | the rows of tile t-1 in column block t (prefetched one tile earlier, masked
+//     with tile t-1's kept bits), and prefetches the two 64-word pieces of tile t+1 before it starts the chain;
+//   * waves 1..15 ("pushers"), while tile t is being resolved, OR the kept rows of tile t-1 into R[u] of EVERY later column block
+//     u >= t+1: one coalesced 512-byte read per column block (the 64 rows of a tile are contiguous in a column block), eight in flight,
+//     and an LDS atomic OR per kept row.  By the time tile u is resolved R[u] holds the rows of all tiles <= u-2; tile u-1 comes in through the prefetch.
+//   * one barrier per tile.  Sequential cost per 64 boxes: the readlane chain + one barrier.
+#define SCAN_THREADS 1024
+__device__ __forceinline__ unsigned op_or_u(unsigned a, unsigned b) { return a | b; }
+// OR over the wave, result valid in lane 63 (quad / row rotations, then row broadcasts)
+__device__ __forceinline__ unsigned long long wave_or64_lane63(unsigned long long v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define NMS_OR_STEP(x, ctrl, rmask) \
+  x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xF, false)
+  NMS_OR_STEP(lo, 0xB1, 0xF); NMS_OR_STEP(hi, 0xB1, 0xF);
+  NMS_OR_STEP(lo, 0x4E, 0xF); NMS_OR_STEP(hi, 0x4E, 0xF);
+  NMS_OR_STEP(lo, 0x124, 0xF); NMS_OR_STEP(hi, 0x124, 0xF);
+  NMS_OR_STEP(lo, 0x128, 0xF); NMS_OR_STEP(hi, 0x128, 0xF);
+  NMS_OR_STEP(lo, 0x142, 0xA); NMS_OR_STEP(hi, 0x142, 0xA);
+  NMS_OR_STEP(lo, 0x143, 0xC); NMS_OR_STEP(hi, 0x143, 0xC);
+#undef NMS_OR_STEP
+  return ((unsigned long long)hi << 32) | lo;
+}
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(char* __restrict__ ws_base, NmsWs L, int* __restrict__ out_count) {
-  extern __shared__ unsigned long long skeptbits[];     // bit r%64 of word r/64: sorted box r is kept
-  __shared__ unsigned long long s_red[SCAN_THREADS / WAVE];
-  __shared__ int s_kc;
+  extern __shared__ unsigned long long s_scan[];        // [words] kept bits per tile, then [words] removed bits per column block
   const int b = blockIdx.x;
   char* ws = ws_base + (size_t)b * L.stride;
   const int n = ((const int*)(ws + L.misc))[0];
@@ -184,65 +296,69 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(char* __restrict
   int* remover = (int*)(ws + L.remover);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
   const int words = (n + 63) / 64;
-  int kc = 0;
+  unsigned long long* skeptbits = s_scan;
+  unsigned long long* sR = s_scan + L.words;
+  for (int i = tid; i < words; i += SCAN_THREADS) sR[i] = 0ull;
+  __syncthreads();
+  constexpr int NPUSH = SCAN_THREADS / WAVE - 1;
+  // resolver state (wave 0): rows of the previous tile in this column block, this tile's transposed diagonal block (lane j: the earlier
+  // boxes of the tile that drop j), the previous tile's kept bits
+  const unsigned long long* diagt = (const unsigned long long*)(ws + L.diagt);
+  unsigned long long curA = 0, curT = 0, kept_prev = 0;
+  if (wid == 0 && lane < n) curT = diagt[lane];
+  int kc = 0;                                           // boxes kept in tiles < t (resolver only)
   for (int t = 0; t < words; ++t) {
-    const int row = t * 64 + lane;
-    const unsigned long long* col = mask + (size_t)t * NP;
-    unsigned long long diag = 0;
-    if (wid == 0 && row < n) diag = col[row];
-    // R_t = OR over the kept rows r < 64 t of word [t][r]: contiguous in r, all loads independent
-    unsigned long long acc = 0;
-    const int rows_before = t * 64;
-    int r = tid;
-    for (; r + 3 * SCAN_THREADS < rows_before; r += 4 * SCAN_THREADS) {
-      const unsigned long long a0 = col[r], a1 = col[r + SCAN_THREADS], a2 = col[r + 2 * SCAN_THREADS], a3 = col[r + 3 * SCAN_THREADS];
-      const unsigned long long kb = skeptbits[r >> 6];      // SCAN_THREADS is a multiple of 64: the four rows share the bit index
-      const unsigned long long k1 = skeptbits[(r + SCAN_THREADS) >> 6], k2 = skeptbits[(r + 2 * SCAN_THREADS) >> 6],
-                               k3 = skeptbits[(r + 3 * SCAN_THREADS) >> 6];
-      const int bit = r & 63;
-      acc |= ((kb >> bit) & 1ull ? a0 : 0ull) | ((k1 >> bit) & 1ull ? a1 : 0ull) | ((k2 >> bit) & 1ull ? a2 : 0ull) | ((k3 >> bit) & 1ull ? a3 : 0ull);
-    }
-    for (; r < rows_before; r += SCAN_THREADS) {
-      const unsigned long long a0 = col[r];
-      if ((skeptbits[r >> 6] >> (r & 63)) & 1ull) acc |= a0;
-    }
-    unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      lo |= (unsigned)__shfl_xor((int)lo, o, WAVE);
-      hi |= (unsigned)__shfl_xor((int)hi, o, WAVE);
-    }
-    if (lane == 0) s_red[wid] = ((unsigned long long)hi << 32) | lo;
-    __syncthreads();
     if (wid == 0) {
-      unsigned long long R = 0;
-#pragma unroll
-      for (int w = 0; w < SCAN_THREADS / WAVE; ++w) R |= s_red[w];
+      const int row = t * 64 + lane;
+      unsigned long long nextA = 0, nextT = 0;
+      if (t + 1 < words) {
+        if (row < n) nextA = mask[(size_t)(t + 1) * NP + row];
+        if (row + 64 < n) nextT = diagt[row + 64];
+      }
+      const unsigned long long q = wave_or64_lane63(((kept_prev >> lane) & 1ull) ? curA : 0ull);
+      const unsigned long long Rt = sR[t];
       const int cn = min(64, n - t * 64);
       const unsigned long long valid = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
-      // wave-uniform values through readfirstlane: the 64-step chain below then runs on the scalar unit
-      const unsigned long long Ru = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(R >> 32)) << 32) |
-                                    (unsigned)__builtin_amdgcn_readfirstlane((int)R);
+      const unsigned long long Ru = (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(q >> 32), 63) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)q, 63)) |
+                                    (((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(Rt >> 32)) << 32) |
+                                     (unsigned)__builtin_amdgcn_readfirstlane((int)Rt));
+      // rounds instead of a 64-step chain: an undecided box that no undecided earlier box of the tile drops is kept (all its possible
+      // droppers are decided, and a kept one would already have removed it); the newly kept ones then remove what they drop.  The lowest
+      // undecided box always qualifies, so every round decides at least one; the number of rounds is the depth of the dependency chain
+      // (a handful), not the number of kept boxes.  Same keep set as the sequential greedy scan.
       unsigned long long alive = ~Ru & valid;
-      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
       unsigned long long kept_bits = 0;
       while (alive) {
-        const int j = __builtin_ctzll(alive);
-        kept_bits |= 1ull << j;
-        const unsigned long long d =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, j);
-        alive &= ~d & ~(1ull << j);
+        const bool me = (alive >> lane) & 1ull;
+        const unsigned long long K = __ballot(me && (curT & alive) == 0ull);
+        kept_bits |= K;
+        const unsigned long long gone = __ballot(me && (curT & K) != 0ull);
+        alive &= ~(K | gone);
       }
       const bool mine = (kept_bits >> lane) & 1ull;
       if (row < n) remover[row] = mine ? -1 : -2;      // -2: removed, the remover is resolved by nms_remover_kernel
       if (mine) kept[kc + __popcll(kept_bits & ((1ull << lane) - 1ull))] = row;
-      if (lane == 0) {
-        skeptbits[t] = kept_bits;
-        s_kc = kc + __popcll(kept_bits);
+      kc += __popcll(kept_bits);
+      if (lane == 0) skeptbits[t] = kept_bits;
+      curA = nextA;
+      curT = nextT;
+      kept_prev = kept_bits;
+    } else if (t >= 1) {
+      const unsigned long long kb = skeptbits[t - 1];   // written before the last barrier
+      if ((kb >> lane) & 1ull) {                        // only the kept rows of tile t-1 take part
+        const unsigned long long* rows = mask + (size_t)(t - 1) * 64 + lane;      // + u * NP: this row's word in column block u
+        for (int u = t + 1 + (wid - 1); u < words; u += 8 * NPUSH) {               // eight independent loads in flight, then LDS atomics
+          unsigned long long w[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) w[i] = (u + i * NPUSH < words) ? rows[(size_t)(u + i * NPUSH) * NP] : 0ull;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (w[i] != 0ull) atomicOr(&sR[u + i * NPUSH], w[i]);
+        }
       }
     }
     __syncthreads();
-    kc = s_kc;
   }
   if (tid == 0) {
     ((int*)(ws + L.misc))[1] = kc;
@@ -655,7 +771,8 @@ int launch_nms_common(int mode, const float* boxes, const float* scores, const l
   if (workspace_bytes < L.stride * (size_t)bs) return fail(MI355DET_EWORKSPACE, "%s: workspace too small (%lld needed)", "nms", (long long)(L.stride * bs));
   int npad = 64;
   while (npad < max_n) npad <<= 1;
-  const size_t lds = (size_t)npad * 8;
+  // bitonic: one 64-bit key per padded slot; radix (npad >= RADIX_MIN_N): u32 keys + u16 indices + the [16][1024] u16 count table
+  const size_t lds = npad >= RADIX_MIN_N ? (size_t)RADIX_CAP * 6 + (size_t)16 * SORT_THREADS * 2 : (size_t)npad * 8;
   if (mode == 0) {
     (void)hipFuncSetAttribute((const void*)nms_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(nms_sort_kernel<0>, dim3(bs), dim3(SORT_THREADS), lds, st, boxes, scores, idxs, count, n_fixed, max_n, (char*)workspace, L);
@@ -666,7 +783,7 @@ int launch_nms_common(int mode, const float* boxes, const float* scores, const l
   const int tiles = (max_n + 63) / 64;
   if (mode == 0) hipLaunchKernelGGL(nms_mask_kernel<0>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);
   else hipLaunchKernelGGL(nms_mask_kernel<1>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);
-  const size_t scan_lds = sizeof(unsigned long long) * (size_t)((max_n + 63) / 64);
+  const size_t scan_lds = 2 * sizeof(unsigned long long) * (size_t)L.words;      // kept bits per tile + removed bits per column block
   (void)hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(bs), dim3(SCAN_THREADS), scan_lds, st, (char*)workspace, L, out_count);
   if (mode == 0) hipLaunchKernelGGL(nms_remover_kernel, dim3((max_n + 255) / 256, bs), dim3(256), 0, st, (char*)workspace, L);

@@ -98,6 +98,17 @@ def test_nms_gpu(n):
     assert np.array_equal(keep, tv.nms(boxes, scores, 0.5))
 
 
+@pytest.mark.parametrize("n", [4097, 6000, 16384])
+def test_nms_many_equal_scores_radix_path(n):
+    """n >= 4096 takes the radix sort of nms_sort_kernel: scores quantised to 32 levels, so almost every box has equal-score neighbours and
+    the keep list depends on the tie order (descending score, lower index first)."""
+    from object_detectors_amd.tvision import boxes as B
+    boxes, scores = nms_inputs(4000 + n, n, extent=3000.0)
+    scores = (np.floor(scores * 32) / 32).astype(np.float32)
+    keep = B.nms(T(boxes), T(scores), 0.5).cpu().numpy()
+    assert np.array_equal(keep, tv.nms(boxes, scores, 0.5))
+
+
 @pytest.mark.parametrize("k", [1, 5, 90, 1203])
 def test_batched_nms_gpu(k):
     from object_detectors_amd.tvision import boxes as B
