@@ -816,10 +816,10 @@ unsigned long long igemm_key(const IgemmParams& p, int epi) {
 }
 
 // applicability of the dx-reuse kernel: 3x3, unit strides on both sides, taps in three rows of equal dy with dx stepping by +-1
-static bool dx_applicable(const IgemmParams& p, int bn = 128) {
+static bool dx_applicable(const IgemmParams& p, int bn = 128, int bk = 64) {
   if (p.T != 9 || p.so != 1 || p.sin != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
   if (p.Hin != p.Hout || p.Win != p.Wout || p.MH != p.Hin || p.MW != p.Win) return false;
-  if (p.Cin % 64 != 0 || p.CoutPad % bn != 0) return false;
+  if (p.Cin % bk != 0 || p.CoutPad % bn != 0) return false;
   for (int g = 0; g < 3; ++g) {
     if (p.dy[3 * g] != p.dy[3 * g + 1] || p.dy[3 * g] != p.dy[3 * g + 2]) return false;
     for (int i = 0; i < 3; ++i)
@@ -833,7 +833,7 @@ template <int WM, int WN, int TM, int TN, int EPI, int NSTB = 2, bool PROF = fal
 int launch_dx(const IgemmParams& p_in, hipStream_t st) {
   IgemmParams p = p_in;
   p.dbg = PROF ? g_dbg : nullptr;
-  if (!dx_applicable(p, WN * TN * 16)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
+  if (!dx_applicable(p, WN * TN * 16, BK)) return fail(MI355DET_EINVAL, "%s: shape not supported by the dx-reuse kernel", "igemm_dx");
   constexpr int NW = WM * WN, BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int R = 1024 / (BK * 2);
   constexpr int A_PER = (BM / R + 2 + NW - 1) / NW;
@@ -912,10 +912,11 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
   {
     auto it = g_igemm_tuned.find(igemm_key(p, EPI));
     if (it != g_igemm_tuned.end()) narrow = it->second;
-    if (g_tune == 29 || g_tune == 30) narrow = g_tune;
+    if (g_tune == 29 || g_tune == 30 || g_tune == 31) narrow = g_tune;
   }
   if (p.CoutPad % 64 == 0) {
     if (narrow == 30 && dx_applicable(p, 64)) return launch_dx<4, 1, 4, 4, EPI>(p, st);
+    if (narrow == 31 && dx_applicable(p, 64, 32)) return launch_dx<4, 1, 4, 4, EPI, 2, false, 32>(p, st);      // 32 input channels: k-step of 32
     return k64 ? launch_cfg<4, 1, 4, 4, 64, 2, EPI>(p, st) : launch_cfg<4, 1, 4, 4, 32, 3, EPI>(p, st);
   }
   if (p.CoutPad % 32 == 0) {
@@ -928,9 +929,10 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // plan-build helper: time the candidate configurations of one launch and remember the fastest
 template <int EPI>
 int autotune_igemm(const IgemmParams& p, hipStream_t st) {
-  if (p.CoutPad % 128 != 0 && p.Cin % 64 == 0 && (p.CoutPad % 64 == 0 ? dx_applicable(p, 64) : dx_applicable(p, 32))) {
-    // narrow output: plain tile (id 0) against the shared-pixel-tile kernel (id 30 / 29)
-    const int alt = p.CoutPad % 64 == 0 ? 30 : 29;
+  const bool narrow32 = p.CoutPad % 128 != 0 && p.CoutPad % 64 == 0 && p.Cin % 64 != 0 && dx_applicable(p, 64, 32);      // 32 -> 64 @320
+  if (narrow32 || (p.CoutPad % 128 != 0 && p.Cin % 64 == 0 && (p.CoutPad % 64 == 0 ? dx_applicable(p, 64) : dx_applicable(p, 32)))) {
+    // narrow output: plain tile (id 0) against the shared-pixel-tile kernel (id 30 / 29; 31 = its 32-deep k-step for 32 input channels)
+    const int alt = narrow32 ? 31 : (p.CoutPad % 64 == 0 ? 30 : 29);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
     float best_ms = 1e30f;

@@ -362,8 +362,9 @@ def test_dx_reuse_kernel_matches_default(case):
 
 @pytest.mark.parametrize("case", [(2, 24, 24, 64, 64), (2, 16, 20, 64, 32), (2, 12, 12, 32, 64), (1, 9, 7, 64, 64)])
 def test_narrow_output_shared_pixel_tile_kernels(case):
-    """256x64 / 256x32 shared-pixel-tile kernels (ids 30 / 29: the first Darknet layers and their data gradients) against the plain
-    narrow tiles: forward + statistics where cout is 32/64, data gradient where cin is 32/64."""
+    """256x64 / 256x32 shared-pixel-tile kernels (ids 30 / 29: the first Darknet layers and their data gradients; 31 = the 256x64 form with a
+    32-deep k-step for 32 input channels) against the plain narrow tiles: forward + statistics where cout is 32/64, data gradient where
+    cin is 32/64."""
     from object_detectors_amd import ops
     from object_detectors_amd._lib import lib
     n, h, w, cin, cout = case
@@ -376,12 +377,12 @@ def test_narrow_output_shared_pixel_tile_kernels(case):
     rows = ops.conv_stats_rows(shape)
     outs = {}
     try:
-        for cfg in (0, 29, 30):
+        for cfg in (0, 29, 30, 31):
             lib().mi355det_debug_set(0, cfg)
             y = torch.full((n, h, w, cout), 5.0, device=dev(), dtype=torch.bfloat16)
             stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())
             dx = torch.full((n, h, w, cin), 5.0, device=dev(), dtype=torch.bfloat16)
-            if cin % 64 == 0:
+            if cin % 64 == 0 or (cin == 32 and cout == 64):      # 31 applies to the 32 -> 64 forward only; elsewhere it falls back to the plain tile
                 ops.conv_fwd(shape, xd, wf, y, stats=stats)
             if cout % 64 == 0:              # the dgrad's reduction dimension
                 ops.conv_dgrad(shape, gyd, wd, dx)
@@ -390,14 +391,15 @@ def test_narrow_output_shared_pixel_tile_kernels(case):
     finally:
         lib().mi355det_debug_set(0, 0)
     y0, s0, d0 = outs[0]
-    for cfg in (29, 30):
+    for cfg in (29, 30, 31):
         y1, s1, d1 = outs[cfg]
         assert float((y1 - y0).abs().max()) <= 1e-2 * float(y0.abs().max()) + 1e-6, cfg
         assert float((d1 - d0).abs().max()) <= 1e-2 * float(d0.abs().max()) + 1e-6, cfg
         torch.testing.assert_close(s1, s0, rtol=2e-2, atol=2e-2 * float(s0.abs().max()) + 1e-6)
     ref = F.conv2d(x, wt, padding=1).permute(0, 2, 3, 1)
-    if cin % 64 == 0:
+    if cin % 64 == 0 or (cin == 32 and cout == 64):
         assert float((y0 - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+        assert float((outs[31][0] - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("case", [(3, 20, 12, 64, 128, 3, 1, 64, 128), (2, 24, 16, 32, 64, 3, 2, 48, 64), (2, 16, 16, 128, 72, 1, 1, 128, 80),
