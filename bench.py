@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (pure timing run)")
-    ap.add_argument("--event-steps", type=int, default=2,
+    ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps (spread evenly) in which every forward-conv launch is bracketed by HIP events; each event pair "
                          "costs ~6 us of serialisation, so bracketing all 75 launches in all steps would take ~2.5 %% off `value`")
     args = ap.parse_args()
