@@ -365,3 +365,60 @@ def test_dynamic_loss_scaler_skips_overflow_steps():
     v[1026] = 3.0e38
     check(lib().mi355det_grad_nonfinite(v.data_ptr(), v.numel(), flag.data_ptr(), torch.cuda.current_stream().cuda_stream), "grad_nonfinite")
     assert int(flag.item()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(), dict(class_loss=0, reduction="mean"), dict(class_loss=2, img_freq="synthetic")])
+def test_fused_step_with_loss_scale_and_criterion_options(opts):
+    """The amp usage pattern (optim.DynamicLossScaler docstring): engine.train_step(..., grad_scale=S) produces S x the gradients (S a power of
+    two: exact up to the rounding order of the atomics), the guarded step with grad_scale 1/S then equals the unscaled step; for every class-loss
+    form the fused bf16-gradient path agrees with loss.backward() through the modules."""
+    from object_detectors_amd.optim import DynamicLossScaler, FlatSGD
+    from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
+    from object_detectors_amd.yolo.nets.yolohead import YoloHead
+    from tests.helpers import synth_targets
+    opts = dict(opts)
+    if opts.get("img_freq") == "synthetic":
+        opts["img_freq"] = np.exp(detrand.uniform(91, (80,), -4.0, 2.0)).astype(np.float32)
+    cfg = {"backbone": {"backbone_name": "darknet_21", "backbone_pretrained": ""}, "dataset": {"anchors": ANCHORS}, "yolo": {"classes": 80}}
+    torch.manual_seed(3)
+    model = YoloHead(cfg).to(dev())
+    crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=128, **opts).to(dev())
+    x = torch.from_numpy(detrand.uniform(6, (2, 3, 128, 128), -2, 2)).to(dev())
+    tg = [{"bbox": torch.from_numpy(b).to(dev()), "category_id": torch.from_numpy(l).to(dev())} for b, l in synth_targets(78, (4, 6), 80)]
+    model.train()
+    eng = model.engine
+    # autograd through the modules vs the fused step
+    for p in model.parameters():
+        p.grad = None
+    loss, _sub, _stats = crit(model(x), tg)
+    loss.backward()
+    g_auto = eng.flat_g.clone()
+    out12 = eng.train_step(x, tg, crit)
+    g1 = eng.flat_g.clone()
+    np.testing.assert_allclose(out12[0].item(), loss.item(), rtol=1e-5)
+    cos = float((g_auto.double() * g1.double()).sum() / (g_auto.double().norm() * g1.double().norm()))
+    assert cos > 0.999, cos
+    # loss scale: gradients x 1024
+    S = 1024.0
+    out12s = eng.train_step(x, tg, crit, grad_scale=S)
+    gS = eng.flat_g.clone()
+    np.testing.assert_allclose(out12s[0].item(), out12[0].item(), rtol=1e-6)        # the reported loss is not scaled
+    rel = float((gS.double() / S - g1.double()).norm() / g1.double().norm())
+    assert rel < 2e-3, rel                                                          # power-of-two scale: only atomic-order noise
+    # the scaler's step with the scaled gradient == a plain step with the unscaled one
+    w0 = eng.flat_w.clone()
+    opt = FlatSGD.for_engine(eng, lr=1e-2, momentum=0.9)
+    scaler = DynamicLossScaler(init_scale=S)
+    assert scaler.step(opt) is True
+    w_scaled = eng.flat_w.clone()
+    eng.flat_w.copy_(w0)
+    eng.flat_g.copy_(g1)
+    FlatSGD.for_engine(eng, lr=1e-2, momentum=0.9).step()
+    assert float((eng.flat_w - w_scaled).abs().max()) <= 1e-2 * 2e-3 * float(g1.abs().max()) + 1e-9
+    # an overflowing gradient is skipped and halves the scale
+    eng.flat_g.copy_(gS)
+    eng.flat_g[123] = float("inf")
+    before = eng.flat_w.clone()
+    assert scaler.step(opt) is False and scaler.loss_scale == S / 2
+    assert torch.equal(eng.flat_w, before)
