@@ -36,6 +36,8 @@ struct SkParams {
   unsigned epoch;      // launch counter of this workspace (never 0)
   int nwg;
   unsigned long long* dbg;   // diagnostic: per-workgroup s_memrealtime stamps (mi355det_debug_ptr key 1), or null
+  int whole;           // 1: persistent workgroups over WHOLE tiles (contiguous tile ranges, no k-split, no slabs): the epilogue's stores of one
+                       // tile drain under the next tile's main loop and there is one launch + one prologue per workgroup instead of per tile
 };
 
 namespace {
@@ -78,8 +80,15 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   const int ntiles = ((p.M + kBM - 1) / kBM) * ntn;
   const unsigned U = (unsigned)ntiles * (unsigned)ksteps;          // U * nblk < 2^31 (checked by the host)
   unsigned u = SK ? (U * (unsigned)bid) / (unsigned)nblk : (unsigned)bid * (unsigned)ksteps;
-  const unsigned u_end = SK ? (U * (unsigned)(bid + 1)) / (unsigned)nblk : u + (unsigned)ksteps;
+  unsigned u_end_ = SK ? (U * (unsigned)(bid + 1)) / (unsigned)nblk : u + (unsigned)ksteps;
+  if (SK && sk.whole) {
+    u = (unsigned)(((unsigned)ntiles * (unsigned)bid) / (unsigned)nblk) * (unsigned)ksteps;
+    u_end_ = (unsigned)(((unsigned)ntiles * (unsigned)(bid + 1)) / (unsigned)nblk) * (unsigned)ksteps;
+  }
+  const unsigned u_end = u_end_;
 
+  unsigned long long pk_t0 = 0, pk_t1 = 0, pk_t2 = 0;
+  if (PROF == 2 && !SK) pk_t0 = __builtin_amdgcn_s_memrealtime();      // workgroup start (100 MHz)
   int stamp_i = 0;
   auto stamp = [&](int tag) {
     if (PROF == 1 && SK && sk.dbg && threadIdx.x == 0 && stamp_i < 15) {
@@ -303,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     constexpr bool PK = PROF == 2 && !SK;
     unsigned ph_sum[4] = {0, 0, 0, 0}, ph_cap[17], ph_prev = 0;      // low 32 bits of the counter: spans are far below 2^32 cycles
     unsigned long long ph_now = 0, ph_rt0 = 0, ph_rt1 = 0;
+    if (PROF == 2 && !SK) pk_t1 = __builtin_amdgcn_s_memrealtime();    // main loop starts (prologue loads issued and landed)
 #pragma unroll
     for (int i = 0; i < 17; ++i) ph_cap[i] = 0;
     const int ph_t = k0 + (PROF == 2 ? 4 : 6);
@@ -388,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       wrd ^= kSTAGE;
     }
 #undef PH_STAMP
+    if (PK) pk_t2 = __builtin_amdgcn_s_memrealtime();                  // main loop done
     if ((PH || PK) && sk.dbg && lane == 0 && bid < 64) {
       unsigned long long* d = sk.dbg + ((size_t)bid * 8 + wid) * 24;
 #pragma unroll
@@ -397,6 +408,11 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       for (int i = 0; i < 17; ++i) d[5 + i] = ph_cap[i];
       d[22] = ph_rt0;
       d[23] = ph_rt1;
+      if (PK) {
+        d[17] = pk_t0;
+        d[18] = pk_t1;
+        d[19] = pk_t2;
+      }
     }
     stamp(2);
     if (wm == 0) bar();             // re-align the two halves
@@ -421,6 +437,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       continue;
     }
     igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, 512, true, wm, wn, lane, mt, n0, m0);
+    if (PROF == 2 && !SK && sk.dbg && lane == 0 && bid < 64) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores have left
+      sk.dbg[((size_t)bid * 8 + wid) * 24 + 20] = __builtin_amdgcn_s_memrealtime();
+    }
     stamp(8);
     if (SK) {
       __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -459,9 +479,10 @@ int sk_workspace(hipStream_t st, SkWorkspace** out) {
 }
 
 template <int EPI>
-int launch8(const IgemmParams& p, hipStream_t st, bool streamk) {
+int launch8(const IgemmParams& p, hipStream_t st, bool streamk, bool whole) {
   const int gm = (p.M + kBM - 1) / kBM, gn = p.CoutPad / kBN;
   SkParams sk{};
+  sk.whole = whole ? 1 : 0;
   if (streamk) {
     SkWorkspace* w = nullptr;
     if (int e = sk_workspace(st, &w)) return e;
@@ -477,7 +498,7 @@ int launch8(const IgemmParams& p, hipStream_t st, bool streamk) {
       (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
       attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(kNWG), dim3(512), kLDS, st, p, sk);
+    hipLaunchKernelGGL(k, dim3(whole ? min(kNWG, gm * gn) : kNWG), dim3(512), kLDS, st, p, sk);
     return check_launch("igemm8_sk");
   }
   if (EPI == EPI_STATS && g_sk_dbg) {
@@ -530,13 +551,13 @@ void igemm8_set_dbg(unsigned long long* ptr) { g_sk_dbg = ptr; }
 void igemm8_set_dbg_mode(int mode) { g_sk_dbg_mode = mode; }
 
 // streamk: one persistent workgroup per CU over (tile, k-step) units instead of one workgroup per tile
-int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk) {
+int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk, bool whole) {
   if (!igemm8_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the phase-staggered kernel", "igemm8");
   switch (epi) {
-    case EPI_STATS: return launch8<EPI_STATS>(p, st, streamk);
-    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st, streamk);
-    case EPI_RES: return launch8<EPI_RES>(p, st, streamk);
-    case EPI_AFF: return launch8<EPI_AFF>(p, st, streamk);
+    case EPI_STATS: return launch8<EPI_STATS>(p, st, streamk, whole);
+    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st, streamk, whole);
+    case EPI_RES: return launch8<EPI_RES>(p, st, streamk, whole);
+    case EPI_AFF: return launch8<EPI_AFF>(p, st, streamk, whole);
     default: break;
   }
   return fail(MI355DET_EINVAL, "%s: epilogue not built for the phase-staggered kernel", "igemm8");

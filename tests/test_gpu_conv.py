@@ -552,7 +552,7 @@ def test_phase_staggered_kernel_matches_default(case):
     rows = ops.conv_stats_rows(shape)
     outs = {}
     try:
-        for cfg in (1, 40, 41):
+        for cfg in (1, 40, 41, 43):
             lib().mi355det_debug_set(0, cfg)
             y = torch.full((n, shape.ho, shape.wo, cout), 5.0, device=dev(), dtype=torch.bfloat16)
             stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())

@@ -56,6 +56,9 @@ for (n, h, w, cin, cout, k, s) in [(32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 51
           f"-> the MFMA peak at this clock is {2.5 * ghz.mean() / 2.4:.2f} PFLOP/s")
     print(f"   one stamp per k-step ({us_k:.1f} us): k-step period {per.mean():.0f} cycles (min {per.min()} max {per.max()}, median {np.median(per):.0f}); "
           f"a SIMD issues 2 x 64 MFMAs of 16 cycles = 2048 cycles per k-step -> MFMA pipe busy {100 * 2048 / per.mean():.0f} % inside the loop")
+    tt = dk[:, :, 17:21].astype(np.float64)[ok] / 100.0          # us: workgroup start, loop start, loop end, epilogue done (stores issued and acknowledged)
+    print(f"   per workgroup (us, mean over waves): prologue {np.mean(tt[:, 1] - tt[:, 0]):.2f} | main loop {np.mean(tt[:, 2] - tt[:, 1]):.2f} | "
+          f"epilogue incl. store acknowledgement {np.mean(tt[:, 3] - tt[:, 2]):.2f} (max {np.max(tt[:, 3] - tt[:, 2]):.2f})")
     off = (caps[:, 4:, 0] - caps[:, :4, 0])
     off = off[ok[:, 4:] & ok[:, :4]]
     print(f"   start of the same k-step, wave w+4 minus wave w (SIMD partners): mean {off.mean():.0f} cycles (min {off.min()} max {off.max()}) = "
