@@ -14,7 +14,7 @@ namespace {
 #define RADIX_CAP 16384        // = NMS_MAX_N
 
 struct NmsWs {   // per-image workspace carve (all offsets in bytes, 16-B aligned)
-  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, diagt, stride;
+  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, diagt, keptbits, stride;
   int words;
 };
 
@@ -31,6 +31,7 @@ __host__ __device__ inline NmsWs nms_layout(int max_n) {
   w.remover = o;    o = align16(o + sizeof(int) * (size_t)max_n);
   w.misc = o;       o = align16(o + 64);
   w.diagt = o;      o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64);   // transposed diagonal blocks: word j = earlier boxes of j's tile that drop j
+  w.keptbits = o;   o = align16(o + sizeof(unsigned long long) * (size_t)w.words);        // per tile: which of its 64 boxes the scan kept
   w.mask = o;       o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64 * w.words);   // [column block][row padded to 64]
   w.stride = o;
   return w;
@@ -340,7 +341,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(char* __restrict
       if (row < n) remover[row] = mine ? -1 : -2;      // -2: removed, the remover is resolved by nms_remover_kernel
       if (mine) kept[kc + __popcll(kept_bits & ((1ull << lane) - 1ull))] = row;
       kc += __popcll(kept_bits);
-      if (lane == 0) skeptbits[t] = kept_bits;
+      if (lane == 0) {
+        skeptbits[t] = kept_bits;
+        ((unsigned long long*)(ws + L.keptbits))[t] = kept_bits;
+      }
       curA = nextA;
       curT = nextT;
       kept_prev = kept_bits;
@@ -366,40 +370,51 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(char* __restrict
   }
 }
 
-// remover[c] = the first kept box (in keep order) whose mask row has bit c: the box that suppressed c (helper.py:355-368).
-// One thread per removed box; the 64 lanes of a wave share the mask word index, so each step is one broadcast load.
-__global__ __launch_bounds__(256) void nms_remover_kernel(char* __restrict__ ws_base, NmsWs L) {
+// remover[c] = the first kept box (in keep order = ascending sorted row) whose mask row has bit c: the box that suppressed c
+// (helper.py:355-368).  One workgroup per column block of 64 boxes; its 16 waves split the row tiles v <= w round-robin.  Per row tile a
+// wave reads the 64 row words of the column block in one coalesced load and walks the tile's KEPT rows in ascending order on the scalar
+// unit (readlane broadcast of the row's word, lane c tests its own bit); each lane keeps its first hit, an LDS min over the waves gives
+// the first kept row overall.  Work: (row tiles) x (kept rows per tile) scalar steps per wave instead of a walk over the whole kept
+// list per 64 boxes (1.16 ms -> ~20 us at n = 10 000).
+#define REMOVER_WAVES 16
+__global__ __launch_bounds__(REMOVER_WAVES* WAVE) void nms_remover_kernel(char* __restrict__ ws_base, NmsWs L) {
+  __shared__ int s_best[REMOVER_WAVES][WAVE];
   const int b = blockIdx.y;
   char* ws = ws_base + (size_t)b * L.stride;
   const int n = ((const int*)(ws + L.misc))[0];
-  const int kc = ((const int*)(ws + L.misc))[1];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if ((c & ~63) >= n) return;          // whole wave out of range
-  const unsigned long long* mask = (const unsigned long long*)(ws + L.mask);
-  const int* kept = (const int*)(ws + L.kept);
-  int* remover = (int*)(ws + L.remover);
-  const int w = c >> 6, bit = c & 63;
+  const int words = (n + 63) / 64;
+  const int w = blockIdx.x;
+  if (w >= words) return;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const size_t NP = (size_t)L.words * 64;
-  bool open = c < n && remover[c] == -2;
-  int found = -1;
-  for (int k0 = 0; k0 < kc; k0 += 4) {
-    if (!__any(open)) break;
-    int r[4];
-    unsigned long long m[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      r[q] = k0 + q < kc ? kept[k0 + q] : 0x7FFFFFFF;
-      m[q] = r[q] < (w + 1) * 64 ? mask[(size_t)w * NP + r[q]] : 0ull;   // rows beyond this column block cannot remove c
+  const unsigned long long* col = (const unsigned long long*)(ws + L.mask) + (size_t)w * NP;
+  const unsigned long long* keptbits = (const unsigned long long*)(ws + L.keptbits);
+  int* remover = (int*)(ws + L.remover);
+  const int c = w * 64 + lane;
+  const bool removed = c < n && remover[c] == -2;
+  int best = 0x7FFFFFFF;
+  for (int v = wid; v <= w; v += REMOVER_WAVES) {
+    if (!__any(removed && best == 0x7FFFFFFF)) break;
+    unsigned long long kb = keptbits[v];
+    if (kb == 0ull) continue;
+    const int row = v * 64 + lane;
+    const unsigned long long mine = row < n ? col[row] : 0ull;
+    const unsigned mlo = (unsigned)mine, mhi = (unsigned)(mine >> 32);
+    while (kb) {
+      const int i = __builtin_ctzll(kb);
+      kb &= kb - 1ull;
+      const unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)mlo, i);
+      if (((word >> lane) & 1ull) && best == 0x7FFFFFFF) best = v * 64 + i;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (open && r[q] < c && ((m[q] >> bit) & 1ull)) {
-        found = r[q];
-        open = false;
-      }
-    if (r[3] >= (w + 1) * 64) break;     // kept rows are ascending: nothing later can precede any column of this wave
   }
-  if (found >= 0) remover[c] = found;
+  s_best[wid][lane] = best;
+  __syncthreads();
+  if (wid == 0 && removed) {
+    int m = s_best[0][lane];
+#pragma unroll
+    for (int q = 1; q < REMOVER_WAVES; ++q) m = min(m, s_best[q][lane]);
+    remover[c] = m;
+  }
 }
 
 // ---- 4. majority vote + output (helper.py:369-375) --------------------------------------------
@@ -426,13 +441,22 @@ __global__ __launch_bounds__(VOTE_WAVES* WAVE) void nms_vote_kernel(const float*
     const int pos = kept[k];
     const float4 s = sbox[pos];
     int nvote = 0;
-    for (int j = pos + 1 + lane; j < n; j += WAVE) {
-      if (remover[j] == pos) {
-        const float v = nms_iou<0>(s, sbox[j]);
-        if (v > thr) {
-          const int c = scls[j];
-          if (c >= 0 && c < num_classes) atomicAdd(&hist[c], 1);
-          ++nvote;
+    // the boxes this one removed are among the set bits of its mask row: lanes run over the column blocks, each walks its word's bits
+    // (was: a scan of every later box for remover == pos)
+    const unsigned long long* mrow = (const unsigned long long*)(ws + L.mask) + pos;
+    const size_t NPm = (size_t)L.words * 64;
+    for (int u = (pos >> 6) + lane; u < (n + 63) / 64; u += WAVE) {
+      unsigned long long word = mrow[(size_t)u * NPm];
+      while (word) {
+        const int j = u * 64 + __builtin_ctzll(word);
+        word &= word - 1ull;
+        if (j < n && remover[j] == pos) {
+          const float v = nms_iou<0>(s, sbox[j]);
+          if (v > thr) {
+            const int c = scls[j];
+            if (c >= 0 && c < num_classes) atomicAdd(&hist[c], 1);
+            ++nvote;
+          }
         }
       }
     }
@@ -786,7 +810,7 @@ int launch_nms_common(int mode, const float* boxes, const float* scores, const l
   const size_t scan_lds = 2 * sizeof(unsigned long long) * (size_t)L.words;      // kept bits per tile + removed bits per column block
   (void)hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(bs), dim3(SCAN_THREADS), scan_lds, st, (char*)workspace, L, out_count);
-  if (mode == 0) hipLaunchKernelGGL(nms_remover_kernel, dim3((max_n + 255) / 256, bs), dim3(256), 0, st, (char*)workspace, L);
+  if (mode == 0) hipLaunchKernelGGL(nms_remover_kernel, dim3((max_n + 63) / 64, bs), dim3(REMOVER_WAVES * WAVE), 0, st, (char*)workspace, L);
   return 0;
 }
 
