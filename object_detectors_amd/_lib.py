@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355det.so")
+LIB_PATH = os.environ.get("MI355DET_LIB", os.path.join(HERE, "libmi355det.so"))      # the override serves same-box A/B runs of two builds
 
 MAX_SCALES, MAX_ANCHORS = 4, 8
 

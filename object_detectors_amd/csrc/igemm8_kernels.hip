@@ -53,6 +53,20 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+template <int PROF_>
+__device__ __forceinline__ void bar_b() {      // barrier in front of an MFMA segment (ablation 8 drops it)
+  if (PROF_ == 8) return;
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+template <int PROF_>
+__device__ __forceinline__ void bar_d() {      // barrier behind an MFMA segment (ablations 7 and 8 drop it)
+  if (PROF_ == 7 || PROF_ == 8) return;
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void bar() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     issue_x(s1, 0, 1);
     issue_w(s1, 0, 1);
     Slot s2 = next_slot();          // k0 + 2
-    wait_vm<8>();
+    wait_vm<6>();                   // X0, W0 and W1 of the first k-step: the leading half reads W1 before the lagging half's next counted wait
     bar();
     if (wm == 1) bar();             // the second pixel half runs one barrier behind
 
@@ -274,6 +288,38 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (wrd ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
     };
+    // fragment reads at (half, k-substep) granularity: 2 W tiles / 4 X tiles of 16 rows each; `nxt` addresses the other k-step buffer
+    auto rdw = [&](int h, int ks, bool nxt) {
+      if (PROF == 4) return;
+      const int base = nxt ? (wrd ^ kSTAGE) : wrd;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
+    };
+    auto rdx = [&](int h, int ks, bool nxt) {
+      if (PROF == 4) return;
+      const int base = nxt ? (xrd ^ kSTAGE) : xrd;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
+    };
+    // the 8 MFMAs of one (W half, X half, k-substep)
+    auto mf = [&](int hw, int hx, int ks) {
+      if (PROF == 5) return;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[hw * 2 + ii][hx * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj], 0, 0, 0);
+    };
+    // scheduling hint for a segment of `nm` MFMAs and `nr` independent fragment reads written before it: one read after each of the
+    // first MFMAs (a ds_read_b128 fits the 16-cycle shadow of an MFMA), the rest of the MFMAs behind
+#define IG8_INTERLEAVE(nm, nr)                                                     \
+  do {                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < (nr); ++q_) {                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+    }                                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, (nm) - (nr), 0);                  \
+  } while (0)
     auto mfma_q = [&](int hw, int hx) {
       if (PROF == 5) return;
       if (PROF == 6) {
@@ -327,6 +373,18 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       ph_prev = (unsigned)ph_now;                                                                               \
     }                                                                                                           \
   } while (0)
+    // The fragment reads live INSIDE the MFMA segments (a k-substep ahead of their use), not in the load segments: with the partner
+    // wave streaming MFMAs, every instruction of a load segment costs the wave ~16 cycles, and reads + LDS-DMA together made that
+    // segment longer than the 256 cycles of MFMAs it runs beside (ablation: the loop without its reads is MFMA-bound).  Order per k-step
+    // (quarters Q1 = W0 X0, Q2 = W1 X0, Q3 = W1 X1, Q4 = W0 X1; k0 / k1 = the two k-substeps):
+    //   phase 1: Q1k0 + reads W0k1, W1k0 | Q1k1 + reads W1k1        phase 2: Q2k0 + reads X1k0 | Q2k1 + reads X1k1
+    //   phase 3: Q3                                                    phase 4: Q4k0 + reads NEXT X0k0 | Q4k1 + reads NEXT W0k0, X0k1
+    // A fragment register set is re-loaded only after its last use, so at most 72 fragment VGPRs are live (64 before).  The reads of the
+    // leading half now come one barrier earlier than the lagging half's counted wait used to cover, hence the vmcnt(6) in front of every
+    // trailing barrier (the pieces of the last three phases may stay in flight); no region is read later than before.
+    rdw(0, 0, false);
+    rdx(0, 0, false);
+    rdx(0, 1, false);
     int buf = 0;
     for (int t = k0; t < k1; ++t) {
       PH_STAMP(-1, 0);
@@ -339,57 +397,82 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
         if (t == ph_t + 11) ph_rt1 = __builtin_amdgcn_s_memrealtime();
       }
       // ---- phase 1
-      read_w(0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_x(0);
       issue_w(s1, 1, buf ^ 1);
       PH_STAMP(0, 1);
       wait_vm<8>();
-      bar();
+      bar_b<PROF>();
       PH_STAMP(1, 2);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_q(0, 0);
+      __builtin_amdgcn_s_setprio(1);
+      rdw(0, 1, false);
+      rdw(1, 0, false);
+      mf(0, 0, 0);
+      IG8_INTERLEAVE(8, 4);
+      rdw(1, 1, false);
+      mf(0, 0, 1);
+      IG8_INTERLEAVE(8, 2);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 3);
-      bar();
+      wait_vm<6>();                 // the partner half reads, right after this barrier, fragments of tiles this wave helped to stage
+      bar_d<PROF>();
       PH_STAMP(3, 4);
       // ---- phase 2
-      read_w(1);
       issue_x(s1, 1, buf ^ 1);
       PH_STAMP(0, 5);
       wait_vm<8>();
-      bar();
+      bar_b<PROF>();
       PH_STAMP(1, 6);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_q(1, 0);
+      __builtin_amdgcn_s_setprio(1);
+      rdx(1, 0, false);
+      mf(1, 0, 0);
+      IG8_INTERLEAVE(8, 4);
+      rdx(1, 1, false);
+      mf(1, 0, 1);
+      IG8_INTERLEAVE(8, 4);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 7);
-      bar();
+      wait_vm<6>();                 // the partner half reads, right after this barrier, fragments of tiles this wave helped to stage
+      bar_d<PROF>();
       PH_STAMP(3, 8);
       // ---- phase 3
-      read_x(1);
       issue_x(s2, 0, buf);
       PH_STAMP(0, 9);
       wait_vm<8>();
-      bar();
+      bar_b<PROF>();
       PH_STAMP(1, 10);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_q(1, 1);
+      __builtin_amdgcn_s_setprio(1);
+      mf(1, 1, 0);
+      mf(1, 1, 1);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 11);
-      bar();
+      wait_vm<6>();                 // the partner half reads, right after this barrier, fragments of tiles this wave helped to stage
+      bar_d<PROF>();
       PH_STAMP(3, 12);
-      // ---- phase 4
+      // ---- phase 4 (its wait publishes W0 / X0 of the next k-step: their fragments are fetched here, from the other buffer)
       issue_w(s2, 0, buf);
       PH_STAMP(0, 13);
       wait_vm<8>();
-      bar();
+      bar_b<PROF>();
       PH_STAMP(1, 14);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_q(0, 1);
+      __builtin_amdgcn_s_setprio(1);
+      rdx(0, 0, true);
+      mf(0, 1, 0);
+      IG8_INTERLEAVE(8, 4);
+      rdw(0, 0, true);
+      rdx(0, 1, true);
+      mf(0, 1, 1);
+      IG8_INTERLEAVE(8, 6);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 15);
-      bar();
+      wait_vm<6>();                 // the partner half reads, right after this barrier, fragments of tiles this wave helped to stage
+      bar_d<PROF>();
       PH_STAMP(3, 16);
       s1 = s2;
       s2 = next_slot();
@@ -398,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       wrd ^= kSTAGE;
     }
 #undef PH_STAMP
+#undef IG8_INTERLEAVE
     if (PK) pk_t2 = __builtin_amdgcn_s_memrealtime();                  // main loop done
     if ((PH || PK) && sk.dbg && lane == 0 && bid < 64) {
       unsigned long long* d = sk.dbg + ((size_t)bid * 8 + wid) * 24;
@@ -517,11 +601,15 @@ int launch8(const IgemmParams& p, hipStream_t st, bool streamk, bool whole) {
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         attr_done_a = true;
       }
       if (g_sk_dbg_mode == 3) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 3>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       else if (g_sk_dbg_mode == 4) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 4>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       else if (g_sk_dbg_mode == 6) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 6>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 7) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 7>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 8) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 8>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 5>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       return check_launch("igemm8_ablation");
     }

@@ -5,7 +5,11 @@
 Per wave and k-step the loop has four phases, each (A) fragment reads + LDS-DMA issue, (B) counted vmcnt wait + barrier, (C) 16 MFMAs,
 (D) trailing barrier.  Waves 0-3 (pixel half 0) and 4-7 (pixel half 1) share the four SIMDs pairwise (wave w and w+4) and run one barrier
 apart, so one wave's (C) should coincide with its partner's (D)+(A)+(B).  The table prints the summed segments and the absolute stamps of one
-k-step for the two waves of SIMD 0 of a few workgroups."""
+k-step for the two waves of SIMD 0 of a few workgroups.
+
+The diagnostic builds add stamp state to a loop that sits at the 256-VGPR cap: with the committed loop (fragment reads between the MFMAs) they
+spill inside the loop and run 2-3x slower than the release build; the committed profile was taken on the loop form with the reads in the load
+segments (234 VGPRs), where the one-stamp build is within 5 % of the release build."""
 import os
 import sys
 
@@ -65,7 +69,8 @@ for (n, h, w, cin, cout, k, s) in [(32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 51
           f"{off.mean() / per.mean():.2f} of a k-step (1/8 = one barrier interval)")
     # ---- ablation builds: the same launch without the loop's LDS-DMA / fragment reads / MFMAs (garbage results, timing only)
     abl = {}
-    for mode, nm in ((3, "no LDS-DMA"), (4, "no fragment reads"), (5, "no MFMAs"), (6, "32x32x16 MFMAs (same FLOPs)")):
+    for mode, nm in ((3, "no LDS-DMA"), (4, "no fragment reads"), (5, "no MFMAs"), (6, "32x32x16 MFMAs (same FLOPs)"), (7, "no trailing barriers"),
+                     (8, "no barriers in the loop")):
         lib().mi355det_debug_set(3, mode)
         lib().mi355det_debug_ptr(1, dbg.data_ptr())
         abl[nm] = timed()
