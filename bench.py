@@ -2,7 +2,7 @@
 """Headline benchmark: images/sec of the YOLOv3 (Darknet-53) training step, forward + backward
 (+ gradient all-reduce when N > 1), 640x640 synthetic COCO-shaped batches, per-GPU batch 32.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps 10 --warmup 3          (N > 1: starts its own N ranks as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -109,6 +109,37 @@ def cpu_baseline(px, sample_bs=1, warmup=3, iters=10):
                       f"(oracle/net_oracle.py torch-CPU fp32 + oracle/yolo_oracle.py numpy criterion), median; {sum(times):.0f} s of CPU work"}
 
 
+def launch_ranks(n):
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process on a free local port,
+    relay its output (rank 0 prints the JSON line) and return its exit code: a failed rank makes the whole run fail."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(rank, world, mode):
+    """CPU rehearsal of the launcher path (tests/test_bench_launcher.py): every rank joins a gloo group and sums its rank; rank 0
+    prints one JSON line.  mode "fail": the last rank exits non-zero, which the launcher must report."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "n_gpus": world, "rank_sum": float(t.item())}), flush=True)
+    dist.destroy_process_group()
+    return 3 if (mode == "fail" and rank == world - 1) else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,14 +153,21 @@ def main():
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps (spread evenly) in which every forward-conv launch is bracketed by HIP events; each event pair "
                          "costs ~6 us of serialisation, so bracketing all 75 launches in all steps would take ~2.5 %% off `value`")
+    ap.add_argument("--launcher-selftest", choices=["ok", "fail"], default=None,
+                    help="no GPU work: only exercise the rank launcher and the process group (CPU test of `python bench.py --gpus N`)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process becomes the launcher (yolo/main.py:38-42 does the same with mp.spawn) - it has not
+        # touched the GPU, starts one fresh rank per GPU as CHILD processes and returns their exit code; nothing is re-exec'ed
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or run `python bench.py --gpus N`, which does)")
+    if args.launcher_selftest:
+        raise SystemExit(launcher_selftest(rank, world, args.launcher_selftest))
     # MI355DET_BENCH_ONE_GPU=1: rehearsal of the multi-process path on a one-GPU box (every rank on cuda:0, gloo instead of RCCL,
     # which refuses two ranks on one device); never used for reported numbers
     rehearsal = os.environ.get("MI355DET_BENCH_ONE_GPU", "0") == "1"
