@@ -201,14 +201,12 @@ def main():
     eng = YoloV3Engine("darknet_53", 3, 80, device=dev, seed=0)
     crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=args.px).to(dev)
     imgs, targets = synth_batch(args.batch, args.px, rank, dev)
-    sync = GradSync(eng.flat_g) if world > 1 else None
+    sync = GradSync(eng.flat_g).attach(eng) if world > 1 else None      # every plan the engine builds gets the bucket hooks
     # the reference's optimizer (yolo/hydra/optimizer/sgd.yaml: momentum 0.9, weight decay 5e-4) as one fused kernel over
     # the flat buffers; the step is inside the timed region (train_one_epoch.py:96)
     opt = FlatSGD.for_engine(eng, lr=args.lr, momentum=0.9, weight_decay=5e-4)
 
     def step():
-        if sync is not None:
-            sync.install(eng.plan(args.batch, args.px, args.px, True))
         out12 = eng.train_step(imgs, targets, crit)
         if sync is not None:
             sync.wait()

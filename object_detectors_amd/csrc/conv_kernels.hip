@@ -871,9 +871,7 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 54: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 4, EPI>(p, st); break;                                     // 128x128x32 ring 4 (64 KB, 2 workgroups/CU)
     case 55: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 3, EPI>(p, st); break;                                     // 128x128x64 ring 3 (96 KB, 1 workgroup/CU)
     case 56: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 6, EPI>(p, st); break;                                     // 128x128x32 ring 6 (96 KB)
-    case 40: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st, false); break;   // phase-staggered 256x256x64, 8 waves
-    case 43: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st, true, true); break;    // persistent workgroups over whole tiles (no k-split)
-    case 41: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st, true); break;    // the same as one persistent workgroup per CU (stream-K)
+    case 40: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st); break;   // phase-staggered 256x256x64, 8 waves
     case 15: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI>(p, st); break;             // 3x3 s1: shared pixel tiles (dx reuse), 128x128
     case 16: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI>(p, st); break;             // dx reuse 256x128, 8 waves, 1 workgroup/CU
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves

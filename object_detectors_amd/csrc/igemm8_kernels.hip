@@ -20,24 +20,13 @@
 // re-staging a half no earlier than two phases after its last read, which covers the one-barrier stagger).
 // Addressing, zero padding (out-of-range buffer offsets), swizzle and the epilogues are those of igemm_kernel.
 //
-// Stream-K form (SK = true): the big Darknet layers have 800 / 400 / 200 / 100 tiles on 256 CUs (3.1 / 1.6 / 0.8 / 0.4 rounds), so a
-// tile-per-workgroup grid idles 22-60 % of the chip in its last round.  One persistent workgroup per CU instead walks a contiguous
-// range of (tile, k-step) units, U / 256 each.  A range that starts inside a tile computes that tile's TAIL first and hands its fp32
-// accumulators over through a slab (write-through stores + flag, cdna_hip_programming.md Guideline 16 R1); the workgroup whose range
-// ENDS with the tile's head (k-step 0) adds the slabs of its successors - written at their very start, long before it asks - and
-// runs the epilogue.  At most one slab write and one tile finish per workgroup; sums are taken in a fixed order (deterministic).
+// Tile quantisation: the big Darknet layers have 800 / 400 / 200 tiles on 256 CUs.  A stream-K form of this kernel (one persistent
+// workgroup per CU over (tile, k-step) units, fp32 slab hand-off) and a persistent whole-tile form were built and measured in round 2
+// (profiles/r02_streamk_timeline.txt, r02_igemm8_persistent_whole_tiles.txt): slower on every YOLO shape, removed in round 3.
 #include "igemm_common.h"
 
-#include <unordered_map>
-
 struct SkParams {
-  float* slabs;        // [nwg][8 waves][32][64 lanes][4] fp32
-  unsigned* flags;     // [nwg] epoch of the last slab published by that workgroup, [nwg] = error word
-  unsigned epoch;      // launch counter of this workspace (never 0)
-  int nwg;
-  unsigned long long* dbg;   // diagnostic: per-workgroup s_memrealtime stamps (mi355det_debug_ptr key 1), or null
-  int whole;           // 1: persistent workgroups over WHOLE tiles (contiguous tile ranges, no k-split, no slabs): the epilogue's stores of one
-                       // tile drain under the next tile's main loop and there is one launch + one prologue per workgroup instead of per tile
+  unsigned long long* dbg;   // diagnostic builds: per-workgroup stamps (mi355det_debug_ptr key 1), or null
 };
 
 namespace {
@@ -73,7 +62,7 @@ __device__ __forceinline__ void bar() {
   asm volatile("" ::: "memory");
 }
 
-template <int EPI, bool SK, int PROF = 0>
+template <int EPI, int PROF = 0>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const SkParams sk) {
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,35 +71,19 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
   const int ntn = p.CoutPad / kBN, nblk = gridDim.x;
   int bid = blockIdx.x;
   {
-    // blocks b and b + 8 share an XCD: give each XCD a contiguous run of tiles / unit ranges (L2 reuse of pixel and weight tiles, and a
-    // finishing workgroup usually reads a slab written on its own XCD); bijective for any grid size
+    // blocks b and b + 8 share an XCD: give each XCD a contiguous run of tiles (L2 reuse of pixel and weight tiles); bijective for any grid size
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int Ktot = p.T * p.Cin;
   const int ksteps = Ktot / kBK, cin_steps = p.Cin / kBK;
 
-  // unit range of this workgroup: unit = tile * ksteps + k-step
-  const int ntiles = ((p.M + kBM - 1) / kBM) * ntn;
-  const unsigned U = (unsigned)ntiles * (unsigned)ksteps;          // U * nblk < 2^31 (checked by the host)
-  unsigned u = SK ? (U * (unsigned)bid) / (unsigned)nblk : (unsigned)bid * (unsigned)ksteps;
-  unsigned u_end_ = SK ? (U * (unsigned)(bid + 1)) / (unsigned)nblk : u + (unsigned)ksteps;
-  if (SK && sk.whole) {
-    u = (unsigned)(((unsigned)ntiles * (unsigned)bid) / (unsigned)nblk) * (unsigned)ksteps;
-    u_end_ = (unsigned)(((unsigned)ntiles * (unsigned)(bid + 1)) / (unsigned)nblk) * (unsigned)ksteps;
-  }
-  const unsigned u_end = u_end_;
+  constexpr bool SK = false;      // (the stream-K form is gone; the segment variables below keep its (tile, k0, k1) vocabulary)
+  unsigned u = (unsigned)bid * (unsigned)ksteps;
+  const unsigned u_end = u + (unsigned)ksteps;
 
   unsigned long long pk_t0 = 0, pk_t1 = 0, pk_t2 = 0;
   if (PROF == 2 && !SK) pk_t0 = __builtin_amdgcn_s_memrealtime();      // workgroup start (100 MHz)
-  int stamp_i = 0;
-  auto stamp = [&](int tag) {
-    if (PROF == 1 && SK && sk.dbg && threadIdx.x == 0 && stamp_i < 15) {
-      sk.dbg[(size_t)bid * 16 + stamp_i] = ((unsigned long long)tag << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00FFFFFFFFFFFFFFull);
-      ++stamp_i;
-    }
-  };
-  stamp(1);
   while (u < u_end) {
     const int tile = (int)(u / (unsigned)ksteps);
     const int k0 = (int)(u - (unsigned)tile * (unsigned)ksteps);
@@ -220,41 +193,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TM; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
-
-    if (SK && k0 == 0 && k1 < ksteps) {
-      // ---- head part of a tile whose other k-steps live at the START of the next workgroups' ranges: begin from the sum of their
-      //      slabs (published long before this workgroup reaches the last segment of its range) instead of zero, in rank order.
-      //      Done here, before the main loop, because nothing else is live yet: after the loop the accumulators and the epilogue's
-      //      temporaries leave no registers for 32 loads in flight.
-      int covered = k1, nxt = bid + 1;
-      while (covered < ksteps && nxt < nblk) {
-        const unsigned nu0 = (U * (unsigned)nxt) / (unsigned)nblk, nu1 = (U * (unsigned)(nxt + 1)) / (unsigned)nblk;
-        if (nu1 == nu0) {           // a workgroup without units publishes nothing
-          ++nxt;
-          continue;
-        }
-        if (wid == 0) {
-          unsigned spins = 0;
-          while (__hip_atomic_load(sk.flags + nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 22)) {       // ~seconds: the producer never ran; flag the launch instead of hanging
-              if (lane == 0) __hip_atomic_store(sk.flags + sk.nwg, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              break;
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const f32x4_t* sl = (const f32x4_t*)(sk.slabs + (size_t)nxt * (8 * 32 * 64 * 4)) + (size_t)wid * 32 * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int j = 0; j < TM; ++j) acc[i][j] += sl[(i * TM + j) * 64];
-        covered += min(ksteps - covered, (int)(nu1 - nu0));
-        ++nxt;
-      }
-    }
 
     // ---- prologue: X0(0) W0(0) W1(0) X1(0) X0(1) W0(1), the steady-state issue order
     Slot s1 = next_slot();          // k-step k0
@@ -498,126 +436,58 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
         d[19] = pk_t2;
       }
     }
-    stamp(2);
     if (wm == 0) bar();             // re-align the two halves
     wait_vm<0>();                   // the zero-fill pieces of the dead k-steps
     __builtin_amdgcn_s_waitcnt(0xC07F);
     bar();                          // the epilogue reuses smem
-    stamp(7);
 
-    if (SK && k0 > 0) {
-      // ---- tail part of a tile whose head belongs to an earlier workgroup: hand the accumulators over.  Write-through (sc1) stores,
-      //      every storing wave drains, one lane publishes the epoch
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sk.slabs + (size_t)bid * (8 * 32 * 64 * 4)), 0, 8 * 32 * 64 * 16, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, (wid * 32 * 64 + lane) * 16, (i * TM + j) * 1024, 16);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(sk.flags + bid, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      stamp(3);
-      continue;
-    }
     igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, 512, true, wm, wn, lane, mt, n0, m0);
     if (PROF == 2 && !SK && sk.dbg && lane == 0 && bid < 64) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores have left
       sk.dbg[((size_t)bid * 8 + wid) * 24 + 20] = __builtin_amdgcn_s_memrealtime();
     }
-    stamp(8);
-    if (SK) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      bar();                        // the next segment's LDS-DMA overwrites the epilogue's staging area
-    }
-    stamp(6);
   }
 }
 
-struct SkWorkspace {
-  float* slabs = nullptr;
-  unsigned* flags = nullptr;
-  unsigned epoch = 0;
-};
 unsigned long long* g_sk_dbg = nullptr;
 int g_sk_dbg_mode = 1;
-std::unordered_map<void*, SkWorkspace> g_sk_ws;       // per stream: launches on one stream are ordered, so they may share slabs
-constexpr int kNWG = 256;                             // one persistent workgroup per CU
-constexpr size_t kSlabFloats = 8 * 32 * 64 * 4;       // 256 KB of fp32 per workgroup
-
-int sk_workspace(hipStream_t st, SkWorkspace** out) {
-  auto it = g_sk_ws.find((void*)st);
-  if (it == g_sk_ws.end()) {
-    SkWorkspace w;
-    void* a = nullptr;
-    void* b = nullptr;
-    if (hipMalloc(&a, kNWG * kSlabFloats * sizeof(float)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMalloc(stream-K slabs) failed", "igemm8");
-    if (hipMalloc(&b, (kNWG + 16) * sizeof(unsigned)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMalloc(stream-K flags) failed", "igemm8");
-    if (hipMemset(b, 0, (kNWG + 16) * sizeof(unsigned)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: hipMemset(stream-K flags) failed", "igemm8");
-    w.slabs = (float*)a;
-    w.flags = (unsigned*)b;
-    it = g_sk_ws.emplace((void*)st, w).first;
-  }
-  *out = &it->second;
-  return 0;
-}
-
 template <int EPI>
-int launch8(const IgemmParams& p, hipStream_t st, bool streamk, bool whole) {
+int launch8(const IgemmParams& p, hipStream_t st) {
   const int gm = (p.M + kBM - 1) / kBM, gn = p.CoutPad / kBN;
   SkParams sk{};
-  sk.whole = whole ? 1 : 0;
-  if (streamk) {
-    SkWorkspace* w = nullptr;
-    if (int e = sk_workspace(st, &w)) return e;
-    if (++w->epoch == 0) w->epoch = 1;
-    sk.slabs = w->slabs;
-    sk.flags = w->flags;
-    sk.epoch = w->epoch;
-    sk.nwg = kNWG;
-    sk.dbg = g_sk_dbg;
-    auto k = igemm8_kernel<EPI, true>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(whole ? min(kNWG, gm * gn) : kNWG), dim3(512), kLDS, st, p, sk);
-    return check_launch("igemm8_sk");
-  }
   if (EPI == EPI_STATS && g_sk_dbg) {
     // diagnostic builds (tools/prof_ig8.py): [64 workgroups][8 waves][24] u64; mode 1 = phase stamps, 2 = k-step starts only
     sk.dbg = g_sk_dbg;
     static bool attr_done_p = false;
     if (!attr_done_p) {
-      (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-      (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+      (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+      (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
       attr_done_p = true;
     }
     if (g_sk_dbg_mode >= 3) {
       static bool attr_done_a = false;
       if (!attr_done_a) {
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         attr_done_a = true;
       }
-      if (g_sk_dbg_mode == 3) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 3>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
-      else if (g_sk_dbg_mode == 4) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 4>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
-      else if (g_sk_dbg_mode == 6) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 6>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
-      else if (g_sk_dbg_mode == 7) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 7>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
-      else if (g_sk_dbg_mode == 8) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 8>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
-      else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 5>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      if (g_sk_dbg_mode == 3) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 3>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 4) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 4>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 6) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 6>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 7) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 7>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else if (g_sk_dbg_mode == 8) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 8>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+      else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 5>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       return check_launch("igemm8_ablation");
     }
-    if (g_sk_dbg_mode == 2) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 2>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
-    else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, false, 1>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+    if (g_sk_dbg_mode == 2) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 2>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+    else hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 1>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
     return check_launch("igemm8_prof");
   }
-  auto k = igemm8_kernel<EPI, false>;
+  auto k = igemm8_kernel<EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
@@ -632,20 +502,19 @@ int launch8(const IgemmParams& p, hipStream_t st, bool streamk, bool whole) {
 bool igemm8_applicable(const IgemmParams& p) {
   if (!(p.CoutPad % kBN == 0 && p.Cin % kBK == 0 && p.T >= 1 && p.T <= MAX_TAPS)) return false;
   const long long units = (long long)((p.M + kBM - 1) / kBM) * (p.CoutPad / kBN) * (p.T * p.Cin / kBK);
-  return units * kNWG < (1ll << 31);      // 32-bit unit arithmetic in the kernel
+  return units < (1ll << 31);      // 32-bit unit arithmetic in the kernel
 }
 
 void igemm8_set_dbg(unsigned long long* ptr) { g_sk_dbg = ptr; }
 void igemm8_set_dbg_mode(int mode) { g_sk_dbg_mode = mode; }
 
-// streamk: one persistent workgroup per CU over (tile, k-step) units instead of one workgroup per tile
-int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk, bool whole) {
+int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st) {
   if (!igemm8_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the phase-staggered kernel", "igemm8");
   switch (epi) {
-    case EPI_STATS: return launch8<EPI_STATS>(p, st, streamk, whole);
-    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st, streamk, whole);
-    case EPI_RES: return launch8<EPI_RES>(p, st, streamk, whole);
-    case EPI_AFF: return launch8<EPI_AFF>(p, st, streamk, whole);
+    case EPI_STATS: return launch8<EPI_STATS>(p, st);
+    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st);
+    case EPI_RES: return launch8<EPI_RES>(p, st);
+    case EPI_AFF: return launch8<EPI_AFF>(p, st);
     default: break;
   }
   return fail(MI355DET_EINVAL, "%s: epilogue not built for the phase-staggered kernel", "igemm8");

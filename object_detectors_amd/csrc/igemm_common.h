@@ -60,7 +60,7 @@ enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4, EPI_
 
 // phase-staggered 256x256x64 kernel (igemm8_kernels.hip)
 bool igemm8_applicable(const IgemmParams& p);
-int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, bool streamk, bool whole = false);
+int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st);
 void igemm8_set_dbg(unsigned long long* ptr);
 void igemm8_set_dbg_mode(int mode);
 

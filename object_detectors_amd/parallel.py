@@ -49,20 +49,21 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.handles = []
-        self.side_stream = None
         backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self.use_avg = backend == "nccl"
         self.ordered = backend == "nccl"          # RCCL runs a group's collectives in issue order on its own stream; gloo's worker threads do not
         self.algo = algo
         self._shards = {}
 
-    def reduce_slice(self, lo, hi):
+    def reduce_slice(self, lo, hi, stream=None):
+        """stream: the side stream of the plan whose backward is running (bound into the hook by install(): every plan has its own,
+        and the collective must be ordered behind THAT plan's weight-gradient kernels)."""
         if self.world == 1:
             return
-        if self.side_stream is not None:
+        if stream is not None:
             # weight gradients are produced on the plan's side stream (which is ordered behind the BN-parameter gradients
             # of the same layers on the main stream): launch the collective from there
-            with torch.cuda.stream(self.side_stream):
+            with torch.cuda.stream(stream):
                 self._reduce(lo, hi)
         else:
             self._reduce(lo, hi)
@@ -90,6 +91,8 @@ class GradSync:
             h = dist.reduce_scatter_tensor(shard, t, op=op, group=self.group, async_op=True)
             if not self.ordered:
                 h.wait()
+            else:
+                self.handles.append((h, None))      # RCCL keeps issue order; the handle is still waited on in wait()
             self.handles.append((dist.all_gather_into_tensor(t, shard, group=self.group, async_op=True), None if self.use_avg else t))
         if n - main:
             t = self.flat[lo + main:hi]
@@ -102,23 +105,34 @@ class GradSync:
                 t.div_(self.world)
         self.handles = []
 
+    def attach(self, engine):
+        """Register with an engine: every training plan the engine builds from now on (one per input size - multi-scale training,
+        train_one_epoch.py:64-69 - and again after an LRU eviction) gets the bucket hooks, and so do the plans it already holds."""
+        syncs = engine.__dict__.setdefault("grad_syncs", [])
+        if self not in syncs:
+            syncs.append(self)
+        for plan in engine.plans.values():
+            if plan.training:
+                self.install(plan)
+        return self
+
     def install(self, plan):
-        """Weave bucket all-reduces into a training plan's backward call list."""
+        """Weave bucket all-reduces into a training plan's backward call list (idempotent per plan)."""
         from .yolo.nets.engine import comm_hook
         if getattr(plan, "_gradsync", None) is self:
             return
         buckets = plan_buckets(plan.bwd_marks, self.flat.numel(), self.bucket_elems)
+        base = plan.bwd_base if hasattr(plan, "bwd_base") else plan.bwd
+        stream = getattr(plan, "side_stream", None)
         calls, prev = [], 0
         for pos, lo, hi in buckets:
-            calls += plan.bwd_base[prev:pos] if hasattr(plan, "bwd_base") else plan.bwd[prev:pos]
-            calls.append((comm_hook, (self.reduce_slice, lo, hi)))
+            calls += base[prev:pos]
+            calls.append((comm_hook, (self.reduce_slice, lo, hi, stream)))
             prev = pos
-        base = plan.bwd_base if hasattr(plan, "bwd_base") else plan.bwd
         calls += base[prev:]
         plan.bwd_base = base
         plan.bwd = calls
         plan._gradsync = self
-        self.side_stream = getattr(plan, "side_stream", None)
         self.buckets = buckets
 
 
@@ -128,7 +142,7 @@ class ParamGradSync:
     gradients are produced by autograd before the engine's backward starts, so ONE flattened all-reduce right after `loss.backward()` runs
     under the whole backbone backward:
 
-        sync = GradSync(model.engine.flat_g); sync.install(plan)         # backbone + RPN
+        sync = GradSync(model.engine.flat_g).attach(model.engine)        # backbone + RPN, every plan
         hsync = ParamGradSync(model.head_parameters())                   # box head
         losses = model(images, targets); hsync.reduce(); sync.wait(); hsync.wait()
     """

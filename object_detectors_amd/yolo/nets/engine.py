@@ -290,6 +290,9 @@ class YoloV3Engine:
                 torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
                 self.plans.pop(next(iter(self.plans)))
             p = Plan(self, n, H, W, training, key[-1])
+            if training:
+                for gs in getattr(self, "grad_syncs", ()):       # parallel.GradSync.attach(): every plan gets the bucket hooks
+                    gs.install(p)
         self.plans[key] = p                                          # most recently used last
         return p
 

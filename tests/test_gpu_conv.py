@@ -552,7 +552,7 @@ def test_phase_staggered_kernel_matches_default(case):
     rows = ops.conv_stats_rows(shape)
     outs = {}
     try:
-        for cfg in (1, 40, 41, 43):
+        for cfg in (1, 40):
             lib().mi355det_debug_set(0, cfg)
             y = torch.full((n, shape.ho, shape.wo, cout), 5.0, device=dev(), dtype=torch.bfloat16)
             stats = torch.zeros((rows + 64, 2, ops.cout_pad_of(cout)), device=dev())
@@ -568,7 +568,7 @@ def test_phase_staggered_kernel_matches_default(case):
     yr = y_ref.detach().permute(0, 2, 3, 1)
     gr = xr.grad.permute(0, 2, 3, 1)
     y1, st1, dx1, dxr1 = outs[1]
-    for cfg in (40, 41):              # 41 = the same kernel as one persistent workgroup per CU over (tile, k-step) units (stream-K)
+    for cfg in (40,):
         y8, st8, dx8, dxr8 = outs[cfg]
         assert float((y8 - yr).abs().max()) <= 2e-2 * float(yr.abs().max()), cfg
         assert float((dx8 - gr).abs().max()) <= 2e-2 * float(gr.abs().max()), cfg

@@ -303,3 +303,65 @@ def test_two_rank_rccl_gradient_average_and_bit_identical_weights():
         assert nb >= 2, (rank, nb, err)
         assert err < 5e-3, (rank, err)            # mean of the per-rank gradients (BN-backward atomics: ~6e-4 run to run)
         assert same, rank                         # weights bit-identical across ranks after the optimizer steps
+
+
+def _worker_multiplan(rank, world, port, q):
+    """Multi-scale training (train_one_epoch.py:64-69) walks through more input sizes than the engine keeps plans (MAX_PLANS = 4): every
+    plan - also one rebuilt after an LRU eviction - must all-reduce on ITS side stream (parallel.py)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        from object_detectors_amd.parallel import GradSync
+        from object_detectors_amd.yolo.nets.engine import YoloV3Engine
+        from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
+        from tests.helpers import synth_targets
+        eng = YoloV3Engine("darknet_21", 3, 80, device=dev, seed=0)
+        sync = GradSync(eng.flat_g, bucket_mb=4).attach(eng)
+        tg = [{"bbox": torch.from_numpy(b).to(dev), "category_id": torch.from_numpy(l).to(dev)} for b, l in synth_targets(7 + rank, (3, 2), 80)]
+        sizes = [64, 96, 128, 160, 192, 64, 96]               # 5 distinct sizes > MAX_PLANS; 64 and 96 come back after their eviction
+        worst, hooks = 0.0, []
+        for i, px in enumerate(sizes):
+            crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=px).to(dev)
+            g = torch.Generator().manual_seed(1000 * rank + i)
+            x = torch.randn((2, 3, px, px), generator=g).to(dev)
+            eng.train_step(x, tg, crit)
+            sync.wait()
+            torch.cuda.synchronize()
+            got = eng.flat_g.clone()
+            plan = eng._last_plan
+            hooks.append(getattr(plan, "_gradsync", None) is sync)
+            saved, plan.bwd = plan.bwd, plan.bwd_base         # the same step without communication, then a manual average
+            eng.train_step(x, tg, crit)
+            plan.bwd = saved
+            torch.cuda.synchronize()
+            want = eng.flat_g.clone()
+            dist.all_reduce(want)
+            want /= world
+            worst = max(worst, float((got - want).abs().max()) / (float(want.abs().max()) + 1e-30))
+        q.put((rank, all(hooks), worst, len(eng.plans)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradsync_follows_every_plan_past_the_lru_limit():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 100
+    procs = [ctx.Process(target=_worker_multiplan, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, hooked, worst, nplans in res:
+        assert hooked, (rank, worst)
+        assert isinstance(worst, float) and worst < 5e-3, (rank, worst)      # BN-backward atomics: ~6e-4 run to run
+        assert nplans <= 4

@@ -83,3 +83,39 @@ def test_gradsync_world2_gloo(algo):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _r, ok, _h in res), res
+
+
+def test_gradsync_binds_each_plans_own_side_stream_and_attaches_to_engines():
+    """every plan has its own side stream; the bucket hook must launch on the stream of the plan whose backward is running,
+    and plans built later (another input size, an LRU rebuild) must get the hooks too."""
+    from object_detectors_amd.parallel import GradSync
+    from object_detectors_amd.yolo.nets.engine import comm_hook
+
+    class FakePlan:
+        training = True
+
+        def __init__(self, stream):
+            self.side_stream = stream
+            self.bwd = [((lambda: 0), ()) for _ in range(4)]
+            self.bwd_marks = [(k + 1, (3 - k) * 100) for k in range(4)]
+
+    class FakeEngine:
+        def __init__(self):
+            self.plans = {}
+
+    flat = torch.zeros(400)
+    sync = GradSync(flat, bucket_mb=200 * 4 / (1 << 20))
+    eng = FakeEngine()
+    a = FakePlan("stream-A")
+    eng.plans["a"] = a
+    sync.attach(eng)                                   # existing plans are hooked at attach time
+    assert eng.grad_syncs == [sync]
+    b = FakePlan("stream-B")
+    for gs in eng.grad_syncs:                          # what Engine.plan() does for a newly built plan
+        gs.install(b)
+    for plan, want in ((a, "stream-A"), (b, "stream-B")):
+        hooks = [args for fn, args in plan.bwd if fn is comm_hook]
+        assert len(hooks) == 2 and all(h[-1] == want for h in hooks), hooks
+        assert [h[1:3] for h in hooks] == [(200, 400), (0, 200)]
+    sync.install(a)                                    # idempotent
+    assert sum(1 for fn, _ in a.bwd if fn is comm_hook) == 2
