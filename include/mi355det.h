@@ -264,6 +264,29 @@ int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad);
  * (k=(kh*3+kw)*3+c, 27 valid) consumed by conv_fwd / conv_wgrad as a 1x1 convolution with cin=32. */
 int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int32_t w, void* stream);
 
+/* Darknet stem without a stored pre-BN tensor (darknet.py:41-43,74-76: conv1 -> bn1 -> LeakyReLU; csrc/stem_kernels.hip).  The 3->32 3x3
+ * convolution is recomputed from the fp32 NCHW image in every pass (K = 27: cheaper than one pass over the 32-channel tensor), so the
+ * step never writes z, the im2col matrix or dz of this layer.  w = packed forward weights [32][32] bf16, k = (kh*3+kw)*3 + c
+ * (mi355det_pack_weights of the [32, 32] "1x1" master the engine keeps).  Needs h % 8 == 0 and w % 32 == 0 (MI355DET_EINVAL otherwise).
+ *   stem_rows            number of partial rows the kernels write (one per persistent workgroup); allocate rows + 64 for
+ *                        bn_finalize / bn_bwd_sum_partials, rows * 1024 floats for the wgrad slab
+ *   stem_fwd_stats       partial[rows][2][32]: per-channel sum z, sum z*z (fp32 z)            -> mi355det_bn_finalize
+ *   stem_fwd_apply       a = lrelu(z*scale + shift) as bf16 NHWC (pitch a_ld); training AND eval (scale_shift from
+ *                        mi355det_bn_finalize or mi355det_bn_eval_scale_shift)
+ *   stem_bwd_reduce      partial[rows][2][32]: sum dy, sum dy*xhat, dy = da * lrelu'(z*scale+shift) -> mi355det_bn_bwd_sum_partials
+ *   stem_bwd_apply_wgrad dz = scale*(dy - mean dy - xhat*mean(dy*xhat)) feeds the weight-gradient MFMA directly:
+ *                        dw[32][32] += dz^T * im2col (fixed order via slab[rows][1024]); dgamma += sums[32..63], dbeta += sums[0..31]
+ * All four are fixed-order (bit-reproducible). */
+int mi355det_stem_rows(int32_t n, int32_t h, int32_t w);
+int mi355det_stem_fwd_stats(const float* img, const void* w, float* partial, int32_t n, int32_t h, int32_t wd, void* stream);
+int mi355det_stem_fwd_apply(const float* img, const void* w, const float* scale_shift, float slope, void* a, int32_t a_ld,
+                            int32_t n, int32_t h, int32_t wd, void* stream);
+int mi355det_stem_bwd_reduce(const float* img, const void* w, const float* scale_shift, float slope, const void* da,
+                             int32_t da_ld, float* partial, int32_t n, int32_t h, int32_t wd, void* stream);
+int mi355det_stem_bwd_apply_wgrad(const float* img, const void* w, const float* scale_shift, const float* sums, float slope,
+                                  const void* da, int32_t da_ld, float* slab, float* dw, float* dgamma, float* dbeta,
+                                  int32_t n, int32_t h, int32_t wd, void* stream);
+
 /* Data gradient: dx = conv_transpose(dy, w); wt packed for dgrad by mi355det_pack_weights.
  * residual != NULL adds a bf16 tensor (same shape as dx) in the epilogue (residual-block skip). */
 int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx,

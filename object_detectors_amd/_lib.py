@@ -88,6 +88,11 @@ PROTOTYPES = {
     "mi355det_conv_autotune_mode": (C.c_int, [C.c_int]),
     "mi355det_conv_stats_rows": (C.c_int, [P(ConvShape), i32]),
     "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "mi355det_stem_rows": (C.c_int, [i32, i32, i32]),
+    "mi355det_stem_fwd_stats": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "mi355det_stem_fwd_apply": (C.c_int, [vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]),
+    "mi355det_stem_bwd_reduce": (C.c_int, [vp, vp, vp, f32, vp, i32, vp, i32, i32, i32, vp]),
+    "mi355det_stem_bwd_apply_wgrad": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "mi355det_bn_eval_scale_shift": (C.c_int, [i32, vp, vp, vp, vp, f32, vp, vp]),
     "mi355det_conv_dgrad_bn_rows": (C.c_int, [P(ConvShape)]),

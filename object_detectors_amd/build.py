@@ -30,6 +30,7 @@ SOURCES = [
     ("wgrad_kernels.hip", []),
     ("dgrad_s2_kernels.hip", []),
     ("elem_kernels.hip", []),
+    ("stem_kernels.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-x", "hip"]
 

@@ -353,7 +353,6 @@ class Plan:
         g5, g4, g3 = (H // 32, W // 32), (H // 16, W // 16), (H // 8, W // 8)
         self.cat1 = new_act(n, g4[0], g4[1], 768)
         self.cat2 = new_act(n, g3[0], g3[1], 384)
-        self.col = new_act(n, H, W, 32)
         self.heads = [torch.zeros((n, g[0], g[1], eng.head_ld), device=dev, dtype=torch.float32) for g in (g5, g4, g3)]
         self.head_grads = [torch.zeros((n, g[0], g[1], eng.head_ld), device=dev, dtype=bf) for g in (g5, g4, g3)]
         self.ops = []   # forward-ordered op records for the backward builder
@@ -443,10 +442,9 @@ class Plan:
                                                    None, cp, self.stream)))
             self.ops.append(dict(kind="out", name=name, spec=s, shp=shp, shp_f=shp_f, x=x, k=k))
 
-        # stem (darknet.py:74-76) as im2col + 1x1
-        self.img_call = len(self.fwd)
-        self.fwd.append((L.mi355det_stem_im2col, [None, self.col.ptr, n, H, W, self.stream]))
-        x = conv_bn("backbone.conv1", self.col)
+        # stem (darknet.py:41-43,74-76): recompute kernels straight from the fp32 image, no stored z / im2col matrix (csrc/stem_kernels.hip)
+        self.img_args = []       # argument lists whose first entry is the image pointer of the current step
+        x = self._stem(n, H, W, new_act, sync_sum)
         feats = {}
         for li, nb in enumerate(BLOCKS[eng.backbone], 1):
             p = f"backbone.layer{li}"
@@ -503,6 +501,48 @@ class Plan:
             self._build_backward()
             self._autotune()
 
+    def _stem(self, n, H, W, new_act, sync_sum):
+        eng, L, dev = self.eng, lib(), self.eng.device
+        name, b = "backbone.conv1", "backbone.bn1"
+        s = eng.by_name[name]
+        wf, _ = eng.packed[name]
+        a = new_act(n, H, W, 32)
+        pixels = n * H * W
+        rows = L.mi355det_stem_rows(n, H, W)
+        if rows <= 0:
+            raise ValueError("stem kernels need H % 8 == 0 and W % 32 == 0")
+        ss = torch.zeros(4 * 32, device=dev, dtype=torch.float32)
+        self.keep += [ss]
+
+        def img_call(fn, args):
+            args = [None] + list(args)
+            self.img_args.append(args)
+            return (fn, args)
+        if not self.training:
+            self.fwd.append((L.mi355det_bn_eval_scale_shift, (32, _vp(eng.params[b + ".weight"]), _vp(eng.params[b + ".bias"]),
+                                                              _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
+                                                              BN_EPS, _vp(ss), self.stream)))
+        else:
+            part = torch.zeros((rows + 64, 2, 32), device=dev, dtype=torch.float32)
+            self.keep.append(part)
+            self.fwd.append(img_call(L.mi355det_stem_fwd_stats, (_vp(wf), _vp(part), n, H, W, self.stream)))
+            fin = (_vp(eng.params[b + ".weight"]), _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM, _vp(eng.buffers[b + ".running_mean"]),
+                   _vp(eng.buffers[b + ".running_var"]), _vp(ss), self.stream)
+            if self.sync_world > 1:
+                row = torch.zeros((1, 2, 32), device=dev, dtype=torch.float32)
+                self.keep.append(row)
+                self.fwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), rows, 32, 32, _vp(row), self.stream)))
+                self.fwd.append((comm_hook, (sync_sum, row)))
+                self.fwd.append((L.mi355det_bn_finalize, (_vp(row), 1, 32, 32, pixels * self.sync_world) + fin))
+            else:
+                self.fwd.append((L.mi355det_bn_finalize, (_vp(part), rows, 32, 32, pixels) + fin))
+        self.fwd.append(img_call(L.mi355det_stem_fwd_apply, (_vp(wf), _vp(ss), SLOPE, a.ptr, a.ld, n, H, W, self.stream)))
+        rec = dict(kind="stem", name=name, spec=s, x=None, a=a, res=None, z=None, ss=ss, pixels=pixels, rows=rows, img_call=img_call)
+        a.producer = rec
+        self.ops.append(rec)
+        self.layers[name] = rec
+        return a
+
     # ------------------------------------------------------------------
     def _build_backward(self):
         eng, L, dev = self.eng, lib(), self.eng.device
@@ -528,7 +568,7 @@ class Plan:
                       for r in self.ops if r["kind"] in ("cbl", "out"))
         self.wgrad_ws = torch.empty(max(ws_need, 16), device=dev, dtype=torch.uint8)
         ws_ptr, ws_bytes = _vp(self.wgrad_ws), self.wgrad_ws.numel()
-        nsum = sum(2 * r["shp"].cout for r in self.ops if r["kind"] == "cbl")
+        nsum = sum(2 * r["shp"].cout for r in self.ops if r["kind"] == "cbl") + 64
         self.sums_all = torch.zeros(nsum, device=dev, dtype=torch.float32)
         sum_off = [0]
 
@@ -548,7 +588,7 @@ class Plan:
                 prod = getattr(x, "producer", None)
                 # this dgrad writes the COMPLETE gradient of a BN+LeakyReLU activation (single conv consumer, at most one skip,
                 # fused as the epilogue residual): start that layer's BatchNorm backward here, while the tile is on chip
-                if prod is not None and x.conv_consumers == 1 and not x.skips and self.fuse_bn_reduce:
+                if prod is not None and prod.get("z") is not None and x.conv_consumers == 1 and not x.skips and self.fuse_bn_reduce:
                     rows = L.mi355det_conv_dgrad_bn_rows(C.byref(shp))
                     cpad = ops.pad_to(x.c, 32)
                     part = torch.zeros((rows + 64, 2, cpad), device=dev, dtype=torch.float32)
@@ -568,9 +608,32 @@ class Plan:
         self.bwd_marks = []      # (index into self.bwd after the layer's calls, lowest flat_g offset completed)
         first_off = {name: o for name, o, _n, _s in eng.param_order}
         for rec in reversed(self.ops):
-            if rec["kind"] in ("out", "cbl"):
+            if rec["kind"] in ("out", "cbl", "stem"):
                 self._mark_name = rec["name"]
-            if rec["kind"] == "out":
+            if rec["kind"] == "stem":
+                # BatchNorm backward + weight gradient of the stem from the image and the activation gradient alone: z and dz are
+                # recomputed in registers (two passes: the per-channel sums, then dz straight into the weight-gradient MFMA)
+                name, a, ss, rows, img_call = rec["name"], rec["a"], rec["ss"], rec["rows"], rec["img_call"]
+                assert a.grad is not None and a.grad_written and not a.skips, name
+                g, b = a.grad, bn_name(name)
+                wf, _ = eng.packed[name]
+                sums = self.sums_all[sum_off[0]:sum_off[0] + 64]
+                sum_off[0] += 64
+                part = torch.zeros((rows + 64, 2, 32), device=dev, dtype=torch.float32)
+                slab = torch.zeros((rows, 1024), device=dev, dtype=torch.float32)
+                self.keep += [part, slab]
+                self.bwd.append(img_call(L.mi355det_stem_bwd_reduce, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(part), self.n, self.H, self.W,
+                                                                      self.stream)))
+                self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), rows, 32, 32, _vp(sums), self.stream)))
+                if self.sync_world > 1:
+                    py(self._sync_avg, sums)
+                self.bwd.append(img_call(L.mi355det_stem_bwd_apply_wgrad, (_vp(wf), _vp(ss), _vp(sums), SLOPE, g.ptr, g.ld, _vp(slab),
+                                                                           _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
+                                                                           _vp(eng.grads[b + ".bias"]), self.n, self.H, self.W, self.stream)))
+                ev_stem = torch.cuda.Event()
+                py(ev_stem.record, main)                  # the stem's gradients come from the main stream: the side stream (last
+                py(self.side.wait_event, ev_stem)         # gradient bucket) must see them
+            elif rec["kind"] == "out":
                 shp, shp_f, x, k, name = rec["shp"], rec["shp_f"], rec["x"], rec["k"], rec["name"]
                 _, wd = eng.packed[name]
                 dy = _vp(self.head_grads[k])
@@ -621,10 +684,9 @@ class Plan:
                                                          ws_ptr, ws_bytes, side_ptr)))
                 py(ev_wg.record, self.side)
                 wg_done[di] = ev_wg
-                if name != "backbone.conv1":
-                    _, wd = eng.packed[name]
-                    emit_dgrad(shp, _vp(dzb), wd, x)
-            if rec["kind"] in ("out", "cbl"):
+                _, wd = eng.packed[name]
+                emit_dgrad(shp, _vp(dzb), wd, x)
+            if rec["kind"] in ("out", "cbl", "stem"):
                 self.bwd_marks.append((len(self.bwd), first_off[rec["name"] + ".weight"]))
         ev_end = torch.cuda.Event()
         py(ev_end.record, self.side)
@@ -637,7 +699,7 @@ class Plan:
         eng, L = self.eng, lib()
         saved = {k: v.clone() for k, v in eng.buffers.items()}
         img = torch.randn((self.n, 3, self.H, self.W), device=eng.device)
-        self.fwd[self.img_call][1][0] = C.c_void_p(img.data_ptr())
+        self._set_image(img)
         for g in self.head_grads:
             g.normal_(0, 1e-2)
         L.mi355det_conv_autotune_mode(1)
@@ -675,9 +737,15 @@ class Plan:
             if st != 0:
                 check(st, fn.__name__)
 
-    def run_forward(self, images):
+    def _set_image(self, images):
+        """The stem kernels of BOTH directions read the fp32 image: it stays referenced until the next forward."""
         self._img = images
-        self.fwd[self.img_call][1][0] = C.c_void_p(images.data_ptr())
+        ptr = C.c_void_p(images.data_ptr())
+        for a in self.img_args:
+            a[0] = ptr
+
+    def run_forward(self, images):
+        self._set_image(images)
         self._run(self.pack)
         self._run(self.fwd)
         if self.training:

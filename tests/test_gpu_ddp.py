@@ -173,8 +173,8 @@ def _worker_syncbn(rank, world, port, q):
         # sharp check of the BACKWARD exchange, independent of rounding noise: BatchNorm's input gradient sums to zero per channel over the
         # batch the statistics were taken from - the GLOBAL batch here, so the per-rank sums are non-zero and cancel across ranks
         plan = eng._last_plan
-        rec = plan.layers["backbone.conv1"]
-        dz = plan.dz2[rec["dz_index"]][:rec["pixels"] * 32].view(-1, 32).float()
+        rec = plan.layers["backbone.layer1.ds_conv"]        # the last layer of backward that goes through a dz buffer (the stem fuses dz away)
+        dz = plan.dz2[rec["dz_index"]][:rec["pixels"] * 64].view(-1, 64).float()
         local = dz.sum(0)
         glob = local.clone()
         dist.all_reduce(glob)

@@ -78,8 +78,9 @@ def test_engine_local_parity_and_wiring(bname, px, bs):
             assert torch.equal(view(cat)[:, :c_up], up)
             continue
         s, xa, name = rec["spec"], rec["x"], rec["name"]
-        acts[id(xa)] = xa
-        xin = view(xa).requires_grad_(True)
+        if xa is not None:              # the stem reads the image, not an activation
+            acts[id(xa)] = xa
+            xin = view(xa).requires_grad_(True)
         if rec["kind"] == "out":
             k = rec["k"]
             w = bf16q(sd[name + ".weight"]).requires_grad_(True)
@@ -95,10 +96,13 @@ def test_engine_local_parity_and_wiring(bname, px, bs):
             continue
         a, b = rec["a"], bn_name(name)
         # ---- forward: z = conv(x), a = lrelu(bn(z)) (+res) on the engine's own operands
-        zg = rec["z"].float().permute(0, 3, 1, 2).cpu()
         if name == "backbone.conv1":
+            # the stem never stores z (csrc/stem_kernels.hip recomputes it from the image in every pass): the reference z stands in
             zz = F.conv2d(bf16q(torch.from_numpy(x)), bf16q(sd[name + ".weight"]), padding=1)
+            assert rec["z"] is None
+            zg = zz
         else:
+            zg = rec["z"].float().permute(0, 3, 1, 2).cpu()
             zz = F.conv2d(xin.detach(), bf16q(sd[name + ".weight"]), stride=s.stride, padding=(s.k - 1) // 2)
         if (zg - zz).abs().max() > 1e-2 * zz.abs().max():
             bad.append((name, "z", float((zg - zz).abs().max() / zz.abs().max())))
@@ -130,8 +134,6 @@ def test_engine_local_parity_and_wiring(bname, px, bs):
     # ---- wiring: every activation gradient == sum of its consumers' contributions
     for key, exp in contrib.items():
         act = acts[key]
-        if act is plan.col:
-            continue
         g = view(act.grad)
         if rel(g, exp) > 3e-2:
             bad.append(("grad-sum", act.c, act.h, rel(g, exp)))

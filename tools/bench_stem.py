@@ -1,0 +1,54 @@
+"""Isolated timing of the four stem recompute kernels (csrc/stem_kernels.hip) at the BASELINE size, with their HBM floors.
+    python tools/bench_stem.py [batch] [px]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detectors_amd._lib import check, lib  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+px = int(sys.argv[2]) if len(sys.argv) > 2 else 640
+dev = torch.device("cuda:0")
+L = lib()
+vp = lambda t: C.c_void_p(t.data_ptr())
+img = torch.randn((n, 3, px, px), device=dev)
+wp = torch.zeros((32, 32), dtype=torch.bfloat16, device=dev)
+wp[:, :27] = (torch.randn((32, 27), device=dev) * 0.27).bfloat16()
+rows = L.mi355det_stem_rows(n, px, px)
+part = torch.zeros((rows + 64, 2, 32), device=dev)
+ss = torch.zeros(128, device=dev)
+gam, bet = torch.ones(32, device=dev), torch.zeros(32, device=dev)
+rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+a = torch.empty((n, px, px, 32), dtype=torch.bfloat16, device=dev)
+da = (torch.randn((n, px, px, 32), device=dev) * 0.05).bfloat16()
+sums = torch.zeros(64, device=dev)
+slab = torch.zeros((rows, 1024), device=dev)
+dw, dg, db = torch.zeros((32, 32), device=dev), torch.zeros(32, device=dev), torch.zeros(32, device=dev)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+pix = n * px * px
+calls = {
+    "stem_fwd_stats": (lambda: L.mi355det_stem_fwd_stats(vp(img), vp(wp), vp(part), n, px, px, st), pix * 12),
+    "bn_finalize": (lambda: L.mi355det_bn_finalize(vp(part), rows, 32, 32, pix, vp(gam), vp(bet), 1e-5, 0.1, vp(rm), vp(rv), vp(ss), st), 0),
+    "stem_fwd_apply": (lambda: L.mi355det_stem_fwd_apply(vp(img), vp(wp), vp(ss), 0.1, vp(a), 32, n, px, px, st), pix * (12 + 64)),
+    "stem_bwd_reduce": (lambda: L.mi355det_stem_bwd_reduce(vp(img), vp(wp), vp(ss), 0.1, vp(da), 32, vp(part), n, px, px, st), pix * (12 + 64)),
+    "bn_bwd_sum_partials": (lambda: L.mi355det_bn_bwd_sum_partials(vp(part), rows, 32, 32, vp(sums), st), 0),
+    "stem_bwd_apply_wgrad": (lambda: L.mi355det_stem_bwd_apply_wgrad(vp(img), vp(wp), vp(ss), vp(sums), 0.1, vp(da), 32, vp(slab), vp(dw), vp(dg),
+                                                                    vp(db), n, px, px, st), pix * (12 + 64)),
+}
+for name, (fn, nbytes) in calls.items():
+    check(fn(), name)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 10 * 1e3)
+    floor = nbytes / 6.3e12 * 1e6
+    print(f"{name:24s} {best:8.1f} us   algorithmic {nbytes / 1e6:8.1f} MB   floor@6.3TB/s {floor:6.1f} us   {nbytes / best / 1e6:6.2f} TB/s", flush=True)
