@@ -19,6 +19,8 @@
 // while the current one is computed.  Everything is fixed-order (bit-reproducible), unlike the atomics of bn_act_bwd_reduce.
 #include "common.h"
 
+#include <type_traits>
+
 using namespace mi355;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -33,7 +35,8 @@ constexpr int HR = TH + 2, HC = TW + 2;    // halo tile
 constexpr int P = 36;                      // LDS row pitch of the halo tile (bf16 elements)
 constexpr int IMG_ELEMS = 3 * HR * P;      // 1080
 constexpr int ZBASE = IMG_ELEMS * 2;        // 128 zero bytes behind the halo tile: the padded k columns 27..31 read them at every fragment offset
-constexpr int IMG_BYTES = ZBASE + 128;
+constexpr int DUMP = ZBASE + 128;           // where the surplus lanes of the halo fetch (1020 values on 1024 lanes) put their value
+constexpr int IMG_BYTES = DUMP + 16;
 static_assert(ZBASE % 16 == 0 && (P + 16) * 2 + 2 <= 128 && (P + 7) * 2 + 2 <= 128, "zero slot covers every fragment offset");
 constexpr int HALO = 3 * HR * HC;          // 1020 values to fetch per tile
 constexpr int PER_T = (HALO + 255) / 256;  // 4 per thread
@@ -49,6 +52,7 @@ struct StemParams {
   float* partial;         // MODE 0 / 2: [grid][2][32]; MODE 3: slab [grid][32][32]
   int ld;
   int n, H, W, tiles_x, tiles_y, ntiles;
+  int rows_total;         // rows the caller allocated (mi355det_stem_rows): the rows beyond this launch's grid are zero-filled
   float slope, inv_count;
 };
 
@@ -135,16 +139,22 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
   }
   char* const dzt = smem + 2 * IMG_BYTES + wid * DZ_WAVE;
 
-  // ---- halo fetch roles: element e of the [3][HR][HC] halo -> LDS element offset (or -1) and its (row, column)
-  int h_lds[PER_T], h_rx[PER_T], h_cH[PER_T];
+  // ---- halo fetch roles: element e of the [3][HR][HC] halo -> LDS element offset (or -1), its byte offset relative to the tile's first halo
+  //      pixel, and which tile edges it lies on (bit 0 top, 1 bottom, 2 left, 3 right: outside the image when the tile touches that border).
+  //      Loads go through a buffer descriptor whose base sits one row and one pixel in front of the image: scalar offset = tile origin
+  //      (never negative), per-lane offset = loop constant, out-of-image lanes get an out-of-range offset and read 0 - no branches.
+  int h_lds[PER_T], h_rel[PER_T], h_edges = 0;      // h_edges: 4 bits per fetched element
 #pragma unroll
   for (int i = 0; i < PER_T; ++i) {
     const int e = tid + i * 256;
     const int cr = e / HC, x = e - cr * HC, c = cr / HR, r = cr - c * HR;
-    h_lds[i] = e < HALO ? (c * HR + r) * P + x : -1;
-    h_rx[i] = r | (x << 8);
-    h_cH[i] = c * p.H;
+    h_lds[i] = e < HALO ? (c * HR + r) * P + x : DUMP / 2;
+    h_rel[i] = e < HALO ? ((c * p.H + r) * p.W + x) * 4 : (int)0x80000000;
+    h_edges |= ((r == 0 ? 1 : 0) | (r == HR - 1 ? 2 : 0) | (x == 0 ? 4 : 0) | (x == HC - 1 ? 8 : 0)) << (4 * i);
   }
+  const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)(p.img - (p.W + 1)), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == 1 ? (const bf16_t*)p.a : p.da), 0, 0x7FFFFFF0, 0x00020000);
+  const int act_lane = (fr * p.ld + fq * 8) * 2;      // byte offset of this lane's 16 bytes inside a 16-pixel fragment
   auto tile_origin = [&](int tile, int& b, int& y0, int& x0) {
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
     const int ty = t2 % p.tiles_y;
@@ -152,51 +162,65 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
     y0 = ty * TH;
     x0 = tx * TW;
   };
-  float hv[PER_T];
-  auto fetch_halo = [&](int tile) {
+  // Prefetch ring, two tiles deep: under a store-heavy load a global load takes several microseconds, and with one tile of look-ahead
+  // every iteration of a workgroup waited for one (stem_fwd_apply: 251 us with one tile of look-ahead).  Slot s = iteration parity.
+  float hv[2][PER_T];
+  auto fetch_halo = [&](int tile, auto SLOT) {
+    constexpr int s_ = decltype(SLOT)::value;
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
-#pragma unroll
-    for (int i = 0; i < PER_T; ++i) {
-      const int iy = y0 - 1 + (h_rx[i] & 0xFF), ix = x0 - 1 + (h_rx[i] >> 8);
-      float v = 0.f;
-      if (h_lds[i] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        v = p.img[((long long)(b * 3 * p.H + h_cH[i] + iy)) * p.W + ix];
-      hv[i] = v;
-    }
-  };
-  auto store_halo = [&](int buf) {
-    bf16_t* s = (bf16_t*)(smem + buf * IMG_BYTES);
+    const int edges = (y0 == 0 ? 1 : 0) | (y0 + TH == p.H ? 2 : 0) | (x0 == 0 ? 4 : 0) | (x0 + TW == p.W ? 8 : 0);
+    const int soff = ((b * 3 * p.H + y0) * p.W + x0) * 4;
 #pragma unroll
     for (int i = 0; i < PER_T; ++i)
-      if (h_lds[i] >= 0) s[h_lds[i]] = f2bf(hv[i]);
+      hv[s_][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, ((h_edges >> (4 * i)) & edges) ? (int)0x80000000 : h_rel[i], soff, 0));
   };
-  uint4 gv[4];
-  auto fetch_grad = [&](int tile) {
+  auto store_halo = [&](int buf, auto SLOT) {
+    constexpr int s_ = decltype(SLOT)::value;
+    bf16_t* s = (bf16_t*)(smem + buf * IMG_BYTES);
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) s[h_lds[i]] = f2bf(hv[s_][i]);
+  };
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  // activation / gradient tile: fragment f = 16 consecutive pixels of tile row 2*wid + f/2; scalar offset = the fragment's first pixel
+  auto frag_soff = [&](int b, int y0, int x0, int f) { return (((b * p.H + y0 + 2 * wid + (f >> 1)) * p.W + x0 + (f & 1) * 16) * p.ld) * 2; };
+  uint4 gv[2][4];
+  auto fetch_grad = [&](int tile, auto SLOT) {
+    constexpr int s_ = decltype(SLOT)::value;
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int y = y0 + 2 * wid + (f >> 1), x = x0 + (f & 1) * 16 + fr;
-      gv[f] = *(const uint4*)(p.da + ((long long)(b * p.H + y) * p.W + x) * p.ld + fq * 8);
-    }
+    for (int f = 0; f < 4; ++f)
+      gv[s_][f] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_act, act_lane, frag_soff(b, y0, x0, f), 0));
   };
 
   // the zero slots behind both image buffers (store_halo never touches them)
   if (tid < 64) *(unsigned*)(smem + (tid >> 5) * IMG_BYTES + ZBASE + (tid & 31) * 4) = 0u;
 
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  const int G = gridDim.x;
   int tile = blockIdx.x;
+  // prologue: tile 0 of this workgroup into LDS buffer 0, tile 1 on its way into ring slot 1, gradients of both
   if (tile < p.ntiles) {
-    fetch_halo(tile);
-    if (MODE >= 2) fetch_grad(tile);
-    store_halo(0);
+    fetch_halo(tile, S0{});
+    if (MODE >= 2) fetch_grad(tile, S0{});
+    if (tile + G < p.ntiles) {
+      fetch_halo(tile + G, S1{});
+      if (MODE >= 2) fetch_grad(tile + G, S1{});
+    }
+    store_halo(0, S0{});
   }
   __syncthreads();
   int buf = 0;
-  for (; tile < p.ntiles; tile += gridDim.x) {
-    const int nxt = tile + gridDim.x;
+  // iteration with parity s: computes `tile` (LDS buffer `buf`, gradient slot s), fetches the halo of tile + 2G into slot s (free: it
+  // went to LDS one iteration ago), stores the halo of tile + G (slot 1 - s, fetched one iteration ago) into the other LDS buffer
+  auto iteration = [&](auto SLOT) {
+    constexpr int s_ = decltype(SLOT)::value;
+    typedef std::integral_constant<int, 1 - s_> OTHER;
+    const int nxt = tile + G, nxt2 = tile + 2 * G;
     const bool has_next = nxt < p.ntiles;
-    if (has_next) fetch_halo(nxt);           // in flight while this tile is computed
+    if (nxt2 < p.ntiles) fetch_halo(nxt2, SLOT);
     const char* simg = smem + buf * IMG_BYTES;
     int b, y0, x0;
     tile_origin(tile, b, y0, x0);
@@ -236,11 +260,10 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
         w4.y = o[2] | ((unsigned)o[3] << 16);
         w4.z = o[4] | ((unsigned)o[5] << 16);
         w4.w = o[6] | ((unsigned)o[7] << 16);
-        const int y = y0 + 2 * wid + (f >> 1), x = x0 + (f & 1) * 16 + fr;
-        *(uint4*)(p.a + ((long long)(b * p.H + y) * p.W + x) * p.ld + fq * 8) = w4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w4), rs_act, act_lane, frag_soff(b, y0, x0, f), 0);
       }
       if (MODE == 2) {
-        const unsigned gi[4] = {gv[f].x, gv[f].y, gv[f].z, gv[f].w};
+        const unsigned gi[4] = {gv[s_][f].x, gv[s_][f].y, gv[s_][f].z, gv[s_][f].w};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float z = acc[k >> 2][k & 3];
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
       }
       if (MODE == 3) {
         // dz -> wave-private LDS tile [pixel row 0..63][32 channels], 32-byte blocks XOR-swizzled by bit 3 of the pixel row
-        const unsigned gi[4] = {gv[f].x, gv[f].y, gv[f].z, gv[f].w};
+        const unsigned gi[4] = {gv[s_][f].x, gv[s_][f].y, gv[s_][f].z, gv[s_][f].w};
         unsigned short o[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -273,7 +296,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
         *(uint4*)(dzt + prow * 64 + blk * 32 + (fq & 1) * 16) = w4;
       }
     }
-    if (MODE >= 2 && has_next) fetch_grad(nxt);      // this tile's gradient registers are consumed: refill them for the next tile
+    if (MODE >= 2 && nxt2 < p.ntiles) fetch_grad(nxt2, SLOT);      // this slot's gradient registers are consumed: refill them two tiles ahead
     if (MODE == 3) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
@@ -314,14 +337,26 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (has_next) store_halo(buf ^ 1);
+    if (has_next) store_halo(buf ^ 1, OTHER{});
     __syncthreads();
     buf ^= 1;
+    tile = nxt;
+  };
+#pragma nounroll
+  while (tile < p.ntiles) {
+    iteration(S0{});
+    if (tile >= p.ntiles) break;
+    iteration(S1{});
   }
 
   // ---- end of the persistent loop: fold the per-lane sums (fixed order) and write this workgroup's row
   __syncthreads();
   float* red = (float*)smem;
+  {
+    const int rowf = MODE == 3 ? 1024 : 64;
+    for (int r = blockIdx.x + gridDim.x; r < p.rows_total; r += gridDim.x)
+      for (int i = tid; i < rowf; i += 256) p.partial[(long long)r * rowf + i] = 0.f;
+  }
   if (MODE == 0 || MODE == 2) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -380,7 +415,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
   }
 }
 
-int stem_grid(int ntiles) {
+int stem_cus() {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -388,14 +423,19 @@ int stem_grid(int ntiles) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const int g = cus * 4;      // MODE 2 / 3 fit three workgroups per CU (168 VGPRs): the fourth queues behind them, same partial-row count for every mode
+  return cus;
+}
+// persistent grid = what is resident at once (a workgroup that has to queue behind the resident ones would run its tiles alone at the end):
+// four workgroups per CU for the forward kernels, three for the backward ones (168 VGPRs)
+int stem_grid(int ntiles, int per_cu = 4) {
+  const int g = stem_cus() * per_cu;
   return ntiles < g ? ntiles : g;
 }
 
 int stem_check(const char* what, int n, int h, int w) {
   if (n <= 0 || h <= 0 || w <= 0 || h % TH != 0 || w % TW != 0)
     return fail(MI355DET_EINVAL, "%s: needs h %% 8 == 0 and w %% 32 == 0 (got %lld x %lld)", what, h, w);
-  if ((long long)n * h * w > 0x7FFFFFFFll) return fail(MI355DET_EINVAL, "%s: image batch too large", what);
+  if ((long long)n * h * w * 12 >= 0x7FFFFFF0ll) return fail(MI355DET_EINVAL, "%s: image batch too large (32-bit byte offsets)", what);
   return 0;
 }
 
@@ -410,6 +450,7 @@ StemParams stem_params(const float* img, const void* w, int n, int h, int wd) {
   p.tiles_y = h / TH;
   p.ntiles = n * p.tiles_x * p.tiles_y;
   p.inv_count = 1.0f / (float)((long long)n * h * wd);
+  p.rows_total = stem_grid(p.ntiles);
   return p;
 }
 
@@ -418,7 +459,7 @@ int stem_launch(const char* what, const StemParams& p, hipStream_t st) {
   constexpr int lds_loop = 2 * IMG_BYTES + (MODE == 3 ? 4 * DZ_WAVE : 0);
   constexpr int lds_end = MODE == 3 ? 4 * 1024 * 4 : 4 * 32 * 2 * 4;
   constexpr int lds = lds_loop > lds_end ? lds_loop : lds_end;
-  hipLaunchKernelGGL(stem_kernel<MODE>, dim3(stem_grid(p.ntiles)), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(stem_kernel<MODE>, dim3(stem_grid(p.ntiles, MODE >= 2 ? 3 : 4)), dim3(256), lds, st, p);
   return check_launch(what);
 }
 
@@ -444,6 +485,7 @@ int mi355det_stem_fwd_apply(const float* img, const void* w, const float* scale_
   if (int e = stem_check("stem_fwd_apply", n, h, wd)) return e;
   if (!img || !w || !scale_shift || !a || a_ld < 32 || a_ld % 8) return fail(MI355DET_EINVAL, "%s: bad argument", "stem_fwd_apply");
   if (!(slope > 0.f && slope < 1.f)) return fail(MI355DET_EINVAL, "%s: LeakyReLU slope must be in (0, 1)", "stem_fwd_apply");
+  if ((long long)n * h * wd * a_ld * 2 >= 0x7FFFFFF0ll) return fail(MI355DET_EINVAL, "%s: tensor too large (32-bit byte offsets)", "stem_fwd_apply");
   StemParams p = stem_params(img, w, n, h, wd);
   p.ss = scale_shift;
   p.slope = slope;
@@ -456,6 +498,7 @@ int mi355det_stem_bwd_reduce(const float* img, const void* w, const float* scale
                              int32_t n, int32_t h, int32_t wd, void* stream) {
   if (int e = stem_check("stem_bwd_reduce", n, h, wd)) return e;
   if (!img || !w || !scale_shift || !da || !partial || da_ld < 32 || da_ld % 8) return fail(MI355DET_EINVAL, "%s: bad argument", "stem_bwd_reduce");
+  if ((long long)n * h * wd * da_ld * 2 >= 0x7FFFFFF0ll) return fail(MI355DET_EINVAL, "%s: tensor too large (32-bit byte offsets)", "stem_bwd_reduce");
   StemParams p = stem_params(img, w, n, h, wd);
   p.ss = scale_shift;
   p.slope = slope;
@@ -471,6 +514,7 @@ int mi355det_stem_bwd_apply_wgrad(const float* img, const void* w, const float* 
   if (int e = stem_check("stem_bwd_apply_wgrad", n, h, wd)) return e;
   if (!img || !w || !scale_shift || !sums || !da || !slab || !dw || da_ld < 32 || da_ld % 8)
     return fail(MI355DET_EINVAL, "%s: bad argument", "stem_bwd_apply_wgrad");
+  if ((long long)n * h * wd * da_ld * 2 >= 0x7FFFFFF0ll) return fail(MI355DET_EINVAL, "%s: tensor too large (32-bit byte offsets)", "stem_bwd_apply_wgrad");
   StemParams p = stem_params(img, w, n, h, wd);
   p.ss = scale_shift;
   p.sums = sums;
