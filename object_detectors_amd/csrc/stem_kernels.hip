@@ -260,7 +260,12 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
         w4.y = o[2] | ((unsigned)o[3] << 16);
         w4.z = o[4] | ((unsigned)o[5] << 16);
         w4.w = o[6] | ((unsigned)o[7] << 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w4), rs_act, act_lane, frag_soff(b, y0, x0, f), 0);
+        // The tile offset goes into the VECTOR offset here (scalar offset 0), unlike the loads.  A 16-byte buffer store reads its data
+        // registers over several cycles; with an SGPR in the soffset field the compiler assumes that overwriting them in the very next
+        // instruction is safe and inserts no wait state - on gfx950 it is not: the last lanes (12-15 of every 16) of the LAST data dword
+        // picked up the next fragment's value whenever another process shared the GPU (tools/debug_stem_stress.py: 4-56 wrong pixels in
+        // ~2 % of the launches).  Without an soffset register the hazard recogniser adds the required wait state itself.
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w4), rs_act, act_lane + frag_soff(b, y0, x0, f), 0, 0);
       }
       if (MODE == 2) {
         const unsigned gi[4] = {gv[s_][f].x, gv[s_][f].y, gv[s_][f].z, gv[s_][f].w};
