@@ -40,6 +40,14 @@ class YoloHead(nn.Module):
             self._plist.append(nn.Parameter(self.engine.params[name]))
         self.train(is_training)
 
+    def train(self, mode=True):
+        """model.eval() (test_one_epoch.py:10, valid_one_epoch.py:9) declares the weights static until the next train() / load: the engine
+        then packs them and folds the BatchNorm layers once per evaluation loop instead of once per batch."""
+        super().train(mode)
+        if hasattr(self, "engine"):
+            self.engine.freeze_inference(not mode)
+        return self
+
     def _attach_grads(self):
         for name, p in zip(self._pnames, self._plist):
             p.grad = self.engine.grads[name]

@@ -424,3 +424,32 @@ def test_fused_step_with_loss_scale_and_criterion_options(opts):
     before = eng.flat_w.clone()
     assert scaler.step(opt) is False and scaler.loss_scale == S / 2
     assert torch.equal(eng.flat_w, before)
+
+
+def test_frozen_inference_matches_and_follows_weight_loads():
+    """freeze_inference (what YoloHead.eval() switches on): the packs and folded BatchNorm rows are built once per evaluation loop;
+    outputs are bit-identical to the per-batch rebuild, and a weight load or a training forward refreshes them."""
+    eng, sd = make_engine("darknet_21", 5000, damp=0.2)
+    x1 = torch.from_numpy(detrand.uniform(77, (2, 3, 96, 96), -2.0, 2.0)).to(dev())
+    x2 = torch.from_numpy(detrand.uniform(78, (2, 3, 96, 96), -2.0, 2.0)).to(dev())
+    base1 = [o.clone() for o in eng.forward(x1, training=False)]
+    base2 = [o.clone() for o in eng.forward(x2, training=False)]
+    eng.freeze_inference(True)
+    for _ in range(2):
+        for x, base in ((x1, base1), (x2, base2)):
+            outs = eng.forward(x, training=False)
+            assert all(torch.equal(o, b) for o, b in zip(outs, base))
+    plan = eng._last_plan
+    assert plan._const_epoch == eng._static_epoch > 0
+    sd2 = {k: (v * 1.5 if k.endswith("conv_out.weight") else v) for k, v in sd.items()}
+    eng.load_reference_state_dict(sd2)                     # un-freezes this epoch: the next forward re-packs
+    outs = eng.forward(x1, training=False)
+    assert not torch.equal(outs[0], base1[0])
+    eng.freeze_inference(False)
+    ref = eng.forward(x1, training=False)
+    assert all(torch.equal(o, r) for o, r in zip(outs, ref))
+    eng.freeze_inference(True)
+    eng.forward(x1, training=False)
+    e0 = eng._static_epoch
+    eng.forward(x1, training=True)                         # a training forward (an optimizer step may follow) invalidates the frozen state
+    assert eng._static_epoch > e0

@@ -38,6 +38,7 @@ def main():
     crit = YOLOForw(anchors=bench.ANCHORS, num_classes=80, img_size=args.px).to(dev)
     imgs, _ = bench.synth_batch(args.batch, args.px, 0, dev)
     eng.training = False
+    eng.freeze_inference(True)       # what model.eval() does in the mirror (yolohead.py): weights static over the evaluation loop
     t_net, heads = timed(lambda: eng.forward(imgs, training=False), args.iters)
     t_dec, pred = timed(lambda: crit(eng.forward(imgs, training=False)), args.iters)
     t_all, dets = timed(lambda: postprocess(crit(eng.forward(imgs, training=False)), 0.5, criterion=crit), args.iters)

@@ -4,11 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from object_detectors_amd.yolo.nets.engine import arch
 path = sys.argv[1]
 rows = list(csv.DictReader(open(glob.glob(path + '/**/*kernel_trace.csv', recursive=True)[0])))
-idx = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'stem_kernel<0>' in r['Kernel_Name']]      # first convolution kernel of a step (stem statistics pass)
 last = rows[idx[-1]:]
-specs = arch()
+specs = arch()[1:]      # the stem runs in csrc/stem_kernels.hip (no igemm / wgrad_kernel launch): listed separately below
 def hw(s):
     n = s.name
     if n == 'backbone.conv1': return 640
@@ -18,24 +17,23 @@ def hw(s):
     return 80
 def dur(r): return (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 fw = [r for r in last if 'igemm' in r['Kernel_Name'] and (', 0, ' in r['Kernel_Name'].split('igemm')[1][:60] or True)]
-# forward igemm launches = first 75 igemm-family kernels of the step (before any wgrad)
+# forward igemm launches = first 74 igemm-family kernels of the step (before any wgrad)
 first_w = next(i for i, r in enumerate(last) if 'wgrad_kernel' in r['Kernel_Name'])
-fwd = sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))[:75]
+fwd = sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))[:74]
 bwd = last[first_w - 10:]
 wg = sorted([r for r in last if 'wgrad_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
 agg = collections.OrderedDict()
 for s, r in zip(specs, fwd):
     k = (s.cin, s.cout, s.k, s.stride, hw(s)); a = agg.setdefault(k, [0, 0.0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += dur(r)
-    kk = 27 if s.name == 'backbone.conv1' else s.cin * s.k * s.k
+    kk = s.cin * s.k * s.k
     a[4] += 2.0 * 32 * hw(s) ** 2 * s.cout * kk
 for s, r in zip(reversed(specs), wg):
     agg[(s.cin, s.cout, s.k, s.stride, hw(s))][3] += dur(r)
 # dgrad: igemm kernels after the first wgrad, grouped per layer in backward order (stride-2 layers have 4 launches)
 allig = sorted([r for r in last if 'igemm' in r['Kernel_Name'] or 'dgrad_s2_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
-dg = allig[75:]
+dg = allig[74:]
 it = iter(dg)
 for s in reversed(specs):
-    if s.name == 'backbone.conv1': continue
     n = 4 if s.stride == 2 else 1
     if s.stride == 2 and s.cout == 64 and s.cin in (32, 64): n = 1    # single-launch stride-2 data gradient (dgrad_s2_kernels.hip)
     t = sum(dur(next(it)) for _ in range(n))
@@ -47,3 +45,9 @@ for k, (n, f, d, w, fl) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1]
     print(f"{k[0]:4d}->{k[1]:4d} k{k[2]} s{k[3]} @{k[4]:3d}       {n:3d} {f / n:8.1f} {tf(f):6.0f} {d / n:8.1f} {tf(d):6.0f} {w / n:8.1f} {tf(w):6.0f}  {(f + d + w) / 1e3:6.2f}")
     tot[0] += f; tot[1] += d; tot[2] += w
 print('totals ms: fwd %.2f dgrad %.2f wgrad %.2f' % tuple(t / 1e3 for t in tot))
+stem = collections.OrderedDict()
+for r in last:
+    if 'stem_' in r['Kernel_Name']:
+        n = r['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '')
+        stem[n] = stem.get(n, 0.0) + dur(r)
+print('stem 3->32 k3 s1 @640 (recompute kernels, us): ' + ', '.join(f'{k} {v:.1f}' for k, v in stem.items()) + f'; total {sum(stem.values()) / 1e3:.2f} ms')
