@@ -106,6 +106,7 @@ class YoloV3Engine:
         self.backbone, self.na, self.nc = backbone, num_anchors, num_classes
         self.head_c = num_anchors * (5 + num_classes)
         self.head_ld = ops.pad_to(self.head_c, 32)
+        self._static_epoch = 0          # > 0 while the weights are declared static (freeze_inference): bumped by every change of the parameters
         self.specs = arch(backbone, num_anchors, num_classes)
         self.by_name = {s.name: s for s in self.specs}
         self._layout_params()
@@ -113,7 +114,6 @@ class YoloV3Engine:
         self.plans = {}
         self.training = True
         self.num_batches_tracked = 0
-        self._static_epoch = 0          # > 0 while the weights are declared static (freeze_inference): bumped by every change of the parameters
 
     def freeze_inference(self, on=True):
         """Declare the parameters and BatchNorm buffers unchanged from now on (model.eval() before a test loop, test_one_epoch.py:10-16):
