@@ -128,7 +128,8 @@ int mi355det_yolo_candidates(const float* pred, const float* score_in /* optiona
  *   argsort" (highest original index first among ties).
  * out: out_rows [bs,max_n,6] kept rows in keep order with the majority relabel applied,
  *      out_idx [bs,max_n] int32 original row index, out_count [bs] int32.
- * max_n <= 16384.  workspace: mi355det_nms_workspace(bs, max_n). */
+ * max_n <= 131072 (up to 16384 boxes are sorted by one workgroup in LDS, more by chunk sorts + a merge by rank; the n*n/8-byte
+ * suppression mask is 2 GiB per image at the cap).  workspace: mi355det_nms_workspace(bs, max_n). */
 size_t mi355det_nms_workspace(int32_t bs, int32_t max_n);
 int mi355det_nms_majority(const float* boxes, const int32_t* count, int32_t bs, int32_t max_n,
                           float thresh_iou, int32_t num_classes /* labels in [0,num_classes) */, float* out_rows, int32_t* out_idx, int32_t* out_count,
@@ -139,7 +140,7 @@ int mi355det_box_iou(const float* boxes1, const float* boxes2, float* out, int64
                      void* stream);
 
 /* torchvision.ops.boxes.nms / batched_nms (retinanet.py:463, rpn.py:272, roi_heads.py:771).
- *   boxes [n,4] xyxy, scores [n], idxs [n] int64 or NULL (plain nms); n <= 16384.
+ *   boxes [n,4] xyxy, scores [n], idxs [n] int64 or NULL (plain nms); n <= 131072.
  *   keep [n] int64 in descending-score order (ties: lower index first), keep_count [1] int32. */
 int mi355det_nms(const float* boxes, const float* scores, const int64_t* idxs, int32_t n,
                  float iou_thr, int64_t* keep, int32_t* keep_count, void* workspace,
@@ -343,8 +344,7 @@ int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* 
  *   bn_act_bwd_reduce: per-channel sums of dy and dy*xhat where dy = (g1[+g2]) * lrelu'(.)
  *   bn_act_bwd_apply: dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat))  (bf16)
  * Limits and reproducibility:
- *   - c must be a multiple of 8 everywhere; bn_act_bwd_reduce additionally needs c/8 to be a power of two <= 256
- *     (c in {8, 16, 32, ..., 2048}: every Darknet / YoloHead layer) and returns MI355DET_EINVAL otherwise;
+ *   - c must be a multiple of 8 everywhere (MI355DET_EINVAL otherwise);
  *   - bn_act_bwd_reduce finishes every workgroup with one fp32 atomicAdd per channel into `sums`, so the two sums - and through them
  *     dz, dgamma, dbeta and everything upstream - differ from run to run in the last bits (measured ~6e-4 of max on the final
  *     gradient of a 75-layer step).  Ranks stay in sync (the all-reduce result is the same on every rank).  The plain-store

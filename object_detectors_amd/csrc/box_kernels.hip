@@ -8,13 +8,14 @@ using namespace mi355;
 
 namespace {
 
-#define NMS_MAX_N 16384
+#define NMS_MAX_N 131072       // the n*n/8-byte suppression mask is 2 GiB per image at this size
+#define NMS_SORT_CHUNK 16384    // boxes one workgroup sorts in LDS; larger inputs: chunk sorts + merge by rank (nms_merge_kernel)
 #define SORT_THREADS 1024
 #define RADIX_MIN_N 4096      // padded sizes from here on are sorted by the radix path of nms_sort_kernel
 #define RADIX_CAP 16384        // = NMS_MAX_N
 
 struct NmsWs {   // per-image workspace carve (all offsets in bytes, 16-B aligned)
-  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, diagt, keptbits, stride;
+  size_t sorted_idx, sbox, scls, mask, kept, remover, misc, diagt, keptbits, ckey, csrc, stride;
   int words;
 };
 
@@ -32,6 +33,8 @@ __host__ __device__ inline NmsWs nms_layout(int max_n) {
   w.misc = o;       o = align16(o + 64);
   w.diagt = o;      o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64);   // transposed diagonal blocks: word j = earlier boxes of j's tile that drop j
   w.keptbits = o;   o = align16(o + sizeof(unsigned long long) * (size_t)w.words);        // per tile: which of its 64 boxes the scan kept
+  w.ckey = o;       o = align16(o + (max_n > NMS_SORT_CHUNK ? sizeof(unsigned) * (size_t)max_n : 0));      // chunk-sorted keys / source rows (large inputs only)
+  w.csrc = o;       o = align16(o + (max_n > NMS_SORT_CHUNK ? sizeof(int) * (size_t)max_n : 0));
   w.mask = o;       o = align16(o + sizeof(unsigned long long) * (size_t)w.words * 64 * w.words);   // [column block][row padded to 64]
   w.stride = o;
   return w;
@@ -40,16 +43,22 @@ __host__ __device__ inline NmsWs nms_layout(int max_n) {
 // ---- 1. sort by score (single block bitonic in LDS), gather sorted boxes -------------------
 // MODE 0: nms_majority rows [n,6]; order = reverse of a stable ascending argsort (helper.py:308,320)
 // MODE 1: torchvision nms; descending score, ties -> lower index first; optional category offsets
-template <int MODE>
+// CHUNK: blockIdx.x = chunk of NMS_SORT_CHUNK consecutive positions of the initial order (index order for MODE 1, reverse index order for
+// MODE 0); the workgroup radix-sorts its chunk and leaves (key, source row) in global memory for nms_merge_kernel.
+template <int MODE, bool CHUNK = false>
 __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                                  const long long* __restrict__ idxs, const int* __restrict__ count,
                                                                  int n_fixed, int max_n, char* __restrict__ ws_base, NmsWs L) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   __shared__ float smax[SORT_THREADS / WAVE];
-  const int b = blockIdx.x;
-  const int n = count ? min(count[b], max_n) : n_fixed;
+  const int b = CHUNK ? blockIdx.y : blockIdx.x;
+  const int n_total = count ? min(count[b], max_n) : n_fixed;
+  const int p_base = CHUNK ? blockIdx.x * NMS_SORT_CHUNK : 0;
+  const int n = CHUNK ? max(0, min(NMS_SORT_CHUNK, n_total - p_base)) : n_total;
   char* ws = ws_base + (size_t)b * L.stride;
-  int npad = 64;
+  if (CHUNK && blockIdx.x == 0 && threadIdx.x == 0) ((int*)(ws + L.misc))[0] = n_total;
+  if (CHUNK && n == 0) return;
+  int npad = CHUNK ? RADIX_MIN_N : 64;
   while (npad < n) npad <<= 1;
   const float* P = boxes + (size_t)b * max_n * (MODE == 0 ? 6 : 4);
   for (int i = threadIdx.x; i < npad; i += SORT_THREADS) {
@@ -63,7 +72,7 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __r
   }
   // batched_nms offset: idxs * (max coordinate + 1)   (torchvision batched_nms)
   float off_scale = 0.f;
-  if (MODE == 1 && idxs) {
+  if (!CHUNK && MODE == 1 && idxs) {
     float m = -INFINITY;
     for (int i = threadIdx.x; i < n * 4; i += SORT_THREADS) m = fmaxf(m, P[i]);
     m = wave_max(m);
@@ -92,10 +101,10 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __r
       unsigned k = 0xFFFFFFFFu;
       unsigned short src = 0;
       if (p < n) {
-        const int i = MODE == 0 ? n - 1 - p : p;
+        const int i = MODE == 0 ? n_total - 1 - (p_base + p) : p_base + p;
         const float sc = MODE == 0 ? P[(size_t)i * 6 + 4] : scores[i];
         k = ~f2ord(sc);
-        src = (unsigned short)i;
+        src = (unsigned short)(CHUNK ? p : i);      // chunk form: position inside the chunk (the row index may exceed 16 bits)
       }
       rk[p] = k;
       ri[p] = src;
@@ -171,6 +180,18 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __r
       }
     }
   }
+  if (CHUNK) {
+    const unsigned* rk = (const unsigned*)keys;
+    const unsigned short* ri = (const unsigned short*)(rk + RADIX_CAP);
+    unsigned* ckey = (unsigned*)(ws + L.ckey);
+    int* csrc = (int*)(ws + L.csrc);
+    for (int j = threadIdx.x; j < n; j += SORT_THREADS) {
+      const int gp = p_base + (int)ri[j];
+      ckey[p_base + j] = rk[j];
+      csrc[p_base + j] = MODE == 0 ? n_total - 1 - gp : gp;
+    }
+    return;
+  }
   int* sorted_idx = (int*)(ws + L.sorted_idx);
   float4* sbox = (float4*)(ws + L.sbox);
   int* scls = (int*)(ws + L.scls);
@@ -193,6 +214,71 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __r
     }
   }
   if (threadIdx.x == 0) ((int*)(ws + L.misc))[0] = n;
+}
+
+// Large inputs (n > NMS_SORT_CHUNK).  The stable LSD sort orders by (key, position in the initial order); keys of different chunks are
+// merged by RANK: element j of chunk c lands at j + sum over the other chunks d of the number of their elements that precede it - those
+// with key <= its key for d < c (earlier initial positions win ties), key < its key for d > c: two binary searches per other chunk, no
+// serial merge.  Then the same gather as the single-workgroup sort (sorted boxes, classes, batched_nms category offsets).
+__global__ __launch_bounds__(256) void nms_maxcoord_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int n_fixed, int max_n,
+                                                           char* __restrict__ ws_base, NmsWs L) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const int n = count ? min(count[b], max_n) : n_fixed;
+  const float* P = boxes + (size_t)b * max_n * 4;
+  float m = -INFINITY;
+  for (long long i = threadIdx.x; i < (long long)n * 4; i += 256) m = fmaxf(m, P[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x / WAVE] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) ((float*)(ws_base + (size_t)b * L.stride + L.misc))[1] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) + 1.0f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void nms_merge_kernel(const float* __restrict__ boxes, const long long* __restrict__ idxs, int max_n,
+                                                        char* __restrict__ ws_base, NmsWs L) {
+  const int b = blockIdx.y;
+  char* ws = ws_base + (size_t)b * L.stride;
+  const int n = ((const int*)(ws + L.misc))[0];
+  const float off_scale = (MODE == 1 && idxs) ? ((const float*)(ws + L.misc))[1] : 0.f;
+  const unsigned* ckey = (const unsigned*)(ws + L.ckey);
+  const int* csrc = (const int*)(ws + L.csrc);
+  int* sorted_idx = (int*)(ws + L.sorted_idx);
+  float4* sbox = (float4*)(ws + L.sbox);
+  int* scls = (int*)(ws + L.scls);
+  const float* P = boxes + (size_t)b * max_n * (MODE == 0 ? 6 : 4);
+  const int chunks = (n + NMS_SORT_CHUNK - 1) / NMS_SORT_CHUNK;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int c = e / NMS_SORT_CHUNK;
+    const unsigned k = ckey[e];
+    int rank = e - c * NMS_SORT_CHUNK;
+    for (int d = 0; d < chunks; ++d) {
+      if (d == c) continue;
+      const unsigned* a = ckey + (size_t)d * NMS_SORT_CHUNK;
+      int lo = 0, hi = min(NMS_SORT_CHUNK, n - d * NMS_SORT_CHUNK);
+      while (lo < hi) {                                   // d < c: first element > k; d > c: first element >= k
+        const int mid = (lo + hi) >> 1;
+        const unsigned v = a[mid];
+        if (d < c ? v <= k : v < k) lo = mid + 1;
+        else hi = mid;
+      }
+      rank += lo;
+    }
+    const int src = csrc[e];
+    sorted_idx[rank] = src;
+    if (MODE == 0) {
+      const float* r = P + (size_t)src * 6;
+      sbox[rank] = make_float4(r[0], r[1], r[2], r[3]);
+      scls[rank] = (int)r[5];
+    } else {
+      float4 v = *(const float4*)(P + (size_t)src * 4);
+      if (idxs) {
+        const float o = (float)idxs[src] * off_scale;
+        v.x += o; v.y += o; v.z += o; v.w += o;
+      }
+      sbox[rank] = v;
+    }
+  }
 }
 
 // IoU variants with the reference's exact operation order
@@ -793,6 +879,21 @@ int launch_nms_common(int mode, const float* boxes, const float* scores, const l
   if (max_n <= 0 || max_n > NMS_MAX_N) return fail(MI355DET_EINVAL, "%s: n must be in [1,%lld]", "nms", NMS_MAX_N);
   L = nms_layout(max_n);
   if (workspace_bytes < L.stride * (size_t)bs) return fail(MI355DET_EWORKSPACE, "%s: workspace too small (%lld needed)", "nms", (long long)(L.stride * bs));
+  if (max_n > NMS_SORT_CHUNK) {
+    // chunk sorts (one workgroup per 16 384 boxes) + merge by rank
+    const size_t lds = (size_t)RADIX_CAP * 6 + (size_t)16 * SORT_THREADS * 2;
+    const int chunks = (max_n + NMS_SORT_CHUNK - 1) / NMS_SORT_CHUNK;
+    if (mode == 0) {
+      (void)hipFuncSetAttribute((const void*)nms_sort_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((nms_sort_kernel<0, true>), dim3(chunks, bs), dim3(SORT_THREADS), lds, st, boxes, scores, idxs, count, n_fixed, max_n, (char*)workspace, L);
+      hipLaunchKernelGGL(nms_merge_kernel<0>, dim3(min(256, (max_n + 255) / 256), bs), dim3(256), 0, st, boxes, idxs, max_n, (char*)workspace, L);
+    } else {
+      (void)hipFuncSetAttribute((const void*)nms_sort_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((nms_sort_kernel<1, true>), dim3(chunks, bs), dim3(SORT_THREADS), lds, st, boxes, scores, idxs, count, n_fixed, max_n, (char*)workspace, L);
+      if (idxs) hipLaunchKernelGGL(nms_maxcoord_kernel, dim3(bs), dim3(256), 0, st, boxes, count, n_fixed, max_n, (char*)workspace, L);
+      hipLaunchKernelGGL(nms_merge_kernel<1>, dim3(min(256, (max_n + 255) / 256), bs), dim3(256), 0, st, boxes, idxs, max_n, (char*)workspace, L);
+    }
+  } else {
   int npad = 64;
   while (npad < max_n) npad <<= 1;
   // bitonic: one 64-bit key per padded slot; radix (npad >= RADIX_MIN_N): u32 keys + u16 indices + the [16][1024] u16 count table
@@ -803,6 +904,7 @@ int launch_nms_common(int mode, const float* boxes, const float* scores, const l
   } else {
     (void)hipFuncSetAttribute((const void*)nms_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(nms_sort_kernel<1>, dim3(bs), dim3(SORT_THREADS), lds, st, boxes, scores, idxs, count, n_fixed, max_n, (char*)workspace, L);
+  }
   }
   const int tiles = (max_n + 63) / 64;
   if (mode == 0) hipLaunchKernelGGL(nms_mask_kernel<0>, dim3(tiles, tiles, bs), dim3(WAVE), 0, st, (char*)workspace, L, thr);

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
   // groups = 8-channel groups per workgroup (power of two <= 256); blockIdx.y picks the channel slab when c/8 > groups
   const int gl = threadIdx.x % groups, pl = threadIdx.x / groups, npl = 256 / groups;
   const int cbase = blockIdx.y * groups * 8;
-  const int c0 = cbase + (gl << 3);
+  const bool live = cbase + (gl << 3) < c;          // the last channel slab may be partly empty (channel counts that are not a multiple of groups * 8)
+  const int c0 = live ? cbase + (gl << 3) : 0;
   float sc[8], sh[8], mu[8], is[8], a1[8], a2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {   // issue all loads first: 8-12 x 16 B in flight per lane
       const long long mm = m + (long long)u * npl;
-      const bool ok = mm < mB;
+      const bool ok = mm < mB && live;
       gu[u] = ok ? *(const uint4*)(g1 + mm * g1_ld + c0) : make_uint4(0, 0, 0, 0);
       zu[u] = ok ? *(const uint4*)(z + mm * z_ld + c0) : make_uint4(0, 0, 0, 0);
       if (g2) hu[u] = ok ? *(const uint4*)(g2 + mm * g2_ld + c0) : make_uint4(0, 0, 0, 0);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     const int gi = ch >> 3, k = ch & 7;
     float s = 0.f;
     for (int p2 = 0; p2 < npl; ++p2) s += red[p2 * groups + gi][which * 8 + k];
-    atomicAdd(sums + which * c + cbase + ch, s);
+    if (cbase + ch < c) atomicAdd(sums + which * c + cbase + ch, s);
   }
 }
 
@@ -614,12 +615,14 @@ int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, i
 int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift,
                                int32_t c, int64_t pixels, float slope, float* sums, void* stream) {
   const int groups = c / 8;
-  if (c <= 0 || c % 8 != 0 || groups > 256 || (groups & (groups - 1)) != 0)
-    return fail(MI355DET_EINVAL, "%s: channels/8 must be a power of two <= 256 (got c=%lld)", "bn_act_bwd_reduce", c);
+  if (c <= 0 || c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8 (got c=%lld)", "bn_act_bwd_reduce", c);
   // a workgroup covers at most 64-128 channels (whole 128-byte lines per pixel) and more pixels instead: every workgroup ends with
   // 2 * (its channels) float atomics, ~24 G atomics/s device-wide measured (410 k of them are 17 us), so wide layers are cut into
   // channel slabs (blockIdx.y) and large tensors get no more than ~2 workgroups per CU
-  const int gb = groups >= 32 ? 16 : (groups > 8 ? 8 : groups), slabs = groups / gb;
+  // (any multiple of 8 channels: the last slab of a channel count that is not gb * 8 * k has idle channel groups)
+  int gb = groups >= 32 ? 16 : (groups > 8 ? 8 : 1);
+  while (gb * 2 <= groups && gb < 8) gb *= 2;
+  const int slabs = (groups + gb - 1) / gb;
   const int npl = 256 / gb;
   long long ppb = (long long)npl * 32;   // 32 pixels per pixel-lane
   long long blocks = (pixels + ppb - 1) / ppb;

@@ -30,8 +30,8 @@ def nms_majority(P, thresh_iou=0.6, num_classes=None):
     n = P.shape[0]
     if n == 0:
         raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) in the reference
-    if n > 16384:
-        raise ValueError("nms_majority: at most 16384 boxes per call")
+    if n > 131072:
+        raise ValueError("nms_majority: at most 131072 boxes per call (the n*n/8-byte suppression mask is 2 GiB at that size)")
     if num_classes is None:
         num_classes = int(P[:, 5].max().item()) + 1
     count = torch.full((1,), n, device=P.device, dtype=torch.int32)

@@ -90,9 +90,10 @@ def det_state(backbone, seed, na=3, nc=80):
     return sd
 
 
-def forward(sd, x, backbone, training=True, quant=None, record=None):
+def forward(sd, x, backbone, training=True, quant=None, record=None, update_running=False):
     """-> (out0, out1, out2).  `quant` optionally rounds activations/weights (e.g. to bf16) to mimic the
-    GPU path's storage precision when judging tolerances."""
+    GPU path's storage precision when judging tolerances.  update_running: training mode also updates the running statistics in `sd`
+    in place (nn.BatchNorm2d's momentum rule), as a module in train() does - used by the multi-step trajectory test."""
     q = (lambda t: t) if quant is None else quant
 
     def cbl(name_conv, name_bn, t, stride=1):
@@ -100,7 +101,8 @@ def forward(sd, x, backbone, training=True, quant=None, record=None):
         k = w.shape[-1]
         z = q(F.conv2d(t, w, stride=stride, padding=(k - 1) // 2))
         if training:
-            y = F.batch_norm(z, None, None, sd[name_bn + ".weight"], sd[name_bn + ".bias"], True, 0.1, 1e-5)
+            rm, rv = (sd[name_bn + ".running_mean"], sd[name_bn + ".running_var"]) if update_running else (None, None)
+            y = F.batch_norm(z, rm, rv, sd[name_bn + ".weight"], sd[name_bn + ".bias"], True, 0.1, 1e-5)
         else:
             y = F.batch_norm(z, sd[name_bn + ".running_mean"], sd[name_bn + ".running_var"], sd[name_bn + ".weight"],
                              sd[name_bn + ".bias"], False, 0.1, 1e-5)

@@ -109,6 +109,20 @@ def test_nms_many_equal_scores_radix_path(n):
     assert np.array_equal(keep, tv.nms(boxes, scores, 0.5))
 
 
+@pytest.mark.parametrize("n", [16385, 40000])
+def test_nms_beyond_one_sort_chunk(n):
+    """More than 16 384 boxes (the reference's nms has no cap): chunk sorts in LDS + merge by rank (nms_merge_kernel).  Quantised scores make
+    the keep list depend on the tie order across chunk borders; batched form with the category offsets of the whole set."""
+    from object_detectors_amd.tvision import boxes as B
+    boxes, scores = nms_inputs(7000 + n, n, extent=6000.0)
+    scores = (np.floor(scores * 64) / 64).astype(np.float32)
+    keep = B.nms(T(boxes), T(scores), 0.5).cpu().numpy()
+    assert np.array_equal(keep, tv.nms(boxes, scores, 0.5))
+    idxs = detrand.randint(91 + n, (n,), 0, 7)
+    keep = B.batched_nms(T(boxes), T(scores), T(idxs), 0.5).cpu().numpy()
+    assert np.array_equal(keep, tv.batched_nms(boxes, scores, idxs, 0.5))
+
+
 @pytest.mark.parametrize("k", [1, 5, 90, 1203])
 def test_batched_nms_gpu(k):
     from object_detectors_amd.tvision import boxes as B

@@ -126,7 +126,8 @@ def test_head_conv_f32_bias_255():
     assert (db.cpu() - br.grad).abs().max().item() < 1e-2 * br.grad.abs().max().item()
 
 
-@pytest.mark.parametrize("c,pixels,res", [(32, 1000, False), (64, 4096, True), (256, 777, True), (1024, 300, False)])
+@pytest.mark.parametrize("c,pixels,res", [(32, 1000, False), (64, 4096, True), (256, 777, True), (1024, 300, False),
+                                          (24, 500, False), (96, 1500, True), (328, 600, False), (2056, 130, True)])      # channel counts that are not 8 * 2^k
 def test_bn_lrelu_fwd_bwd(c, pixels, res):
     from object_detectors_amd._lib import check, lib, ptr, stream_ptr
     z = rnd((pixels, c), 11, 2.0) + 0.3

@@ -181,6 +181,20 @@ def test_nms_majority_equal_scores_radix_path():
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_nms_majority_beyond_one_sort_chunk():
+    """helper.nms_majority has no size cap in the reference (helper.py:280-382): 20 000 boxes go through the chunk sorts + merge by rank;
+    quantised scores put equal-score runs across the chunk border."""
+    n = 20000
+    c = detrand.uniform(91, (n, 2), 40, 4000)
+    s = np.exp(detrand.uniform(92, (n, 2), np.log(8), np.log(250))).astype(np.float32)
+    sc = (np.floor(detrand.uniform(93, (n, 1), 0.1, 1) * 64) / 64).astype(np.float32)
+    P = np.concatenate([c - s / 2, c + s / 2, sc, detrand.randint(94, (n, 1), 0, 20).astype(np.float32)], 1).astype(np.float32)
+    from object_detectors_amd.yolo.utilities import helper
+    out = helper.nms_majority(torch.from_numpy(P.copy()).to(dev()), 0.6)
+    ref, _ = yo.nms_majority(P, 0.6)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
 def test_postprocess_gpu(golden):
     from object_detectors_amd.yolo.procedures.test_one_epoch import postprocess
     g = golden("g11_postproc")
