@@ -753,6 +753,44 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
   }
 }
 
+
+// ---- class-concatenated form of the 3x3 / stride-2 data gradient ("s2cat") ------------------------------------------------------------
+// The four output-parity classes of a stride-2 data gradient read the SAME dy lattice pixels (offsets oy, ox in {0, 1}) with different taps.
+// Run as four implicit GEMMs they have N = Cin (64 for the 64->128 layer: narrow tiles), K = 1, 2, 2, 4 taps and four launches, and
+// they take 2-3x the forward time of the same layer.  Concatenating the classes of one output-row parity py along N gives two GEMMs
+//   py = 0:  N = (px, ci) = 2*Cin,  K = (ox, co)     = 2*Cout      dx rows 2*yy
+//   py = 1:  N = (px, ci) = 2*Cin,  K = (oy, ox, co) = 4*Cout      dx rows 2*yy + 1
+// whose output row for lattice pixel (yy, xx) is 2*Cin CONTIGUOUS values - dx pixels (2xx, 2xx+1) - so the ordinary epilogue writes it
+// with y stride 2 and x stride 1 on the view [n, 2Ho, Wo, 2*Cin].  The weight matrix has zero blocks where a class does not use an
+// offset (px = 0 never looks at ox = 1, py = 0 never at oy = 1): 12 blocks are multiplied for 9 that carry weights (1.33x the FLOPs), at the
+// rate of the wide tiles instead of the narrow ones.  Chosen per shape by the autotuner against the four class launches.
+__host__ __device__ inline int s2cat_k(int parity, int off) {      // kernel row / column a class of this parity reads at lattice offset `off`, or -1
+  return parity == 0 ? (off == 0 ? 1 : -1) : (off == 0 ? 2 : 0);
+}
+static bool s2cat_eligible(const mi355det_conv_shape* s) {
+  return s->ksize == 3 && s->stride == 2 && s->pad == 1 && !(s->h & 1) && !(s->w & 1) && (s->cin == 64 || s->cin == 128) && s->cout % 64 == 0 &&
+         s->in_ld == s->cin;
+}
+static size_t s2cat_elems(const mi355det_conv_shape* s) { return s2cat_eligible(s) ? (size_t)12 * s->cin * s->cout : 0; }
+static size_t dgrad_class_elems(const mi355det_conv_shape* s) { return (size_t)((s->cin + 31) / 32 * 32) * (size_t)(s->ksize * s->ksize) * (size_t)s->cout; }
+
+// out: [py = 0: [2*cin][2][cout]] then [py = 1: [2*cin][4][cout]]
+__global__ void pack_s2cat_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int cin, long long s_co, long long s_ci, long long s_t) {
+  const long long n0 = (long long)2 * cin * 2 * cout, total = n0 + (long long)2 * cin * 4 * cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int py = i >= n0;
+    const long long j = py ? i - n0 : i;
+    const int T = py ? 4 : 2;
+    const int co = (int)(j % cout), tap = (int)((j / cout) % T), r = (int)(j / ((long long)cout * T));
+    const int px = r / cin, ci = r - px * cin;
+    const int oy = py ? tap >> 1 : 0, ox = py ? tap & 1 : tap;
+    const int kh = s2cat_k(py, oy), kw = s2cat_k(px, ox);
+    float v = 0.f;
+    if (kh >= 0 && kw >= 0) v = w[co * s_co + ci * s_ci + (kh * 3 + kw) * s_t];
+    out[i] = f2bf(v);
+  }
+}
+
 bf16_t* g_zero_page = nullptr;
 
 int ensure_zero_page() {
@@ -811,13 +849,14 @@ unsigned long long igemm_key(const IgemmParams& p, int epi) {
   k = k * 4099 + p.Cin;
   k = k * 31 + p.T;
   k = k * 7 + p.sin * 2 + p.so;
+  k = k * 3 + p.sox;
   k = k * 5 + epi;
   return k;
 }
 
 // applicability of the dx-reuse kernel: 3x3, unit strides on both sides, taps in three rows of equal dy with dx stepping by +-1
 static bool dx_applicable(const IgemmParams& p, int bn = 128, int bk = 64) {
-  if (p.T != 9 || p.so != 1 || p.sin != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
+  if (p.T != 9 || p.so != 1 || p.sox != 0 || p.sin != 1 || p.oy0 != 0 || p.ox0 != 0) return false;
   if (p.Hin != p.Hout || p.Win != p.Wout || p.MH != p.Hin || p.MW != p.Win) return false;
   if (p.Cin % bk != 0 || p.CoutPad % bn != 0) return false;
   for (int g = 0; g < 3; ++g) {
@@ -1013,12 +1052,14 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(bf16_t* __restrict__ 
 }
 
 bool g_autotune_mode = false;   // set by mi355det_conv_autotune around a regular entry-point call
+std::unordered_map<unsigned long long, int> g_s2cat_tuned;   // stride-2 data gradient: 1 = class-concatenated form, 0 = four class launches
+int g_s2cat_force = -1;          // mi355det_debug_set(5, v): force a form (tests compare the two)
 
 template <int EPI>
 int dispatch_igemm(const IgemmParams& p_in, hipStream_t st) {
   IgemmParams p = p_in;
   p.lin_in = p.T == 1 && p.dy[0] == 0 && p.dx[0] == 0 && p.sin == 1 && p.MH == p.Hin && p.MW == p.Win;
-  p.lin_out = p.so == 1 && p.oy0 == 0 && p.ox0 == 0 && p.MH == p.Hout && p.MW == p.Wout;
+  p.lin_out = p.so == 1 && p.sox == 0 && p.oy0 == 0 && p.ox0 == 0 && p.MH == p.Hout && p.MW == p.Wout;
   return g_autotune_mode ? autotune_igemm<EPI>(p, st) : launch_igemm<EPI>(p, st);
 }
 
@@ -1059,6 +1100,7 @@ int mi355det_debug_set(int key, int value) {
   if (key == 1) g_wgrad_general = value;
   if (key == 2) g_dgrad_s2_off = value;
   if (key == 3) igemm8_set_dbg_mode(value);      // 1 = phase stamps, 2 = k-step starts only (tools/prof_ig8.py)
+  if (key == 5) g_s2cat_force = value;           // stride-2 data gradient: 1 = class-concatenated form, 0 = four class launches, -1 = tuned choice
   return 0;
 }
 
@@ -1166,8 +1208,9 @@ static int dgrad_taps(const mi355det_conv_shape* s, int py, int px, int* fwd_tap
 
 size_t mi355det_dgrad_pack_elems(const mi355det_conv_shape* s) {
   if (!s) return 0;
-  const size_t cin_pad = (size_t)((s->cin + 31) / 32 * 32);
-  return cin_pad * (size_t)(s->ksize * s->ksize) * (size_t)s->cout + 64;
+  mi355det_conv_shape d = *s;
+  d.in_ld = d.cin;                                       // sizes only: the class-concatenated pack exists for the shape, whatever pitch a call uses
+  return dgrad_class_elems(s) + s2cat_elems(&d) + 64;    // [four class packs | stride-2 concatenated packs | slack]
 }
 
 int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is_ohwi, void* w_fwd, int32_t cout_pad, void* w_dgrad,
@@ -1194,6 +1237,13 @@ int mi355det_pack_weights(const mi355det_conv_shape* s, const float* w, int w_is
                          cin_pad, kk, nt, s_co, s_ci, s_t, ft[0], ft[1], ft[2], ft[3], ft[4], ft[5], ft[6], ft[7], ft[8]);
       out += total;
     }
+    mi355det_conv_shape d = *s;
+    d.in_ld = d.cin;
+    if (s2cat_eligible(&d)) {
+      const long long total = (long long)12 * s->cin * s->cout;
+      hipLaunchKernelGGL(pack_s2cat_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), w,
+                         (bf16_t*)w_dgrad + dgrad_class_elems(s), s->cout, s->cin, s_co, s_ci, s_t);
+    }
   }
   return check_launch("pack_weights");
 }
@@ -1214,6 +1264,24 @@ struct PackEntry {
 __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __restrict__ entries, const int2* __restrict__ blocks) {
   const int2 bt = blocks[blockIdx.x];
   const PackEntry e = entries[bt.x];
+  if (e.mode == 2) {
+    // class-concatenated stride-2 data-gradient packs (pack_s2cat_kernel's layout): elementwise, two small layers per step
+    const long long n0 = (long long)2 * e.cin * 2 * e.cdim;
+    const int end = min(e.total, bt.y + PACK_CHUNK);
+    for (int i = bt.y + threadIdx.x; i < end; i += 256) {
+      const int py = i >= n0;
+      const long long j = py ? i - n0 : i;
+      const int T = py ? 4 : 2;
+      const int co = (int)(j % e.cdim), tap = (int)((j / e.cdim) % T), r = (int)(j / ((long long)e.cdim * T));
+      const int px = r / e.cin, ci = r - px * e.cin;
+      const int oy = py ? tap >> 1 : 0, ox = py ? tap & 1 : tap;
+      const int kh = s2cat_k(py, oy), kw = s2cat_k(px, ox);
+      float v = 0.f;
+      if (kh >= 0 && kw >= 0) v = e.src[co * e.s_co + ci * e.s_ci + (kh * 3 + kw) * e.s_t];
+      e.dst[i] = f2bf(v);
+    }
+    return;
+  }
   if (e.mode == 0) {
     // forward pack: the OHWI master is already K-contiguous -> linear, coalesced both ways
     const int end = min(e.total, bt.y + PACK_CHUNK);
@@ -1270,6 +1338,12 @@ size_t mi355det_pack_table_bytes(const mi355det_pack_item* items, int32_t n, int
         const int cob = s->cout % 64 == 0 ? 64 : 32;
         nb += (long long)nt * (cin_pad / 32) * (s->cout / cob);
       }
+      mi355det_conv_shape d = *s;
+      d.in_ld = d.cin;
+      if (s2cat_eligible(&d)) {
+        ++ne;
+        nb += ((long long)s2cat_elems(&d) + PACK_CHUNK - 1) / PACK_CHUNK;
+      }
     }
   }
   if (n_entries) *n_entries = ne;
@@ -1319,6 +1393,15 @@ int mi355det_pack_table_build(const mi355det_pack_item* items, int32_t n, void* 
         ++ei;
         out += e.total;
       }
+      mi355det_conv_shape d = *s;
+      d.in_ld = d.cin;
+      if (s2cat_eligible(&d)) {
+        PackEntry& e = E[ei];
+        e = PackEntry{};
+        e.src = items[i].w; e.dst = (bf16_t*)items[i].w_dgrad + dgrad_class_elems(s); e.s_co = s_co; e.s_ci = s_ci; e.s_t = s_t;
+        e.total = (int)s2cat_elems(&d); e.cin = s->cin; e.cdim = s->cout; e.mode = 2;
+        add_blocks(ei++, e.total);
+      }
     }
   }
   return 0;
@@ -1354,6 +1437,75 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
   const int cin_pad = (s->cin + 31) / 32 * 32;
   const bf16_t* wp = (const bf16_t*)wt;
   const int classes = s->stride == 1 ? 1 : 4;
+  if (!partials && s2cat_eligible(s) && (!residual || residual_ld == s->cin)) {
+    // class-concatenated form (two wide GEMMs) or the four class launches: per shape, whichever the plan-build timing found faster
+    const unsigned long long key = ((((unsigned long long)s->n * 4099 + s->h) * 4099 + s->w) * 4099 + s->cin) * 4099 + s->cout + (residual ? 1ull << 62 : 0);
+    int choice = -1;
+    auto it = g_s2cat_tuned.find(key);
+    if (it != g_s2cat_tuned.end()) choice = it->second;
+    if (g_s2cat_force >= 0) choice = g_s2cat_force;
+    auto run_cat = [&]() -> int {
+      const bf16_t* wc = (const bf16_t*)wt + dgrad_class_elems(s);
+      for (int py = 0; py < 2; ++py) {
+        IgemmParams p{};
+        p.T = py ? 4 : 2;
+        for (int t = 0; t < p.T; ++t) {
+          p.dy[t] = py ? t >> 1 : 0;
+          p.dx[t] = py ? t & 1 : t;
+        }
+        p.x = (const bf16_t*)dy;
+        p.w = wc;
+        p.y = dx;
+        p.res = (const bf16_t*)residual;
+        p.ldres = 2 * s->cin;
+        p.zero = g_zero_page;
+        p.MH = s->ho; p.MW = s->wo;
+        p.M = s->n * s->ho * s->wo;
+        p.Hin = s->ho; p.Win = s->wo; p.ldin = s->out_ld; p.Cin = s->cout; p.sin = 1;
+        p.Hout = s->h; p.Wout = s->wo; p.ldout = 2 * s->cin;       // view [n, h, wo, 2*cin] of dx: a row of the view = the two pixels 2xx, 2xx+1
+        p.so = 2; p.sox = 1; p.oy0 = py; p.ox0 = 0;
+        p.Cout = 2 * s->cin; p.CoutPad = 2 * s->cin;
+        p.dMW = make_fastdiv((unsigned)p.MW);
+        p.dMH = make_fastdiv((unsigned)p.MH);
+        set_tap_pad(p);
+        const int e = residual ? dispatch_igemm<EPI_RES>(p, S(stream)) : dispatch_igemm<EPI_PLAIN>(p, S(stream));
+        if (e < 0) return e;
+        wc += (size_t)2 * s->cin * p.T * s->cout;
+      }
+      return 0;
+    };
+    if (g_autotune_mode && g_s2cat_force < 0) {
+      // time both forms (each tunes its own tiles first); the output stays valid either way
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_dgrad");
+      float ms[2] = {0.f, 0.f};
+      for (int form = 0; form < 2; ++form) {
+        g_s2cat_force = form;
+        int e = conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, nullptr, 0, nullptr, 0.f, nullptr, stream);      // tunes the tiles of this form
+        g_autotune_mode = false;
+        if (!e) {
+          (void)hipEventRecord(e0, S(stream));
+          for (int r = 0; r < 3 && !e; ++r) e = conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, nullptr, 0, nullptr, 0.f, nullptr, stream);
+          (void)hipEventRecord(e1, S(stream));
+          (void)hipEventSynchronize(e1);
+          (void)hipEventElapsedTime(&ms[form], e0, e1);
+        }
+        g_autotune_mode = true;
+        g_s2cat_force = -1;
+        if (e) return e;
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      choice = ms[1] < ms[0] ? 1 : 0;
+      g_s2cat_tuned[key] = choice;
+      static const bool tune_log = getenv("MI355DET_TUNE_LOG") != nullptr;
+      if (tune_log) fprintf(stderr, "[mi355det] stride-2 dgrad %d->%d @%dx%d: four classes %.1f us, concatenated %.1f us\n", s->cin, s->cout, s->h, s->w,
+                            ms[0] * 1e3f / 3.f, ms[1] * 1e3f / 3.f);
+      if (choice == 1) return run_cat();       // leave the output of the chosen form (identical up to summation order)
+    } else if (choice == 1) {
+      return run_cat();
+    }
+  }
   for (int c = 0; c < classes; ++c) {
     IgemmParams p{};
     int ft[9];

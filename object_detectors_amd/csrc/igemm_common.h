@@ -44,6 +44,7 @@ struct IgemmParams {
   int M, MH, MW;         // lattice: M = N*MH*MW
   int Hin, Win, ldin, Cin, sin;
   int Hout, Wout, ldout, so, oy0, ox0;
+  int sox;               // output stride along x (0 = the same as `so`): the class-concatenated stride-2 data gradient steps 2 in y and 1 in x
   int Cout, CoutPad, ldres;
   int T;
   int dy[MAX_TAPS], dx[MAX_TAPS];
@@ -196,7 +197,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       if (m >= p.M) continue;
       const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
       const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
-      const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+      const int oy = yy * p.so + p.oy0, ox = xx * (p.sox ? p.sox : p.so) + p.ox0;
       if (oy >= p.Hout || ox >= p.Wout) continue;
       float* orow = (float*)p.y + (long long)n * p.ynstride + (long long)(oy * p.Wout + ox) * p.ldout;
 #pragma unroll
@@ -275,7 +276,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
         } else if (m < p.M && co < p.Cout) {
           const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
           const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
-          const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+          const int oy = yy * p.so + p.oy0, ox = xx * (p.sox ? p.sox : p.so) + p.ox0;
           if (oy < p.Hout && ox < p.Wout) pixi = (n * p.Hout + oy) * p.Wout + ox;
         }
         pixp[pass] = pixi;
@@ -290,7 +291,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       } else if (m < p.M) {
         const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
         const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
-        const int oy = yy * p.so + p.oy0, ox = xx * p.so + p.ox0;
+        const int oy = yy * p.so + p.oy0, ox = xx * (p.sox ? p.sox : p.so) + p.ox0;
         if (oy < p.Hout && ox < p.Wout) pixi = (n * p.Hout + oy) * p.Wout + ox;
       }
       rowpix[lane] = pixi;

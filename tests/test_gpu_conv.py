@@ -577,3 +577,40 @@ def test_phase_staggered_kernel_matches_default(case):
         assert float((dx8 - dx1).abs().max()) <= 1e-2 * float(dx1.abs().max()), cfg
         assert float((dxr8 - dxr1).abs().max()) <= 1e-2 * float(dxr1.abs().max()), cfg
         torch.testing.assert_close(st8, st1, rtol=2e-2, atol=2e-2 * float(st1.abs().max()))
+
+
+@pytest.mark.parametrize("case", [(2, 26, 26, 64, 128), (1, 16, 48, 128, 256), (3, 12, 20, 64, 64), (2, 40, 40, 128, 128)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_stride2_dgrad_class_concatenated_form(case, with_res):
+    """3x3 / stride-2 data gradient as two class-concatenated GEMMs (N = 2*Cin, y stride 2 / x stride 1 epilogue on the [n, h, w/2, 2*Cin]
+    view) against the four class launches and against PyTorch fp32, with and without the residual; both the single-call pack and the
+    batched pack table produce the concatenated weights."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout = case
+    x = rnd((n, cin, h, w), 31)
+    wt = rnd((cout, cin, 3, 3), 32, (2.0 / (cin * 9)) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt, stride=2, padding=1)
+    gy = rnd(tuple(y_ref.shape), 33)
+    y_ref.backward(gy)
+    res = rnd((n, cin, h, w), 34)
+    want = xr.grad + (res if with_res else 0)
+    shape = ops.conv_shape(n, h, w, cin, cout, 3, 2)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    gyd = nhwc(gy)
+    resd = nhwc(res) if with_res else None
+    outs = {}
+    try:
+        for form in (0, 1):
+            lib().mi355det_debug_set(5, form)
+            dx = torch.full((n, h, w, cin), 7.0, device=dev(), dtype=torch.bfloat16)
+            ops.conv_dgrad(shape, gyd, wd, dx, residual=resd, residual_ld=cin if with_res else 0)
+            torch.cuda.synchronize()
+            outs[form] = dx.float().cpu().permute(0, 3, 1, 2)
+    finally:
+        lib().mi355det_debug_set(5, -1)
+    scale = float(want.abs().max())
+    assert float((outs[0] - want).abs().max()) <= 2e-2 * scale
+    assert float((outs[1] - want).abs().max()) <= 2e-2 * scale
+    assert float((outs[1] - outs[0]).abs().max()) <= 1e-2 * scale
