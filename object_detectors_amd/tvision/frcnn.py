@@ -11,9 +11,10 @@ Where the work runs:
   * RPN / RoI target assignment: fused IoU+Matcher kernels (`tvision/rpn.py`, `tvision/roi_heads.py`); the samplers stay in torch
     (SURVEY 8 row a19);
   * MultiScaleRoIAlign forward/backward: `mi355det_roi_align`;
-  * TwoMLPHead / FastRCNNPredictor (frcnn.py:238-290) are plain dense GEMMs on [512*N, 12544]: `torch.nn.Linear` (rocBLAS/hipBLASLt,
-    the library path the MI355X rules reserve for plain GEMMs); their parameters are ordinary torch parameters, the backbone's live in
-    `model.engine.flat_w` (optimise with `optim.FlatSGD.for_engine(model.engine)` + a torch optimizer over `model.head_parameters()`).
+  * TwoMLPHead / FastRCNNPredictor (frcnn.py:238-290): `tvision/linear.py:MfmaLinear` - the library's MFMA 1x1-convolution kernels
+    (forward with bias / ReLU epilogue, data gradient, weight gradient) on [512*N, 12544] bf16 operands; their parameters are ordinary
+    fp32 torch parameters with nn.Linear's names, the backbone's live in `model.engine.flat_w` (optimise with
+    `optim.FlatSGD.for_engine(model.engine)` + a torch optimizer over `model.head_parameters()`).
 Inputs as in tvision/retinanet.py: a list of [3,H,W] images goes through the GPU GeneralizedRCNNTransform (generalized_rcnn.py:78-79,110), a ready
 [N,3,H,W] batch skips it.
 """
@@ -22,6 +23,7 @@ from torch import nn
 
 from .. import ops
 from ._utils import BoxCoder
+from .linear import MfmaLinear
 from .engine import IMAGE_MEAN, IMAGE_STD, FasterRCNNEngine
 from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals
 from .roi_align import MultiScaleRoIAlign
@@ -35,12 +37,12 @@ class TwoMLPHead(nn.Module):
 
     def __init__(self, in_channels, representation_size):
         super().__init__()
-        self.fc6 = nn.Linear(in_channels, representation_size)
-        self.fc7 = nn.Linear(representation_size, representation_size)
+        self.fc6 = MfmaLinear(in_channels, representation_size, relu=True)          # F.relu(self.fc6(x)) with the ReLU in the GEMM epilogue
+        self.fc7 = MfmaLinear(representation_size, representation_size, relu=True)
 
     def forward(self, x):
         x = x.flatten(start_dim=1)
-        return torch.relu(self.fc7(torch.relu(self.fc6(x))))
+        return self.fc7(self.fc6(x))
 
 
 class FastRCNNPredictor(nn.Module):
@@ -48,8 +50,8 @@ class FastRCNNPredictor(nn.Module):
 
     def __init__(self, in_channels, num_classes):
         super().__init__()
-        self.cls_score = nn.Linear(in_channels, num_classes)
-        self.bbox_pred = nn.Linear(in_channels, num_classes * 4)
+        self.cls_score = MfmaLinear(in_channels, num_classes)
+        self.bbox_pred = MfmaLinear(in_channels, num_classes * 4)
 
     def forward(self, x):
         if x.dim() == 4:

@@ -176,3 +176,34 @@ def test_select_training_samples_shapes(golden):
         np.testing.assert_allclose(reg[i].cpu().numpy(), want, rtol=1e-5, atol=1e-6)
         # every GT box was appended to the proposals, so each is its own perfect match and labelled with its class
         assert int((lab[i] > 0).sum()) >= 1
+
+
+@pytest.mark.parametrize("rows,fin,fout,relu", [(300, 12544, 1024, True), (2048, 1024, 1024, True), (257, 1024, 91, False), (512, 1024, 364, False)])
+def test_mfma_linear_matches_fp32_linear(rows, fin, fout, relu):
+    """Box-head layers (frcnn.py:243-289) on the library's MFMA kernels against F.linear in fp32 on the same bf16-rounded operands:
+    output, input gradient, weight and bias gradients; parameter names / shapes are nn.Linear's."""
+    import torch.nn.functional as F
+    from object_detectors_amd.tvision.linear import MfmaLinear
+    torch.manual_seed(rows + fout)
+    m = MfmaLinear(fin, fout, relu=relu).to(dev())
+    assert tuple(m.weight.shape) == (fout, fin) and tuple(m.bias.shape) == (fout,) and set(dict(m.named_parameters())) == {"weight", "bias"}
+    x = (torch.randn(rows, fin, device=dev()) * 0.5).bfloat16().float().requires_grad_(True)
+    g = torch.randn(rows, fout, device=dev()).bfloat16().float()
+    y = m(x)
+    y.backward(g)
+    wq = m.weight.detach().bfloat16().float().requires_grad_(True)
+    bq = m.bias.detach().clone().requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.linear(xr, wq, bq)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(g)
+    rel = lambda a, b: float((a.float() - b.float()).abs().max()) / (float(b.float().abs().max()) + 1e-30)
+    assert rel(y, yr) < 1.5e-2
+    assert rel(x.grad, xr.grad) < 2e-2
+    assert rel(m.weight.grad, wq.grad) < 2e-2 and rel(m.bias.grad, bq.grad) < 2e-2
+    # a parameter update invalidates the cached packs
+    with torch.no_grad():
+        m.weight.mul_(2.0)
+    y2 = m(x.detach())
+    assert rel(y2, torch.relu(F.linear(x.detach(), wq.detach() * 2, bq.detach())) if relu else F.linear(x.detach(), wq.detach() * 2, bq.detach())) < 1.5e-2
