@@ -162,6 +162,23 @@ def box_iou(boxes1, boxes2):
     return out
 
 
+def nms_raw(boxes, scores, iou_threshold, idxs=None):
+    """nms / batched_nms without the host round trip: (keep [n] int64 - only the first `count` entries are defined -, count [1] int32 on
+    the device).  Callers that post-process several images read all their counts with ONE transfer."""
+    boxes, scores = _f32c(boxes), _f32c(scores)
+    n = boxes.shape[0]
+    if idxs is not None:
+        idxs = idxs.to(torch.int64).contiguous()
+    keep = torch.zeros(max(n, 1), device=boxes.device, dtype=torch.int64)
+    cnt = torch.zeros(1, device=boxes.device, dtype=torch.int32)
+    if n:
+        wsb = lib().mi355det_nms_workspace(1, n)
+        ws = torch.empty(wsb, device=boxes.device, dtype=torch.uint8)
+        check(lib().mi355det_nms(ptr(boxes), ptr(scores), ptr(idxs), n, float(iou_threshold), ptr(keep), ptr(cnt), ptr(ws), wsb,
+                                 stream_ptr()), "nms")
+    return keep, cnt
+
+
 def nms(boxes, scores, iou_threshold, idxs=None):
     boxes, scores = _f32c(boxes), _f32c(scores)
     n = boxes.shape[0]

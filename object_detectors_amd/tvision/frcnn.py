@@ -159,8 +159,21 @@ class FasterRCNN(nn.Module):
         n = images.shape[0]
         if targets is not None and self.tfidf_mini_batch:         # roi_heads.py:801-809
             self.tfidf = minibatch_tfidf(targets, self.num_classes, self.tfidf_norm).to(images.device).float().reshape(1, -1)
+        rpn_side = None
+        if self.training:
+            # RPN target assignment + sampling (rpn.py:179-213,296-300) need only the anchors and the ground truth, and they are host-bound
+            # (the RNG sampler reads counts back): issue them on a side stream so that they run under the network forward instead of after it
+            plan0 = self.engine.plan(images.shape[0], images.shape[2], images.shape[3], True)
+            cur = torch.cuda.current_stream(images.device)
+            if not hasattr(self, "_tgt_stream"):
+                self._tgt_stream = torch.cuda.Stream(device=images.device)
+            self._tgt_stream.wait_stream(cur)
         out = self.engine.forward(images, training=self.training)
         plan = self.engine._last_plan
+        if self.training:
+            assert plan is plan0
+            with torch.cuda.stream(self._tgt_stream):
+                rpn_side = self.rpn_targets.prepare([plan.anchors] * n, targets)
         boxes, _scores = self._proposals(out, plan, image_shapes)
         feats = self.engine.feature_maps_nhwc(4)       # the engine's bf16 NHWC buffers themselves
         if not self.training:
@@ -176,7 +189,8 @@ class FasterRCNN(nn.Module):
         # ---- training: RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient)
         obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
         dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
-        rpn_losses = self.rpn_targets.losses(obj, dl, [plan.anchors] * n, targets)
+        torch.cuda.current_stream(images.device).wait_stream(self._tgt_stream)
+        rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
         # ---- RoI heads (roi_heads.py:783-848): sample, pool, two FC layers, predictor, Fast R-CNN loss
         proposals, _mi, labels, reg_targets = self.roi_targets.select_training_samples([b.detach() for b in boxes], targets)
         x = self.box_roi_pool.forward_nhwc(feats, proposals, image_shapes)

@@ -29,16 +29,30 @@ def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_le
     batch = torch.arange(num_images, device=proposals.device)[:, None]
     obj = torch.sigmoid(objectness[batch, top_idx])
     props = proposals[batch, top_idx]
+    # rpn.py:259-280 per image: clip, drop boxes smaller than min_size and scores below score_thresh, per-level NMS, first post_nms_top_n.
+    # The two filters run as a MASK here (score -> -inf) instead of a compaction: a dropped box ranks below every surviving one, so it can
+    # never suppress one, and in the kept list (descending score) the survivors come first - the result is the reference's, but nothing has
+    # a data-dependent shape until the very end, and the counts of ALL images are read with one device-to-host transfer (the per-image
+    # compactions cost three synchronisations per image: 3.1 ms of a 17 ms step at batch 4).
+    hw = torch.tensor([[float(s[1]), float(s[0])] for s in image_shapes], device=props.device, dtype=props.dtype)      # (w, h) per image
+    lim = hw.repeat(1, 2)[:, None, :]                                                                                   # [N, 1, 4] = w, h, w, h
+    boxes = torch.minimum(props.clamp(min=0), lim)
+    ws, hs = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
+    valid = (ws >= min_size) & (hs >= min_size) & (obj >= score_thresh)
+    masked = torch.where(valid, obj, torch.full_like(obj, float("-inf")))
+    keeps, counts = [], []
+    ar = torch.arange(boxes.shape[1], device=props.device)
+    for i in range(num_images):
+        keep, cnt = ops.nms_raw(boxes[i], masked[i], nms_thresh, idxs=levels[i])
+        good = (ar < cnt) & valid[i][keep.clamp(max=boxes.shape[1] - 1)]
+        keeps.append(keep)
+        counts.append(good.sum())
+    counts = torch.stack(counts).clamp(max=post_nms_top_n).tolist()           # the one synchronisation of the proposal filter
     final_boxes, final_scores = [], []
-    for boxes, scores, lvl, shape in zip(props, obj, levels, image_shapes):
-        boxes = box_ops.clip_boxes_to_image(boxes, shape)
-        keep = box_ops.remove_small_boxes(boxes, min_size)
-        boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
-        keep = torch.where(scores >= score_thresh)[0]
-        boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
-        keep = box_ops.batched_nms(boxes, scores, lvl, nms_thresh)[:post_nms_top_n]
-        final_boxes.append(boxes[keep])
-        final_scores.append(scores[keep])
+    for i in range(num_images):
+        k = keeps[i][:counts[i]]
+        final_boxes.append(boxes[i][k])
+        final_scores.append(obj[i][k])
     return final_boxes, final_scores
 
 

@@ -46,6 +46,22 @@ class RPNTargets:
         objectness_loss = F.binary_cross_entropy_with_logits(objectness[sampled], labels[sampled])
         return objectness_loss, box_loss
 
+    def prepare(self, anchors, targets):
+        """Everything of the RPN loss that does not depend on the network outputs: labels, regression targets, sampled indices."""
+        labels, matched = self.assign_targets_to_anchors(anchors, targets)
+        reg = self.box_coder.encode(matched, anchors)
+        pos, neg = self.fg_bg_sampler(labels)
+        pos = torch.where(torch.cat(pos, dim=0))[0]
+        neg = torch.where(torch.cat(neg, dim=0))[0]
+        return dict(pos=pos, sampled=torch.cat([pos, neg], dim=0), labels=torch.cat(labels, dim=0), reg=torch.cat(reg, dim=0))
+
+    def losses_prepared(self, objectness, pred_bbox_deltas, prep):
+        """compute_loss (rpn.py:282-318) on the indices / targets of prepare()."""
+        pos, sampled = prep["pos"], prep["sampled"]
+        box_loss = F.smooth_l1_loss(pred_bbox_deltas[pos], prep["reg"][pos], beta=1 / 9, reduction="sum") / sampled.numel()
+        objectness_loss = F.binary_cross_entropy_with_logits(objectness.flatten()[sampled], prep["labels"][sampled])
+        return {"loss_objectness": objectness_loss, "loss_rpn_box_reg": box_loss}
+
     def losses(self, objectness, pred_bbox_deltas, anchors, targets):
         """rpn.py:353-361: -> {'loss_objectness', 'loss_rpn_box_reg'}."""
         labels, matched = self.assign_targets_to_anchors(anchors, targets)

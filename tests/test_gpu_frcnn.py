@@ -13,6 +13,10 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
 
 
+def dev():
+    return torch.device("cuda:0")
+
+
 class FirstK:
     """deterministic stand-in for the RNG sampler (same rule as tools/make_golden.py:g13_frcnn)."""
 
