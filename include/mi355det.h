@@ -354,6 +354,14 @@ int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_
                          const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var,
                          float* scale_shift /* [4*c]: scale, shift, mean, invstd */, void* stream);
+/* SyncBN forward (apex convert_syncbn_model, yolo/procedures/initialize.py:31-32): the per-rank partial rows are folded in double
+ * (exactly bn_finalize's own accumulation) into sums64 [2][c_pad] = (sum x | sum x*x), which the caller all-reduces as fp64 across the
+ * ranks; bn_finalize_f64 then produces the same scale / shift / running statistics bn_finalize would from the global batch
+ * (count = global element count per channel).  stats needs the 64 spare rows like bn_finalize. */
+int mi355det_bn_fold_partials_f64(const float* stats, int32_t rows, int32_t c, int32_t c_pad, double* sums64, void* stream);
+int mi355det_bn_finalize_f64(const double* sums64, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var, float* scale_shift,
+                             void* stream);
 /* eval mode (model.eval(), test_one_epoch.py:10): scale/shift from the running statistics */
 int mi355det_bn_eval_scale_shift(int32_t c, const float* gamma, const float* beta, const float* running_mean,
                                  const float* running_var, float eps, float* scale_shift, void* stream);

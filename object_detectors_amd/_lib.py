@@ -95,6 +95,8 @@ PROTOTYPES = {
     "mi355det_stem_bwd_apply_wgrad": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "mi355det_bn_eval_scale_shift": (C.c_int, [i32, vp, vp, vp, vp, f32, vp, vp]),
+    "mi355det_bn_fold_partials_f64": (C.c_int, [vp, i32, i32, i32, vp, vp]),
+    "mi355det_bn_finalize_f64": (C.c_int, [vp, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "mi355det_conv_dgrad_bn_rows": (C.c_int, [P(ConvShape)]),
     "mi355det_conv_dgrad_bn": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp, i32, vp, C.c_float, vp, vp]),
     "mi355det_bn_bwd_sum_partials": (C.c_int, [vp, i32, i32, i32, vp, vp]),

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/mi355det.h"
 
 #define WAVE 64
@@ -68,5 +70,18 @@ __device__ __forceinline__ float ord2f(unsigned u) {
 }
 
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+// one-time-per-DEVICE guard for hipFuncSetAttribute: the attribute lives in the device's copy of the code object, so a process that uses a
+// second GPU must set it there too (a process-wide flag left kernels with > 64 KB of dynamic LDS unlaunchable on cuda:1); atomic, so two
+// host threads may race through it
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long b = 1ull << (d & 63);
+    return (mask.fetch_or(b) & b) == 0;
+  }
+};
 
 }  // namespace mi355

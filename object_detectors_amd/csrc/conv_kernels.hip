@@ -814,10 +814,9 @@ int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
   constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
   auto k = igemm_kernel<WM, WN, TM, TN, BK, NST, EPI, PROF, ILV, OCC, ABL>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm");
@@ -831,10 +830,9 @@ int launch_il(const IgemmParams& p, hipStream_t st) {
   constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
   auto k = igemm_il_kernel<WM, WN, TM, TN, BK, EPI, SCHED>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm_il");
@@ -881,10 +879,9 @@ int launch_dx(const IgemmParams& p_in, hipStream_t st) {
   constexpr int lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
   auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB, PROF, BK>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm_dx");

@@ -227,10 +227,9 @@ int launch(const DgradS2Params& p, int cin, hipStream_t st) {
   const int per_cu = NCH == 1 ? 2 : 1;
   const int gx = min(p.ntiles, max(1, 256 * per_cu / (cin / 32)));   // persistent: one resident round over both channel halves
   auto go = [&](auto kern) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_done;
+    if (attr_done.first()) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(gx, cin / 32), dim3(256), lds, st, p);
   };

@@ -101,6 +101,53 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
+// SyncBN forward: the same fold as bn_finalize_kernel's first half (double accumulation over the partial rows), but the per-channel
+// sums leave as doubles so that the cross-rank all-reduce and the finalisation keep the local path's precision
+// (sums64 [2][c_pad]: sum x | sum x*x)
+__global__ __launch_bounds__(256) void bn_fold_f64_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, double* __restrict__ sums64) {
+  __shared__ double sh[8][32][2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  double s1 = 0, s2 = 0;
+  if (ch < c)
+    for (int r = rl; r < rows; r += 8) {
+      s1 += (double)partial[(size_t)r * 2 * c_pad + ch];
+      s2 += (double)partial[(size_t)r * 2 * c_pad + c_pad + ch];
+    }
+  sh[rl][cl][0] = s1;
+  sh[rl][cl][1] = s2;
+  __syncthreads();
+  if (rl == 0 && ch < c_pad) {
+    for (int r = 1; r < 8; ++r) {
+      s1 += sh[r][cl][0];
+      s2 += sh[r][cl][1];
+    }
+    sums64[ch] = ch < c ? s1 : 0.0;
+    sums64[c_pad + ch] = ch < c ? s2 : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_f64_kernel(const double* __restrict__ sums64, int c, int c_pad, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ ss) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const double mean = sums64[ch] / count;
+  double var = sums64[c_pad + ch] / count - mean * mean;
+  if (var < 0) var = 0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * invstd;
+  ss[ch] = sc;
+  ss[c + ch] = beta[ch] - (float)mean * sc;
+  ss[2 * c + ch] = (float)mean;
+  ss[3 * c + ch] = invstd;
+  if (rmean) {
+    rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+  }
+}
+
 // final stage of the fused BN-backward reduction: [rows<=256][2][c_pad] -> sums[2*c] (sum dy | sum dy*xhat)
 __global__ __launch_bounds__(256) void bn_bwd_sum_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, float* __restrict__ sums) {
   __shared__ float sh[8][32][2];
@@ -589,6 +636,27 @@ int mi355det_bn_bwd_sum_partials(const float* partials, int32_t rows, int32_t c,
   }
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((c + 31) / 32), dim3(256), 0, S(stream), partials, rows, c, c_pad, sums);
   return check_launch("bn_bwd_sum_partials");
+}
+
+int mi355det_bn_fold_partials_f64(const float* stats, int32_t rows, int32_t c, int32_t c_pad, double* sums64, void* stream) {
+  if (c <= 0 || rows <= 0 || c_pad < c || !stats || !sums64) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_fold_partials_f64");
+  if (rows > 256) {
+    const int chunks = 64, chunk = (rows + chunks - 1) / chunks;
+    float* scratch = const_cast<float*>(stats) + (size_t)rows * 2 * c_pad;       // the 64 spare rows behind the partials, as bn_finalize
+    hipLaunchKernelGGL(bn_partial_kernel, dim3((c_pad + 31) / 32, chunks), dim3(256), 0, S(stream), stats, rows, c_pad, chunk, scratch);
+    stats = scratch;
+    rows = chunks;
+  }
+  hipLaunchKernelGGL(bn_fold_f64_kernel, dim3((c_pad + 31) / 32), dim3(256), 0, S(stream), stats, rows, c, c_pad, sums64);
+  return check_launch("bn_fold_partials_f64");
+}
+
+int mi355det_bn_finalize_f64(const double* sums64, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
+  if (c <= 0 || c_pad < c || count <= 0 || !sums64) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize_f64");
+  hipLaunchKernelGGL(bn_finalize_f64_kernel, dim3((c + 255) / 256), dim3(256), 0, S(stream), sums64, c, c_pad, (double)count, gamma, beta, eps, momentum,
+                     running_mean, running_var, scale_shift);
+  return check_launch("bn_finalize_f64");
 }
 
 int mi355det_bn_eval_scale_shift(int32_t c, const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,

@@ -458,22 +458,20 @@ int launch8(const IgemmParams& p, hipStream_t st) {
   if (EPI == EPI_STATS && g_sk_dbg) {
     // diagnostic builds (tools/prof_ig8.py): [64 workgroups][8 waves][24] u64; mode 1 = phase stamps, 2 = k-step starts only
     sk.dbg = g_sk_dbg;
-    static bool attr_done_p = false;
-    if (!attr_done_p) {
+    static DeviceOnce attr_done_p;
+    if (attr_done_p.first()) {
       (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
       (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-      attr_done_p = true;
     }
     if (g_sk_dbg_mode >= 3) {
-      static bool attr_done_a = false;
-      if (!attr_done_a) {
+      static DeviceOnce attr_done_a;
+      if (attr_done_a.first()) {
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-        attr_done_a = true;
       }
       if (g_sk_dbg_mode == 3) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 3>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       else if (g_sk_dbg_mode == 4) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 4>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
@@ -488,10 +486,9 @@ int launch8(const IgemmParams& p, hipStream_t st) {
     return check_launch("igemm8_prof");
   }
   auto k = igemm8_kernel<EPI>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-    attr_done = true;
   }
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(512), kLDS, st, p, sk);
   return check_launch("igemm8");

@@ -585,10 +585,9 @@ int mi355det_topk(const float* x, int32_t rows, int64_t n, int64_t row_stride, i
                   int32_t* count_out, void* stream) {
   if (rows <= 0 || n <= 0 || k <= 0 || k > TOPK_MAXK || n >= (1ll << 32)) return fail(MI355DET_EINVAL, "%s: need 1 <= k <= 16384 and n < 2^32", "topk");
   const int lds = TOPK_MAXK * 8;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(TOPK_THREADS), lds, S(stream), x, (long long)n, (long long)row_stride, k, min_value,
                      (long long*)idx_out, val_out, count_out);
@@ -613,11 +612,10 @@ int mi355det_topk_ws(const float* x, int32_t rows, int64_t n, int64_t row_stride
   hipLaunchKernelGGL(topk_hist_kernel<2>, grid, dim3(1024), 0, st, x, (long long)n, (long long)row_stride, k, min_value, states);
   hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(1024), 0, st, x, (long long)n, (long long)row_stride, k, min_value, states, cand);
   const int lds = TOPK_MAXK * 8;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)topk_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL(topk_finish_kernel, dim3(rows), dim3(TOPK_THREADS), lds, st, k, states, cand, (long long*)idx_out, val_out, count_out);
   // rows whose threshold value repeats more often than the candidate list holds: exact redo by the one-workgroup form (exits at once otherwise)

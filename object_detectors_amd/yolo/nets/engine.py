@@ -102,6 +102,13 @@ class YoloV3Engine:
         forward and one of (sum dy, sum dy*xhat) in backward per layer (2C floats each: latency-bound, 72 layers)."""
         lib()   # fail loudly if the HIP library is missing
         self.sync_bn, self.process_group = bool(sync_bn), process_group
+        if self.sync_bn and process_group is None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # the 2 x 72 small statistics all-reduces are BLOCKING steps of the forward / backward dependency chain: on their own
+                # communicator they do not queue behind the asynchronous gradient buckets of the default group (every rank constructs
+                # its engine at the same point, so this collective call is matched)
+                self.process_group = dist.new_group()
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.backbone, self.na, self.nc = backbone, num_anchors, num_classes
         self.head_c = num_anchors * (5 + num_classes)
@@ -425,14 +432,14 @@ class Plan:
             if world > 1:
                 # SyncBN: fold the partial rows into ONE row [sum | sum of squares] (the generic row reduction), all-reduce it, and
                 # finalise from that row with the global element count
-                row = torch.zeros((1, 2, cp), device=dev, dtype=torch.float32)
+                row = torch.zeros((2, cp), device=dev, dtype=torch.float64)      # folded, all-reduced and finalised in double (the local path's precision)
                 self.keep.append(row)
-                self.fwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(stats), rows, cp, cp, _vp(row), self.stream)))
+                self.fwd.append((L.mi355det_bn_fold_partials_f64, (_vp(stats), rows, shp.cout, cp, _vp(row), self.stream)))
                 self.fwd.append((comm_hook, (sync_sum, row)))
-                self.fwd.append((L.mi355det_bn_finalize, (_vp(row), 1, shp.cout, cp, pixels * world, _vp(eng.params[b + ".weight"]),
-                                                          _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
-                                                          _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
-                                                          _vp(ss), self.stream)))
+                self.fwd.append((L.mi355det_bn_finalize_f64, (_vp(row), shp.cout, cp, pixels * world, _vp(eng.params[b + ".weight"]),
+                                                              _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
+                                                              _vp(eng.buffers[b + ".running_mean"]), _vp(eng.buffers[b + ".running_var"]),
+                                                              _vp(ss), self.stream)))
             else:
                 self.fwd.append((L.mi355det_bn_finalize, (_vp(stats), rows, shp.cout, cp, pixels, _vp(eng.params[b + ".weight"]),
                                                           _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM,
@@ -548,11 +555,11 @@ class Plan:
             fin = (_vp(eng.params[b + ".weight"]), _vp(eng.params[b + ".bias"]), BN_EPS, BN_MOM, _vp(eng.buffers[b + ".running_mean"]),
                    _vp(eng.buffers[b + ".running_var"]), _vp(ss), self.stream)
             if self.sync_world > 1:
-                row = torch.zeros((1, 2, 32), device=dev, dtype=torch.float32)
+                row = torch.zeros((2, 32), device=dev, dtype=torch.float64)
                 self.keep.append(row)
-                self.fwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), rows, 32, 32, _vp(row), self.stream)))
+                self.fwd.append((L.mi355det_bn_fold_partials_f64, (_vp(part), rows, 32, 32, _vp(row), self.stream)))
                 self.fwd.append((comm_hook, (sync_sum, row)))
-                self.fwd.append((L.mi355det_bn_finalize, (_vp(row), 1, 32, 32, pixels * self.sync_world) + fin))
+                self.fwd.append((L.mi355det_bn_finalize_f64, (_vp(row), 32, 32, pixels * self.sync_world) + fin))
             else:
                 self.fwd.append((L.mi355det_bn_finalize, (_vp(part), rows, 32, 32, pixels) + fin))
         self.fwd.append(img_call(L.mi355det_stem_fwd_apply, (_vp(wf), _vp(ss), SLOPE, a.ptr, a.ld, n, H, W, self.stream)))

@@ -119,3 +119,41 @@ def test_gradsync_binds_each_plans_own_side_stream_and_attaches_to_engines():
         assert [h[1:3] for h in hooks] == [(200, 400), (0, 200)]
     sync.install(a)                                    # idempotent
     assert sum(1 for fn, _ in a.bwd if fn is comm_hook) == 2
+
+
+def _worker_paramsync(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_detectors_amd.parallel import ParamGradSync
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2), requires_grad=False),
+              torch.nn.Parameter(torch.zeros(4))]
+    params[0].grad = torch.full((5, 3), float(rank + 1))
+    params[1].grad = torch.arange(7.0) * (rank + 1)
+    params[3].grad = None                                  # a parameter without a gradient on this rank counts as zero
+    sync = ParamGradSync(params)
+    sync.reduce()
+    sync.wait()
+    ok = (torch.allclose(params[0].grad, torch.full((5, 3), 1.5)) and torch.allclose(params[1].grad, torch.arange(7.0) * 1.5)
+          and params[2].grad is None and torch.equal(params[3].grad, torch.zeros(4)))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_param_grad_sync_world2_gloo():
+    """ParamGradSync (the Faster R-CNN box-head parameters outside the engine's flat buffer, detection/train.py:160): one flattened
+    all-reduce, average written back into every .grad."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_paramsync, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _r, ok in res), res
