@@ -582,9 +582,10 @@ class Plan:
         # SLOWER end to end in round 1 (849 vs 871 img/s): the z tile is read at the tile's end where nothing hides the HBM latency.
         # Opt-in until the prefetch is moved into the last k-steps.
         self.fuse_bn_reduce = os.environ.get("MI355DET_BN_FUSION", "0") == "1"
-        self.side = torch.cuda.Stream(device=dev)
-        side_ptr = C.c_void_p(self.side.cuda_stream)
         main = torch.cuda.current_stream(dev)
+        # MI355DET_ONE_STREAM=1: every weight gradient on the step's own stream (A/B of the two-stream backward: profiles/r03_*)
+        self.side = main if os.environ.get("MI355DET_ONE_STREAM", "0") == "1" else torch.cuda.Stream(device=dev)
+        side_ptr = C.c_void_p(self.side.cuda_stream)
         wg_done = [None, None]        # event: last wgrad that read dz2[i]
         flip = [0]
 
