@@ -389,7 +389,8 @@ int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, i
  * im2col_nchw: NCHW fp32 image, optional per-channel (x-mean)*inv_std (GeneralizedRCNNTransform.normalize,
  *   tvision/transform.py:120-124) -> rows [n*ho*wo][kpad] bf16, k=(kh*ks+kw)*c+ch: the 7x7/2 stem (resnet.py:173) runs
  *   as a 1x1 convolution with cin=kpad on the MFMA path.
- * maxpool3x3s2: nn.MaxPool2d(3,2,1) (resnet.py:176).
+ * maxpool3x3s2: nn.MaxPool2d(3,2,1) (resnet.py:176); _bwd: its adjoint (gradient to the first maximum of every window, gather form,
+ *   deterministic) - needed when the 7x7 stem is trained (trainable_backbone_layers = 5, backbone_utils.py:100-104).
  * relu_affine_bwd: gm = (g1 [+g2]) * [a>0] (if relu), dz = gm * scale[c] (scale NULL = 1); gm / dz nullable.
  * upsample_nearest_add: out = lateral + interpolate(x, size=(out_h,out_w), nearest) (FPN top-down); _bwd its adjoint
  *   (out = accumulate + sum of g over the pixels that read it).
@@ -398,6 +399,8 @@ int mi355det_im2col_nchw(const float* img, const float* mean, const float* inv_s
                          int32_t h, int32_t w, int32_t ksize, int32_t stride, int32_t pad, int32_t kpad, void* stream);
 int mi355det_maxpool3x3s2(const void* x, int32_t x_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* out,
                           int32_t out_ld, void* stream);
+int mi355det_maxpool3x3s2_bwd(const void* x, int32_t x_ld, const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w,
+                              int32_t c, void* dx, int32_t dx_ld, void* stream);
 int mi355det_relu_affine_bwd(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* a, int32_t a_ld,
                              const float* scale, int32_t c, int64_t pixels, int relu, void* dz, int32_t dz_ld,
                              void* gm, int32_t gm_ld, void* stream);

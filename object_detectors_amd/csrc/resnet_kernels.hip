@@ -109,6 +109,51 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16_t* __restr
   }
 }
 
+// Backward of nn.MaxPool2d(3, 2, 1) as a GATHER (deterministic, no atomics): an input element receives the gradient of every output window
+// whose maximum it is - the FIRST maximum in the window's (kh, kw) scan, torch's index rule (the forward keeps `val > max`, so ties stay with
+// the earlier position).  An input pixel lies in at most 2 x 2 windows; each window's arg-max is re-derived from the forward input.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, int x_ld, const bf16_t* __restrict__ g, int g_ld, int n, int h,
+                                                                int w, int c, int ho, int wo, bf16_t* __restrict__ dx, int dx_ld) {
+  const int groups = c >> 3;
+  const long long total = (long long)n * h * w * groups;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int gq = (int)(i % groups);
+    const long long p = i / groups;
+    const int ix = (int)(p % w), iy = (int)((p / w) % h), b = (int)(p / ((long long)w * h));
+    const bf8 me = unpack8(*(const uint4*)(x + p * x_ld + gq * 8));
+    bf8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;      // windows with 2*o - 1 <= i <= 2*o + 1
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      if (oy >= ho) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        if (ox >= wo) continue;
+        const int my = iy - (2 * oy - 1), mx = ix - (2 * ox - 1);                          // this element's position in the window
+        bool win[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) win[j] = true;
+        for (int kh = 0; kh < 3; ++kh) {
+          const int yy = 2 * oy - 1 + kh;
+          if (yy < 0 || yy >= h) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int xx = 2 * ox - 1 + kw;
+            if (xx < 0 || xx >= w || (kh == my && kw == mx)) continue;
+            const bf8 v = unpack8(*(const uint4*)(x + ((long long)(b * h + yy) * w + xx) * x_ld + gq * 8));
+            const bool earlier = kh < my || (kh == my && kw < mx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) win[j] = win[j] && (earlier ? v.v[j] < me.v[j] : v.v[j] <= me.v[j]) ;
+          }
+        }
+        const bf8 gv = unpack8(*(const uint4*)(g + ((long long)(b * ho + oy) * wo + ox) * g_ld + gq * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] += win[j] ? gv.v[j] : 0.f;
+      }
+    }
+    *(uint4*)(dx + p * dx_ld + gq * 8) = pack8(acc);
+  }
+}
+
 __global__ __launch_bounds__(256) void relu_affine_bwd_kernel(const bf16_t* __restrict__ g1, int g1_ld, const bf16_t* __restrict__ g2, int g2_ld,
                                                                const bf16_t* __restrict__ a, int a_ld, const float* __restrict__ scale, int c,
                                                                long long pixels, int relu, bf16_t* __restrict__ dz, int dz_ld,
@@ -224,6 +269,15 @@ int mi355det_maxpool3x3s2(const void* x, int32_t x_ld, int32_t n, int32_t h, int
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((long long)n * ho * wo * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)x, x_ld, n, h, w, c,
                      ho, wo, (bf16_t*)out, out_ld);
   return check_launch("maxpool3x3s2");
+}
+
+int mi355det_maxpool3x3s2_bwd(const void* x, int32_t x_ld, const void* g, int32_t g_ld, int32_t n, int32_t h, int32_t w, int32_t c, void* dx,
+                              int32_t dx_ld, void* stream) {
+  if (c % 8 != 0 || !x || !g || !dx) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "maxpool3x3s2_bwd");
+  const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for((long long)n * h * w * (c / 8))), dim3(256), 0, S(stream), (const bf16_t*)x, x_ld,
+                     (const bf16_t*)g, g_ld, n, h, w, c, ho, wo, (bf16_t*)dx, dx_ld);
+  return check_launch("maxpool3x3s2_bwd");
 }
 
 int mi355det_relu_affine_bwd(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* a, int32_t a_ld, const float* scale,

@@ -44,11 +44,12 @@ class Conv:
 def arch(num_classes=91, num_anchors=9, trainable_layers=3, body="resnet50", model="retinanet"):
     """Ordered conv specs (reference state_dict order).  Frozen: everything in the body below the last
     `trainable_layers` of [layer4, layer3, layer2, layer1, conv1] (backbone_utils.py:100-104); BN is always frozen."""
-    if not 0 <= trainable_layers <= 4:
-        raise NotImplementedError("trainable_backbone_layers must be in [0,4] (5 would train the 7x7 stem through the max-pool)")
-    train = set(["layer4", "layer3", "layer2", "layer1"][:trainable_layers])
+    if not 0 <= trainable_layers <= 5:
+        raise ValueError("trainable_backbone_layers must be in [0,5]")          # backbone_utils.py:100 `assert 0 <= trainable_layers <= 5`
+    train = set(["layer4", "layer3", "layer2", "layer1", "conv1"][:trainable_layers])
     B = "backbone.body."
-    specs = [Conv(B + "conv1", STEM_K, 64, 1, 1, bn=B + "bn1", relu=True, trainable=False)]
+    # 5 also lists 'bn1' (backbone_utils.py:103-104), which is a FrozenBatchNorm2d: buffers only, nothing becomes trainable
+    specs = [Conv(B + "conv1", STEM_K, 64, 1, 1, bn=B + "bn1", relu=True, trainable="conv1" in train)]
     inpl = 64
     for li, (planes, nb) in enumerate(zip(PLANES, BODY_LAYERS[body]), 1):
         tr = f"layer{li}" in train
@@ -440,8 +441,9 @@ class RetinaPlan:
         self.fwd.append((L.mi355det_im2col_nchw, [None, _vp(eng.mean) if eng.normalize else None, _vp(eng.inv_std) if eng.normalize else None,
                                                   self.col.ptr, n, 3, H, W, 7, 2, 3, STEM_K, self.stream]))
         c1 = conv("backbone.body.conv1", self.col)
-        x = new_act(n, down(h2, 1), down(w2, 1), 64, False)
+        x = new_act(n, down(h2, 1), down(w2, 1), 64, c1.needs_grad)       # only a trained stem needs the gradient through the max-pool
         self.fwd.append((L.mi355det_maxpool3x3s2, (c1.ptr, c1.ld, n, c1.h, c1.w, 64, x.ptr, x.ld, self.stream)))
+        self.ops.append(dict(kind="maxpool", x=c1, a=x))
         feats = []
         for li, nb in enumerate(BODY_LAYERS[eng.body_name], 1):
             for b in range(nb):
@@ -604,6 +606,15 @@ class RetinaPlan:
                 x = rec["x"]
                 d = dense(x)                   # zeros except the sampled pixels
                 self.bwd.append((comm_hook, ((lambda d=d, g=g: d.buf[:, ::2, ::2].copy_(g.buf)),)))
+                add_tensor(x, d)
+                continue
+            if kind == "maxpool":
+                g = finalize(rec["a"])
+                if g is None:
+                    continue
+                x = rec["x"]
+                d = dense(x)
+                self.bwd.append((L.mi355det_maxpool3x3s2_bwd, (x.ptr, x.ld, g.ptr, g.ld, x.n, x.h, x.w, x.c, d.ptr, d.ld, self.stream)))
                 add_tensor(x, d)
                 continue
             if kind == "up_add":

@@ -197,3 +197,52 @@ def test_image_without_ground_truth(setup):
     losses = eng.train_step(x.to(dev()), both_empty)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(losses).all()) and float(losses[1]) == 0.0
+
+
+def test_trainable_layers_5_trains_the_stem_through_the_max_pool():
+    """trainable_backbone_layers = 5 (backbone_utils.py:100-104): conv1 (7x7/2) and layer1 receive gradients - through the new max-pool
+    backward (gradient to the first maximum of every 3x3 window) and FrozenBN + ReLU of the stem - against fp32 autograd of the oracle."""
+    from object_detectors_amd.tvision.engine import RetinaNetEngine
+    sd = ro.det_state(SEED)
+    eng = RetinaNetEngine(91, 9, 5, device=dev(), seed=0)
+    eng.load_reference_state_dict(sd)
+    assert all(s.trainable for s in eng.specs)
+    x = torch.from_numpy(detrand.uniform(4242, (BS, 3, PX, PX), 0.0, 1.0))
+    sdg, ref = _oracle_with_grads(eng, sd, x)
+    targets, gts = _targets()
+    eng.forward(x.to(dev()), training=True)
+    anchors = eng._last_plan.anchors.cpu().numpy()
+    cl, rl, _mis, (gc, gr) = tv.retinanet_loss(ref["cls_logits"].detach().numpy(), ref["bbox_regression"].detach().numpy(), anchors, gts)
+    ((ref["cls_logits"] * torch.from_numpy(gc)).sum() + (ref["bbox_regression"] * torch.from_numpy(gr)).sum()).backward()
+    eng.train_step(x.to(dev()), targets)
+    torch.cuda.synchronize()
+    got = eng.reference_state_dict(grads=True)
+    for k in ("backbone.body.conv1.weight", "backbone.body.layer1.0.conv1.weight", "backbone.body.layer1.0.downsample.0.weight",
+              "backbone.body.layer1.2.conv3.weight", "backbone.body.layer2.0.conv2.weight"):
+        g, r = got[k].cpu(), sdg[k].grad
+        c, ratio = cos(g, r), float(g.double().norm() / (r.double().norm() + 1e-30))
+        assert c > 0.99 and 0.95 < ratio < 1.05, (k, c, ratio)
+    with pytest.raises(ValueError):
+        RetinaNetEngine(91, 9, 6, device=dev(), seed=0)
+
+
+def test_maxpool_backward_matches_torch():
+    import ctypes as C
+    import torch.nn.functional as F
+    from object_detectors_amd._lib import check, lib
+    g = torch.Generator().manual_seed(5)
+    for (n, h, w, c) in [(2, 17, 23, 16), (1, 32, 32, 64)]:
+        x = torch.randn((n, c, h, w), generator=g).bfloat16().float()
+        x[:, :, 4:8, 4:8] = 0.5                                     # ties: the first maximum of a window takes the gradient
+        xr = x.clone().requires_grad_(True)
+        y = F.max_pool2d(xr, 3, 2, 1)
+        gy = torch.randn(tuple(y.shape), generator=g).bfloat16().float()
+        y.backward(gy)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev()).bfloat16()
+        gd = gy.permute(0, 2, 3, 1).contiguous().to(dev()).bfloat16()
+        dx = torch.full((n, h, w, c), 3.0, device=dev(), dtype=torch.bfloat16)
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        check(lib().mi355det_maxpool3x3s2_bwd(vp(xd), c, vp(gd), c, n, h, w, c, vp(dx), c, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "maxpool_bwd")
+        got = dx.float().cpu().permute(0, 3, 1, 2)
+        want = xr.grad.bfloat16().float()
+        assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max()), (n, h, w, c)
