@@ -278,6 +278,15 @@ int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int3
  *   stem_bwd_apply_wgrad dz = scale*(dy - mean dy - xhat*mean(dy*xhat)) feeds the weight-gradient MFMA directly:
  *                        dw[32][32] += dz^T * im2col (fixed order via slab[rows][1024]); dgamma += sums[32..63], dbeta += sums[0..31]
  * All four are fixed-order (bit-reproducible). */
+/* Stem activation + the first down-sampling convolution fused (csrc/stem_l1_kernels.hip; darknet.py:41-43,64-66,74-76): per 8 x 16 tile of
+ * z1 = layer1.ds_conv(a0) the kernel recomputes a0 = lrelu(bn1(conv1(img))) (scale_shift0 from mi355det_bn_finalize of stem_fwd_stats) into
+ * LDS and convolves it there (32 -> 64, 3x3, stride 2, pad 1; w1 = that layer's forward pack [64][9*32]).  Writes z1 (bf16 NHWC, pitch
+ * z1_ld >= 64), its BatchNorm partial statistics stats[rows + 64][2][64] (rows = mi355det_stem_l1_rows) and - when a0 != NULL - the
+ * activation itself (pitch a0_ld >= 32) for the layer's weight gradient.  Replaces stem_fwd_apply + conv_fwd of that layer in training.
+ * Needs h % 16 == 0 and w % 32 == 0. */
+int mi355det_stem_l1_rows(int32_t n, int32_t h, int32_t w);
+int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1, void* a0,
+                         int32_t a0_ld, void* z1, int32_t z1_ld, float* stats, int32_t n, int32_t h, int32_t w, void* stream);
 int mi355det_stem_rows(int32_t n, int32_t h, int32_t w);
 int mi355det_stem_fwd_stats(const float* img, const void* w, float* partial, int32_t n, int32_t h, int32_t wd, void* stream);
 int mi355det_stem_fwd_apply(const float* img, const void* w, const float* scale_shift, float slope, void* a, int32_t a_ld,

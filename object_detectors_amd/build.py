@@ -30,7 +30,8 @@ SOURCES = [
     ("wgrad_kernels.hip", []),
     ("dgrad_s2_kernels.hip", []),
     ("elem_kernels.hip", []),
-    ("stem_kernels.hip", ["-fno-slp-vectorize"]),     # packed fp32 adds cost more moves than they save (and 36 VGPRs)
+    ("stem_kernels.hip", ["-fno-slp-vectorize"]),
+    ("stem_l1_kernels.hip", ["-fno-slp-vectorize"]),     # packed fp32 adds cost more moves than they save (and 36 VGPRs)
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-x", "hip"]
 

@@ -397,7 +397,8 @@ class Plan:
         self._sync_avg = sync_avg
 
         # ---- forward graph
-        def conv_bn(name, x, out=None, res=None):
+        def conv_bn(name, x, out=None, res=None, fused=None):
+            """fused: (rows, emit(z, stats)) - a launch that produces this layer's z and partial statistics itself (stem + layer1.ds_conv)"""
             s = eng.by_name[name]
             shp = eng._wshape(s, x.n, x.h, x.w, in_ld=x.ld)
             x.conv_consumers += 1
@@ -425,10 +426,13 @@ class Plan:
                 return a
             shp.out_ld = shp.cout   # z pitch
             z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
-            rows = ops.conv_stats_rows(shp)
+            rows = fused[0] if fused else ops.conv_stats_rows(shp)
             stats = torch.zeros((rows + 64, 2, cp), device=dev, dtype=torch.float32)
             self.keep += [shp, z, stats, ss]
-            self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp), x.ptr, _vp(wf), None, _vp(z), 0, _vp(stats), cp, self.stream)))
+            if fused:
+                fused[1](z, stats)
+            else:
+                self.fwd.append((L.mi355det_conv_fwd, (C.byref(shp), x.ptr, _vp(wf), None, _vp(z), 0, _vp(stats), cp, self.stream)))
             if world > 1:
                 # SyncBN: fold the partial rows into ONE row [sum | sum of squares] (the generic row reduction), all-reduce it, and
                 # finalise from that row with the global element count
@@ -469,10 +473,11 @@ class Plan:
         # stem (darknet.py:41-43,74-76): recompute kernels straight from the fp32 image, no stored z / im2col matrix (csrc/stem_kernels.hip)
         self.img_args = []       # argument lists whose first entry is the image pointer of the current step
         x = self._stem(n, H, W, new_act, sync_sum)
+        stem_fused = self.layers["backbone.conv1"].get("fused_l1")
         feats = {}
         for li, nb in enumerate(BLOCKS[eng.backbone], 1):
             p = f"backbone.layer{li}"
-            x = conv_bn(p + ".ds_conv", x)
+            x = conv_bn(p + ".ds_conv", x, fused=stem_fused if li == 1 else None)
             for b in range(nb):
                 y = conv_bn(f"{p}.residual_{b}.conv1", x)
                 out = None
@@ -562,8 +567,20 @@ class Plan:
                 self.fwd.append((L.mi355det_bn_finalize_f64, (_vp(row), 32, 32, pixels * self.sync_world) + fin))
             else:
                 self.fwd.append((L.mi355det_bn_finalize, (_vp(part), rows, 32, 32, pixels) + fin))
-        self.fwd.append(img_call(L.mi355det_stem_fwd_apply, (_vp(wf), _vp(ss), SLOPE, a.ptr, a.ld, n, H, W, self.stream)))
-        rec = dict(kind="stem", name=name, spec=s, x=None, a=a, res=None, z=None, ss=ss, pixels=pixels, rows=rows, img_call=img_call)
+        fused = None
+        l1_rows = L.mi355det_stem_l1_rows(n, H, W)
+        if self.training and l1_rows > 0 and os.environ.get("MI355DET_STEM_L1", "1") != "0":
+            # training: the activation is produced INSIDE the kernel that convolves it (layer1.ds_conv, 32 -> 64 stride 2) and written to HBM
+            # only as a side output for that layer's weight gradient (csrc/stem_l1_kernels.hip)
+            wf1, _ = eng.packed["backbone.layer1.ds_conv"]
+
+            def emit(z1, stats1):
+                self.fwd.append(img_call(L.mi355det_stem_l1_fwd, (_vp(wf), _vp(ss), SLOPE, _vp(wf1), a.ptr, a.ld, _vp(z1), 64, _vp(stats1), n, H, W,
+                                                                  self.stream)))
+            fused = (l1_rows, emit)
+        else:
+            self.fwd.append(img_call(L.mi355det_stem_fwd_apply, (_vp(wf), _vp(ss), SLOPE, a.ptr, a.ld, n, H, W, self.stream)))
+        rec = dict(kind="stem", name=name, spec=s, x=None, a=a, res=None, z=None, ss=ss, pixels=pixels, rows=rows, img_call=img_call, fused_l1=fused)
         a.producer = rec
         self.ops.append(rec)
         self.layers[name] = rec

@@ -122,3 +122,49 @@ def test_stem_rejects_unsupported_sizes():
     wp = torch.zeros((32, 32), dtype=torch.bfloat16, device=dev())
     part = torch.zeros((80, 2, 32), device=dev())
     assert L.mi355det_stem_fwd_stats(_vp(x), _vp(wp), _vp(part), 1, 20, 32, None) == -1
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64), (1, 16, 32), (3, 48, 96), (2, 128, 64)])
+def test_fused_stem_and_first_downsampling_conv(shape):
+    """csrc/stem_l1_kernels.hip: a0 = lrelu(bn1(conv1(img))) and z1 = layer1.ds_conv(a0) (32 -> 64, 3x3, stride 2) from ONE kernel against
+    PyTorch fp32 on the same bf16-rounded operands: the side-output activation equals stem_fwd_apply's bit for bit, z1 and its statistics
+    match the convolution of that (bf16) activation."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import check, lib
+    L = lib()
+    n, h, w = shape
+    img, wt, gamma, beta, _da = _inputs(n, h, w, 21 + h)
+    g = torch.Generator().manual_seed(99)
+    w1 = (torch.randn((64, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5).bfloat16().float()
+    imgd, wp = img.to(dev()), _pack(wt)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rows = L.mi355det_stem_rows(n, h, w)
+    part = torch.zeros((rows + 64, 2, 32), device=dev())
+    check(L.mi355det_stem_fwd_stats(_vp(imgd), _vp(wp), _vp(part), n, h, w, st), "stem_fwd_stats")
+    gd, bd = gamma.to(dev()), beta.to(dev())
+    ss = torch.zeros(128, device=dev())
+    check(L.mi355det_bn_finalize(_vp(part), rows, 32, 32, n * h * w, _vp(gd), _vp(bd), EPS, 0.1, None, None, _vp(ss), st), "bn_finalize")
+    a_ref = torch.full((n, h, w, 32), 7.0, dtype=torch.bfloat16, device=dev())
+    check(L.mi355det_stem_fwd_apply(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(a_ref), 32, n, h, w, st), "stem_fwd_apply")
+    shp1 = ops.conv_shape(n, h, w, 32, 64, 3, 2)
+    wf1, _wd1 = ops.pack_weights(shp1, w1.to(dev()))
+    rows1 = L.mi355det_stem_l1_rows(n, h, w)
+    assert rows1 > 0
+    a0 = torch.full((n, h, w, 32), 5.0, dtype=torch.bfloat16, device=dev())
+    z1 = torch.full((n, h // 2, w // 2, 64), 5.0, dtype=torch.bfloat16, device=dev())
+    stats = torch.zeros((rows1 + 64, 2, 64), device=dev())
+    check(L.mi355det_stem_l1_fwd(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(wf1), _vp(a0), 32, _vp(z1), 64, _vp(stats), n, h, w, st), "stem_l1_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a_ref)                                            # same arithmetic, same rounding
+    zr = F.conv2d(a_ref.float().cpu().permute(0, 3, 1, 2), w1, stride=2, padding=1)
+    got = z1.float().cpu().permute(0, 3, 1, 2)
+    assert float((got - zr).abs().max()) <= 1e-2 * float(zr.abs().max())
+    s = stats[:rows1].double().sum(0).cpu()
+    zq = z1.double().cpu()
+    torch.testing.assert_close(s[0], zq.sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(s[1], (zq ** 2).sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
+    # without the side output
+    z1b = torch.zeros_like(z1)
+    check(L.mi355det_stem_l1_fwd(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(wf1), None, 0, _vp(z1b), 64, _vp(stats), n, h, w, st), "stem_l1_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(z1b, z1)

@@ -38,6 +38,16 @@ calls = {
     "stem_bwd_apply_wgrad": (lambda: L.mi355det_stem_bwd_apply_wgrad(vp(img), vp(wp), vp(ss), vp(sums), 0.1, vp(da), 32, vp(slab), vp(dw), vp(dg),
                                                                     vp(db), n, px, px, st), pix * (12 + 64)),
 }
+from object_detectors_amd import ops  # noqa: E402
+shp1 = ops.conv_shape(n, px, px, 32, 64, 3, 2)
+wf1, _ = ops.pack_weights(shp1, torch.randn(64, 32, 3, 3, device=dev) * 0.08)
+rows1 = L.mi355det_stem_l1_rows(n, px, px)
+z1 = torch.empty((n, px // 2, px // 2, 64), dtype=torch.bfloat16, device=dev)
+stats1 = torch.zeros((rows1 + 64, 2, 64), device=dev)
+calls["stem_l1_fwd (a0 side output)"] = (lambda: L.mi355det_stem_l1_fwd(vp(img), vp(wp), vp(ss), 0.1, vp(wf1), vp(a), 32, vp(z1), 64, vp(stats1), n, px, px, st),
+                                          pix * (12 + 64 + 32))
+calls["stem_l1_fwd (no side output)"] = (lambda: L.mi355det_stem_l1_fwd(vp(img), vp(wp), vp(ss), 0.1, vp(wf1), None, 0, vp(z1), 64, vp(stats1), n, px, px, st),
+                                          pix * (12 + 32))
 for name, (fn, nbytes) in calls.items():
     check(fn(), name)
     torch.cuda.synchronize()
