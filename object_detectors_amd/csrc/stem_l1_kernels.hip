@@ -36,7 +36,8 @@ constexpr int A_IDX = OT_W + 1;                    // pixels per plane row (17 e
 constexpr int A_ROW = A_IDX * 64;                  // bytes per plane row
 constexpr int A_PLANE = AR * A_ROW;
 constexpr int A_BYTES = 2 * A_PLANE;
-constexpr int NFRAG = AR * 3;                      // stem fragments per tile: 3 per activation row (columns 0-15, 16-31, 32)
+constexpr int NFRAG = 2 * AR + 2;                  // stem fragments per tile: 2 per activation row (columns 0-15, 16-31) + 2 for column 32
+static_assert(NFRAG % 12 == 0, "whole groups of three fragments per wave");
 static_assert(ZBASE % 16 == 0 && A_ROW % 64 == 0 && A_PLANE % 64 == 0, "alignment");
 
 struct StemL1Params {
@@ -51,6 +52,11 @@ struct StemL1Params {
   int n, H, W, tiles_x, tiles_y, ntiles;
   float slope;
 };
+
+// workgroup barrier for LDS hand-offs only: this wave's LDS traffic has completed and the compiler moves no memory access across it.
+// __syncthreads() also drains vmcnt, i.e. it waits for the prefetched image halo and for every output store of the tile (2-4 us of HBM
+// latency per barrier: the persistent loops ran at half their speed with it).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
     h_edges |= (unsigned)((r < 2 ? 1 : 0) | (r == IR - 1 ? 2 : 0) | (x < 2 ? 4 : 0) | (x == IC - 1 ? 8 : 0)) << (4 * i);
   }
   const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)(p.img - 2 * (p.W + 1)), 0, 0x7FFFFFF0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.a0, 0, 0x7FFFFFF0, 0x00020000);
+  const bool write_a0 = p.a0 != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)(write_a0 ? p.a0 : p.z1), 0, write_a0 ? 0x7FFFFFF0 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_z1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.z1, 0, 0x7FFFFFF0, 0x00020000);
   auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
     const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
@@ -157,10 +164,20 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
     const char* simg = smem + buf * IMG_BYTES;
     int b, oy0, ox0;
     tile_origin(tile, b, oy0, ox0);
-    // ================= stem phase: activation pixel (r, lc) of the 17 x 33 tile = image-local (r + kh, lc + kw)
-    for (int f = wid; f < NFRAG; f += 4) {
-      const int r = f / 3, cb = f - r * 3;
-      const int lc = min(cb * 16 + fr, AC - 1);            // fragment 2 of a row carries one real pixel (column 32); the other lanes repeat it
+    // ================= stem phase: activation pixel (r, lc) of the 17 x 33 tile = image-local (r + kh, lc + kw).  36 fragments of 16
+    // pixels: two per row (columns 0-15, 16-31) and two for column 32 (rows 0-15, row 16); nine per wave, unrolled so that the LDS
+    // read -> MFMA -> BatchNorm -> LDS write chains of different fragments overlap
+#pragma unroll 1
+    for (int it0 = 0; it0 < NFRAG / 4; it0 += 3)
+#pragma unroll
+    for (int it = it0; it < it0 + 3; ++it) {
+      const int f = wid + 4 * it;
+      // branch-free on purpose: with branches the three fragments of a group run one after the other
+      const bool rowf = f < 2 * AR;                                  // (wave-uniform) row fragment or column-32 fragment
+      const int rr = rowf ? f >> 1 : (f - 2 * AR) * 16 + fr;
+      const int lc = rowf ? (f & 1) * 16 + fr : AC - 1;
+      const bool live = rr < AR;
+      const int r = min(rr, AR - 1);
       const int pix = (r * IP + lc) * 2;
       unsigned short v[8];
 #pragma unroll
@@ -187,14 +204,15 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
       w4.y = o[2] | ((unsigned)o[3] << 16);
       w4.z = o[4] | ((unsigned)o[5] << 16);
       w4.w = o[6] | ((unsigned)o[7] << 16);
-      if (cb * 16 + fr < AC) {
-        const int idx = lc >> 1;
-        *(uint4*)(a0s + (lc & 1) * A_PLANE + r * A_ROW + idx * 64 + ((fq ^ ((idx >> 1) & 3)) << 4)) = w4;
-        if (p.a0 && r >= 1 && lc >= 1)        // the 16 x 32 activation pixels only this tile owns
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w4), rs_a0, (((b * p.H + ay) * p.W + ax) * p.a0_ld + fq * 8) * 2, 0, 0);
-      }
+      const int idx = lc >> 1;
+      // dead lanes (rows 17.. of the last column fragment) park their value in a scratch slot behind the planes
+      *(uint4*)(a0s + (live ? (lc & 1) * A_PLANE + r * A_ROW + idx * 64 + ((fq ^ ((idx >> 1) & 3)) << 4) : A_BYTES + lane * 16)) = w4;
+      // side output: the 16 x 32 activation pixels only this tile owns; every other lane gets an out-of-range offset (the store is dropped)
+      const bool own = write_a0 && live && r >= 1 && lc >= 1;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w4), rs_a0,
+                                             own ? (((b * p.H + ay) * p.W + ax) * p.a0_ld + fq * 8) * 2 : (int)0x80000000, 0, 0);
     }
-    __syncthreads();
+    lds_barrier();
     // ================= convolution phase: z1 rows row_half*4 .. +3, 16 columns, channels ch_half*32 .. +31
     f32x4_t acc[4][2];
 #pragma unroll
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
                                              (((b * (p.H / 2) + oy) * (p.W / 2) + ox) * p.z1_ld + ch_half * 32 + fq * 8) * 2, 0, 0);
     }
     if (has_next) store_halo(buf ^ 1);
-    __syncthreads();
+    lds_barrier();
     buf ^= 1;
   }
 
@@ -314,7 +332,7 @@ int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_sh
   p.tiles_y = h / (2 * OT_H);
   p.ntiles = n * p.tiles_x * p.tiles_y;
   p.slope = slope;
-  constexpr int lds = 2 * IMG_BYTES + A_BYTES;
+  constexpr int lds = 2 * IMG_BYTES + A_BYTES + 64 * 16;
   static DeviceOnce once;
   if (once.first()) (void)hipFuncSetAttribute((const void*)stem_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(stem_l1_kernel, dim3(l1_grid(p.ntiles)), dim3(256), lds, S(stream), p);
