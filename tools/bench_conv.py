@@ -51,5 +51,9 @@ for (n, h, w, cin, cout, k, s, cnt) in SHAPES:
     lib().mi355det_debug_set(0, 0)
     us = timeit(lambda: ops.conv_dgrad(shape, dy, wd, dx)); tot[1] += cnt * us; msg += f" dgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF |"
     us = timeit(lambda: ops.conv_wgrad(shape, x, dy, dw, workspace=ws)); tot[2] += cnt * us; msg += f" wgrad {us:7.1f}us {fl / us / 1e6:6.0f}TF"
+    # floors: dense bf16 MFMA peak 2.5 PFLOP/s; algorithmic HBM bytes (each operand once, bf16 tensors, fp32 dW) at 8 TB/s
+    px_in, px_out = n * h * w, n * shape.ho * shape.wo
+    by = {"f": 2 * (px_in * cin + px_out * cout), "d": 2 * (px_in * cin + px_out * cout), "w": 2 * (px_in * cin + px_out * cout) + 4 * cout * cin * k * k}
+    msg += "  || floor us (mfma, hbm): " + f"{fl / 2.5e9:5.1f} " + " ".join(f"{b / 8e6:5.1f}" for b in by.values())
     print(f"x{cnt:2d} " + msg, flush=True)
 print(f"sum over the step's launches (ms): fwd {tot[0] / 1e3:.2f}  dgrad {tot[1] / 1e3:.2f}  wgrad {tot[2] / 1e3:.2f}")

@@ -19,7 +19,10 @@ def dur(r): return (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
 fw = [r for r in last if 'igemm' in r['Kernel_Name'] and (', 0, ' in r['Kernel_Name'].split('igemm')[1][:60] or True)]
 # forward igemm launches = first 74 igemm-family kernels of the step (before any wgrad)
 first_w = next(i for i, r in enumerate(last) if 'wgrad_kernel' in r['Kernel_Name'])
-fwd = sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))[:74]
+# fused path (csrc/stem_l1_kernels.hip): backbone.layer1.ds_conv's forward runs inside stem_l1_kernel (with the stem activation), 73 igemm launches remain
+fused = [r for r in last if 'stem_l1_kernel' in r['Kernel_Name']]
+NF = 73 if fused else 74
+fwd = fused[:1] + sorted([r for r in last if 'igemm' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))[:NF]
 bwd = last[first_w - 10:]
 wg = sorted([r for r in last if 'wgrad_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
 agg = collections.OrderedDict()
@@ -29,15 +32,21 @@ for s, r in zip(specs, fwd):
     a[4] += 2.0 * 32 * hw(s) ** 2 * s.cout * kk
 for s, r in zip(reversed(specs), wg):
     agg[(s.cin, s.cout, s.k, s.stride, hw(s))][3] += dur(r)
-# dgrad: igemm kernels after the first wgrad, grouped per layer in backward order (stride-2 layers have 4 launches)
-allig = sorted([r for r in last if 'igemm' in r['Kernel_Name'] or 'dgrad_s2_kernel' in r['Kernel_Name']], key=lambda r: int(r['Start_Timestamp']))
-dg = allig[74:]
-it = iter(dg)
-for s in reversed(specs):
-    n = 4 if s.stride == 2 else 1
-    if s.stride == 2 and s.cout == 64 and s.cin in (32, 64): n = 1    # single-launch stride-2 data gradient (dgrad_s2_kernels.hip)
-    t = sum(dur(next(it)) for _ in range(n))
-    agg[(s.cin, s.cout, s.k, s.stride, hw(s))][2] += t
+# dgrad: a BN layer's backward opens with one bn_bwd_reduce_kernel; the igemm / dgrad_s2 launches up to the next one are its data gradient
+# (1 launch, or 2 / 4 for the stride-2 layers depending on the tuned form).  The three head convolutions have no BN: the first dgrad launch seen
+# while a head layer is next in line belongs to it.
+rev = list(reversed(specs))
+fwd_ids = {id(r) for r in fwd}
+li, got = -1, 0
+for r in last:
+    nm = r['Kernel_Name']
+    if 'bn_bwd_reduce_kernel' in nm:
+        li = next(i for i in range(li + 1, len(rev)) if rev[i].bn); got = 0
+    elif ('igemm' in nm or 'dgrad_s2_kernel' in nm) and id(r) not in fwd_ids:
+        if li + 1 < len(rev) and not rev[li + 1].bn and (li < 0 or got > 0 or not rev[li].bn):
+            li += 1; got = 0
+        s = rev[li]; got += 1
+        agg[(s.cin, s.cout, s.k, s.stride, hw(s))][2] += dur(r)
 print(f"{'cin->cout k s @hw':28s} {'n':>3s} {'fwd us':>8s} {'TF':>6s} {'dgrad':>8s} {'TF':>6s} {'wgrad':>8s} {'TF':>6s}  tot ms")
 tot = [0, 0, 0]
 for k, (n, f, d, w, fl) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2] + kv[1][3])):
@@ -47,7 +56,8 @@ for k, (n, f, d, w, fl) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1]
 print('totals ms: fwd %.2f dgrad %.2f wgrad %.2f' % tuple(t / 1e3 for t in tot))
 stem = collections.OrderedDict()
 for r in last:
-    if 'stem_' in r['Kernel_Name']:
+    if 'stem_' in r['Kernel_Name'] and 'stem_l1_kernel' not in r['Kernel_Name']:
         n = r['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '')
         stem[n] = stem.get(n, 0.0) + dur(r)
+if fused: print('  32->  64 k3 s2 @320 fwd = stem_l1_kernel: stem activation (recomputed from the image) + this convolution + its BN statistics in one launch')
 print('stem 3->32 k3 s1 @640 (recompute kernels, us): ' + ', '.join(f'{k} {v:.1f}' for k, v in stem.items()) + f'; total {sum(stem.values()) / 1e3:.2f} ms')

@@ -27,6 +27,8 @@ def family(name):
         kind = m.group(1)
         e = a[0] if kind == "igemm8_kernel" else a[6] if kind == "igemm_kernel" else (a[4] if kind == "igemm_dx_kernel" else a[5])
         return "igemm " + {"0": "fwd (BN partial stats)", "1": "fwd (fp32 head)", "2": "dgrad (+skip)", "3": "dgrad", "4": "fwd (affine)"}.get(e, e)
+    if name.startswith("stem_kernel<"):
+        return name.split("(")[0][:60]        # the four modes of csrc/stem_kernels.hip are different kernels
     return name.split("(")[0].split("<")[0][:60]
 
 

@@ -49,9 +49,9 @@ busy = sum(a[1] for a in agg.values())
 print(f"# per-step kernel table (last {K} steps of the run; plan build / autotune excluded)\n")
 print(f"wall per step (first launch -> last completion): {(t1 - t0) / 1e6 / K:.3f} ms; summed kernel time per step: {busy / 1e3 / K:.3f} ms "
       f"(> wall where the two backward streams overlap)\n")
-fw = [(n, t) for f, (n, t, _a, _b) in agg.items() if f.startswith("igemm") and ("epi=stats" in f or "epi=f32" in f)]
+fw = [(n, t) for f, (n, t, _a, _b) in agg.items() if (f.startswith("igemm") and ("epi=stats" in f or "epi=f32" in f)) or f.startswith(("stem_l1_kernel", "stem_kernel<0>", "stem_kernel<1>"))]
 nf, tf = sum(n for n, _ in fw), sum(t for _, t in fw)
-print(f"forward convolution launches (igemm epi=stats + epi=f32 head, the kernel priced by bench.py's `roofline`): {nf / K:.0f} per step, "
+print(f"forward convolution launches (igemm epi=stats + epi=f32 head + the stem forward kernels, the launches priced by bench.py's `roofline`): {nf / K:.0f} per step, "
       f"average duration {tf / nf:.2f} us, {tf / 1e3 / K:.3f} ms per step\n")
 print("| kernel family | launches/step | ms/step | avg us | min us | max us | % of kernel time |\n|---|---|---|---|---|---|---|")
 for f, (n, t, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
