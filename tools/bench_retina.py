@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--px", type=int, default=800)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-fwd-only", action="store_true", help="skip the trailing forward-only timing (profiling passes: the trace then ends with whole steps)")
     ap.add_argument("--body", default="resnet50")
     ap.add_argument("--classes", type=int, default=91)
     args = ap.parse_args()
@@ -58,7 +59,7 @@ def main():
     dt = (time.perf_counter() - t0) / args.steps
     # forward-only timing
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(0 if args.no_fwd_only else args.steps):
         eng.forward(imgs, training=True)
     torch.cuda.synchronize()
     df = (time.perf_counter() - t0) / args.steps

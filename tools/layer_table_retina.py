@@ -78,7 +78,7 @@ def run_with_events(calls):
             st = fn(*a)
             e1.record(stream)
             fl = 2.0 * shp.n * shp.ho * shp.wo * shp.cout * shp.cin * shp.ksize * shp.ksize
-            events.append((kind, name_of.get(C.addressof(shp), f"{shp.cin}->{shp.cout} k{shp.ksize}"), fl, e0, e1))
+            events.append((kind, name_of.get(C.addressof(shp), f"{shp.cin}->{shp.cout} k{shp.ksize}"), fl, e0, e1, shp.ho))
         if st != 0:
             check(st, fn.__name__)
 
@@ -91,7 +91,12 @@ opt.step()
 t1.record()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for kind, fam, fl, e0, e1 in events:
+lev = collections.OrderedDict()
+for kind, fam, fl, e0, e1, ho in events:
+    if fam in ("cls_logits", "bbox_reg"):
+        b = lev.setdefault((fam, ho), {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]})[kind]
+        b[0] += e0.elapsed_time(e1)
+        b[1] += fl
     a = agg.setdefault(fam, {"fwd": [0, 0.0, 0.0], "dgrad": [0, 0.0, 0.0], "wgrad": [0, 0.0, 0.0]})[kind]
     a[0] += 1
     a[1] += e0.elapsed_time(e1)
@@ -111,3 +116,9 @@ for fam, d in agg.items():
         tot[k][1] += d[k][2]
 print(f"| all convolutions | | {tot['fwd'][0]:.3f} | {tot['fwd'][1] / tot['fwd'][0] / 1e9:.0f} ({tot['fwd'][1] / tot['fwd'][0] / 1e9 / 2500:.2f}) | {tot['dgrad'][0]:.3f} | "
       f"{tot['dgrad'][1] / max(tot['dgrad'][0], 1e-9) / 1e9:.0f} | {tot['wgrad'][0]:.3f} | {tot['wgrad'][1] / max(tot['wgrad'][0], 1e-9) / 1e9:.0f} |")
+
+print("\n## head output convolutions per pyramid level (ms, TFLOP/s)\n")
+print("| layer | map | fwd ms | TF | dgrad ms | TF | wgrad ms | TF |\n|---|---|---|---|---|---|---|---|")
+for (fam, ho), d in lev.items():
+    c = lambda k: f"{d[k][0]:.3f} | {d[k][1] / d[k][0] / 1e9:.0f}" if d[k][0] else "- | -"
+    print(f"| {fam} | {ho}x{ho} | {c('fwd')} | {c('dgrad')} | {c('wgrad')} |")

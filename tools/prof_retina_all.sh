@@ -12,8 +12,8 @@ python3 tools/summarize_rocprof.py $O/prof_r50 $O/retina_r50_kernel_stats.md "ro
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r101 -- python3 tools/bench_retina.py --body resnet101 --classes 1204 --batch 8 --steps 5 --warmup 2 > $O/prof_r101.log 2>&1
 python3 tools/summarize_rocprof.py $O/prof_r101 $O/retina_r101_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 tools/bench_retina.py --body resnet101 --classes 1204 --batch 8 --steps 5 --warmup 2"
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r101_$c -- python3 tools/bench_retina.py --body resnet101 --classes 1204 --batch 8 --steps 3 --warmup 1 > $O/pmc_r101_$c.log 2>&1
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r50_$c -- python3 tools/bench_retina.py --steps 3 --warmup 1 > $O/pmc_r50_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r101_$c -- python3 tools/bench_retina.py --body resnet101 --classes 1204 --batch 8 --steps 3 --warmup 1 --no-fwd-only > $O/pmc_r101_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc_r50_$c -- python3 tools/bench_retina.py --steps 3 --warmup 1 --no-fwd-only > $O/pmc_r50_$c.log 2>&1
 done
 python3 tools/pmc_summary.py 3 $O/retina_r101_pmc.md $O/retina_r101_pmc.json $O/pmc_r101_FETCH_SIZE $O/pmc_r101_WRITE_SIZE $O/pmc_r101_MfmaUtil
 python3 tools/pmc_summary.py 3 $O/retina_r50_pmc.md $O/retina_r50_pmc.json $O/pmc_r50_FETCH_SIZE $O/pmc_r50_WRITE_SIZE $O/pmc_r50_MfmaUtil
