@@ -191,6 +191,23 @@ int mi355det_retina_loss(const float* cls_logits, const float* bbox_regression, 
                          float gamma, float grad_scale, float* num_fg, float* losses, float* grad_logits,
                          float* grad_regression, void* stream);
 
+/* The same head loss with the classification gradient written where the head's backward reads it (replaces the autograd hand-over between
+ * retinanet.py:107-143 and the cls_logits convolution, retinanet.py:75-105): bf16, per pyramid level an NHWC buffer [n_images, pixels, ld]
+ * whose channel a*k + c is anchor a, class c of the pixel (exactly the layout of the level-concatenated logits [n, sum HWA, k]).  Saves the
+ * fp32 gradient tensor and its cast (2 x 4 B per logit: 9 GB per step for the 1204-class head at batch 8).  Padding channels of the
+ * buffers are not written (zero them once).  sum(pixels[q]) * anchors_per_pixel must equal rows_per_image. */
+typedef struct {
+  int32_t n_levels;             /* 1..8 */
+  int32_t anchors_per_pixel;
+  int64_t pixels[8];            /* h*w of each level */
+  void* grad[8];                /* bf16 [n_images, pixels, grad_ld] */
+  int32_t grad_ld[8];           /* >= anchors_per_pixel * k */
+} mi355det_level_grads;
+int mi355det_retina_loss_lv(const float* cls_logits, const float* bbox_regression, const float* anchors, const int64_t* matched,
+                            const float* gt_boxes, const int64_t* gt_labels, const int32_t* gt_offsets, const float* class_scale,
+                            int32_t n_images, int64_t rows_per_image, int32_t k, float alpha, float gamma, float grad_scale,
+                            float* num_fg, float* losses, const mi355det_level_grads* cls_levels, float* grad_regression, void* stream);
+
 /* torchvision.ops.roi_align / MultiScaleRoIAlign (tvision/frcnn.py:208-211, roi_heads.py:818): NCHW fp32 features.
  *   feats/hs/ws/scales: HOST arrays of num_levels (1..4) device pointers / sizes / spatial scales; with several levels
  *   the LevelMapper (k = floor(4 + log2(sqrt(area)/224) + 1e-6) clamped to [k_min,k_max]) picks the level per RoI.
@@ -301,6 +318,16 @@ int mi355det_stem_bwd_apply_wgrad(const float* img, const void* w, const float* 
  * residual != NULL adds a bf16 tensor (same shape as dx) in the epilogue (residual-block skip). */
 int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx,
                         const void* residual, int32_t residual_ld, void* stream);
+
+/* The same data gradient with a caller-owned workspace (replaces the same autograd step, torch/nn/grad.py conv2d_input as reached from
+ * loss.backward() in detection/engine.py:49-57).  When the shape has few output pixels and a very deep reduction (stride 1, <= 96 tiles
+ * of 128 x 128, k*k*cout >= 8192: the 1204-class RetinaNet head on the small pyramid levels, retinanet.py:75-105) the reduction is split
+ * over channel ranges into fp32 partial tiles in `workspace` and added in a fixed order (deterministic; the bf16 rounding happens once,
+ * after the sum and the residual).  mi355det_conv_dgrad_workspace returns the bytes that form needs, 0 when it does not apply; with a
+ * NULL / zero workspace or a shape it does not apply to, conv_dgrad_ws IS conv_dgrad. */
+size_t mi355det_conv_dgrad_workspace(const mi355det_conv_shape* s);
+int mi355det_conv_dgrad_ws(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Data gradient that also starts the BatchNorm backward of the layer it feeds: dx is the gradient of an activation
  * a = lrelu(bn(z)); while the dx tile is still on chip the epilogue accumulates that layer's per-channel

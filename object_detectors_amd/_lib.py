@@ -42,6 +42,11 @@ class ConvEpilogue(C.Structure):
                 ("slope", C.c_float)]
 
 
+class LevelGrads(C.Structure):
+    """mi355det_level_grads: where mi355det_retina_loss_lv writes the bf16 class gradient (one NHWC buffer per pyramid level)."""
+    _fields_ = [("n_levels", i32), ("anchors_per_pixel", i32), ("pixels", i64 * 8), ("grad", vp * 8), ("grad_ld", i32 * 8)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("shape", ConvShape), ("cout_pad", i32), ("w_is_ohwi", i32)]
 
@@ -76,6 +81,8 @@ PROTOTYPES = {
     "mi355det_topk": (C.c_int, [vp, i32, i64, i64, i32, f32, vp, vp, vp, vp]),
     "mi355det_conv_fwd": (C.c_int, [P(ConvShape), vp, vp, vp, vp, C.c_int, vp, i32, vp]),
     "mi355det_conv_dgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp]),
+    "mi355det_conv_dgrad_workspace": (sz, [P(ConvShape)]),
+    "mi355det_conv_dgrad_ws": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp, sz, vp]),
     "mi355det_conv_wgrad_workspace": (sz, [P(ConvShape)]),
     "mi355det_conv_wgrad_autotune": (C.c_int, [P(ConvShape), vp, vp, vp, vp, sz, vp]),
     "mi355det_conv_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, vp, sz, vp]),
@@ -104,6 +111,7 @@ PROTOTYPES = {
     "mi355det_bn_bwd_sum_partials": (C.c_int, [vp, i32, i32, i32, vp, vp]),
     "mi355det_conv_fwd_ex": (C.c_int, [P(ConvShape), vp, vp, P(ConvEpilogue), vp, C.c_int, i32, vp]),
     "mi355det_retina_loss": (C.c_int, [vp] * 8 + [i32, i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp]),
+    "mi355det_retina_loss_lv": (C.c_int, [vp] * 8 + [i32, i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, P(LevelGrads), vp, vp]),
     "mi355det_im2col_nchw": (C.c_int, [vp, vp, vp, vp] + [i32] * 8 + [vp]),
     "mi355det_maxpool3x3s2": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mi355det_maxpool3x3s2_bwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),

@@ -743,13 +743,23 @@ __device__ __forceinline__ void sfl(float x, float t, float alpha, float gamma, 
 // TGT_MODE 0: dense target tensor t; 1: target from Matcher output (matched>=0 -> class gt_labels[matched])
 #define FOCAL_THREADS 1024     // 16 waves fold their sums through LDS: ONE atomic per workgroup on the loss word, <= 512 workgroups (atomics to
                                // one address retire at ~90 per microsecond: 2048 of them were 23 of the kernel's 56 us at K = 91)
+// optional bf16 gradient output in the layout the head convolution's backward reads: per pyramid level an NHWC buffer [n, h*w, ld] whose
+// channel a*k + c is anchor a, class c of that pixel (row r of the level-concatenated [n, sum HWA, k] logits = pixel r / A, anchor r % A)
+struct FocalLevels {
+  int nlev, A;
+  long long start[8];       // first row of level q inside one image's rows
+  long long pixels[8];      // h*w of level q
+  bf16_t* dst[8];
+  int ld[8];
+};
+
 template <int TGT_MODE, int NT = FOCAL_THREADS>
 __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, const float* __restrict__ t, const long long* __restrict__ matched,
                                                     const long long* __restrict__ gt_labels, const float* __restrict__ scale,
                                                     const unsigned char* __restrict__ valid, long long rows, int k, float alpha, float gamma,
                                                     float gscale, float* __restrict__ loss_sum, float* __restrict__ grad,
                                                     const float* __restrict__ nfg = nullptr, long long rows_per_image = 0,
-                                                    const int* __restrict__ gt_off = nullptr, float inv_images = 1.f) {
+                                                    const int* __restrict__ gt_off = nullptr, float inv_images = 1.f, const FocalLevels lv = FocalLevels{}) {
   __shared__ float red[NT / WAVE];
   const long long total = rows * k;
   const bool vec = (total & 3) == 0;      // 4 consecutive elements per lane: 16-byte loads/stores of logits and gradients
@@ -776,9 +786,28 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
     bool ok = true;
     bool fresh = true;
     float wimg = 1.f;          // batched form: 1 / max(1, num_foreground of the row's image) / num_images (retinanet.py:141-143)
+    // bf16 level output: `drow` = channel 0 of the current row's (pixel, anchor); a group of 4 that stays inside one row and is 8-byte
+    // aligned (always for k % 4 == 0) is written with one store
+    auto locate = [&](long long row) -> bf16_t* {
+      const long long b = row / rows_per_image, rl = row - b * rows_per_image;
+      long long st0 = 0, px = lv.pixels[0];
+      bf16_t* base = lv.dst[0];
+      int ldq = lv.ld[0];
+#pragma unroll
+      for (int l = 1; l < 8; ++l)
+        if (l < lv.nlev && rl >= lv.start[l]) {
+          st0 = lv.start[l]; px = lv.pixels[l]; base = lv.dst[l]; ldq = lv.ld[l];
+        }
+      const long long local = rl - st0, pix = local / lv.A;
+      return base + (b * px + pix) * ldq + (local - pix * lv.A) * k;
+    };
+    bf16_t* drow = lv.nlev > 0 ? locate(r) : nullptr;
+    bf16_t* const dfirst = drow ? drow + c : nullptr;
+    const bool packed = drow && vec && c + 3 < k && (((unsigned long long)dfirst) & 7ull) == 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (e >= cnt) break;
+      if (fresh && e > 0 && lv.nlev > 0) drow = locate(r);
       if (fresh) {
         if (TGT_MODE == 0) ok = !valid || valid[r];
         else {
@@ -803,6 +832,7 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
         g *= sc * gscale * wimg;
       }
       gv[e] = g;
+      if (lv.nlev > 0 && !packed) drow[c] = f2bf(g);
       if (++c == k) {
         c = 0;
         ++r;
@@ -812,6 +842,12 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
     if (grad) {
       if (vec) *(float4*)(grad + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
       else grad[i0] = gv[0];
+    }
+    if (packed) {
+      uint2 o;
+      o.x = f2bf(gv[0]) | ((unsigned)f2bf(gv[1]) << 16);
+      o.y = f2bf(gv[2]) | ((unsigned)f2bf(gv[3]) << 16);
+      *(uint2*)dfirst = o;
     }
   }
   acc = wave_sum(acc);
@@ -1056,6 +1092,44 @@ int mi355det_retina_loss(const float* cls_logits, const float* bbox_regression, 
                      (const long long*)matched, gt_boxes, (const int*)gt_offsets, (const float*)num_fg, n_images, (long long)rows_per_image, 1.f, 1.f,
                      1.f, 1.f, grad_scale, losses + 1, grad_regression);
   return check_launch("retina_loss");
+}
+
+int mi355det_retina_loss_lv(const float* cls_logits, const float* bbox_regression, const float* anchors, const int64_t* matched,
+                            const float* gt_boxes, const int64_t* gt_labels, const int32_t* gt_offsets, const float* class_scale, int32_t n_images,
+                            int64_t rows_per_image, int32_t k, float alpha, float gamma, float grad_scale, float* num_fg, float* losses,
+                            const mi355det_level_grads* cls_levels, float* grad_regression, void* stream) {
+  if (n_images <= 0 || rows_per_image <= 0 || k <= 0) return fail(MI355DET_EINVAL, "%s: bad shape", "retina_loss_lv");
+  if (!cls_logits || !bbox_regression || !anchors || !matched || !gt_boxes || !gt_labels || !gt_offsets || !num_fg || !losses || !cls_levels)
+    return fail(MI355DET_EINVAL, "%s: null argument", "retina_loss_lv");
+  if (cls_levels->n_levels < 1 || cls_levels->n_levels > 8 || cls_levels->anchors_per_pixel < 1)
+    return fail(MI355DET_EINVAL, "%s: 1..8 levels and >= 1 anchor per pixel", "retina_loss_lv");
+  FocalLevels lv{};
+  lv.nlev = cls_levels->n_levels;
+  lv.A = cls_levels->anchors_per_pixel;
+  long long at = 0;
+  for (int q = 0; q < lv.nlev; ++q) {
+    if (!cls_levels->grad[q] || cls_levels->pixels[q] <= 0 || cls_levels->grad_ld[q] < lv.A * k)
+      return fail(MI355DET_EINVAL, "%s: level %d: null buffer, no pixels or pitch < anchors * classes", "retina_loss_lv", q);
+    lv.start[q] = at;
+    lv.pixels[q] = cls_levels->pixels[q];
+    lv.dst[q] = (bf16_t*)cls_levels->grad[q];
+    lv.ld[q] = cls_levels->grad_ld[q];
+    at += cls_levels->pixels[q] * lv.A;
+  }
+  if (at != rows_per_image) return fail(MI355DET_EINVAL, "%s: the levels hold %lld rows per image, the logits %lld", "retina_loss_lv", at, (long long)rows_per_image);
+  hipStream_t st = S(stream);
+  (void)hipMemsetAsync(num_fg, 0, sizeof(float) * n_images, st);
+  (void)hipMemsetAsync(losses, 0, sizeof(float) * 2, st);
+  hipLaunchKernelGGL(count_fg_kernel, dim3((int)min((long long)64, (long long)((rows_per_image + 255) / 256)), n_images), dim3(256), 0, st,
+                     (const long long*)matched, (long long)rows_per_image, num_fg);
+  const long long rows = (long long)n_images * rows_per_image;
+  FOCAL_LAUNCH(1, rows * k, st, cls_logits, (const float*)nullptr, (const long long*)matched, (const long long*)gt_labels, class_scale,
+               (const unsigned char*)nullptr, rows, k, alpha, gamma, grad_scale, losses, (float*)nullptr, (const float*)num_fg, (long long)rows_per_image,
+               (const int*)gt_offsets, 1.0f / (float)n_images, lv);
+  hipLaunchKernelGGL(retina_reg_kernel, dim3((int)min((long long)2048, (rows + 255) / 256)), dim3(256), 0, st, bbox_regression, anchors,
+                     (const long long*)matched, gt_boxes, (const int*)gt_offsets, (const float*)num_fg, n_images, (long long)rows_per_image, 1.f, 1.f,
+                     1.f, 1.f, grad_scale, losses + 1, grad_regression);
+  return check_launch("retina_loss_lv");
 }
 
 }  // extern "C"

@@ -61,8 +61,15 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   // XCD-aware block remap (bijective form): blocks that share an A tile (same m-tile, all n-tiles) and
   // neighbouring m-tiles run on one XCD so the re-reads hit that XCD's L2.
   const int ntn = p.CoutPad / BN;
-  const int nblk = gridDim.x;
+  int nblk = gridDim.x;
   int bid = blockIdx.x;
+  int sp = 0;                                  // split-K: the splits of one tile are neighbouring blocks
+  if (p.ksplit > 1) {
+    const int q = __builtin_amdgcn_readfirstlane(bid / p.ksplit);      // integer division runs on the vector ALU: back to scalar registers
+    sp = bid - q * p.ksplit;
+    bid = q;
+    nblk = __builtin_amdgcn_readfirstlane(nblk / p.ksplit);
+  }
   {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -133,12 +140,16 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   __builtin_amdgcn_s_barrier();
   STAMP(t_p4);
 
-  const int ksteps = ABL == 5 ? 0 : Ktot / BK;   // ABL 5: prologue + epilogue only
-  const int cin_steps = p.Cin / BK;
+  // k-steps walk (tap, channel chunk); a split-K block walks only its channel range [c0b, c0b + cin_steps*BK) of every tap
+  const int cin_steps = __builtin_amdgcn_readfirstlane((p.ksplit > 1 ? p.Cin / p.ksplit : p.Cin) / BK);
+  const int c0b = sp * cin_steps * (BK * 2);                     // byte offset of the split's first channel (0 without split-K)
+  const int ksteps = ABL == 5 ? 0 : p.T * cin_steps;            // ABL 5: prologue + epilogue only
   int pf_t = 0, pf_c = 0;   // (tap, cin-step) of the next stage to prefetch
 
   auto stage = [&](int s, int buf) {
-    const int soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
+    const int coff = c0b + pf_c * (BK * 2);
+    const int soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + coff;
+    const int boff = pf_t * (p.Cin * 2) + coff;                  // = s * BK * 2 without split-K
     char* sa = smem + buf * STAGE;
     char* sb = sa + BM * ROWB;
 #pragma unroll
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
       bufld16(rsrc_x, sa + instr * 1024, ((a_valid[i] >> pf_t) & 1u) ? a_voff[i] : OOB_VOFF, soff);
     }
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) bufld16(rsrc_w, sb + b_instr[i] * 1024, b_voff[i], s * (BK * 2));
+    for (int i = 0; i < B_PER; ++i) bufld16(rsrc_w, sb + b_instr[i] * 1024, b_voff[i], boff);
     if (++pf_c == cin_steps) {
       pf_c = 0;
       ++pf_t;
@@ -155,14 +166,14 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   };
 
   // one LDS-DMA piece of the stage being prefetched (q < A_PER: activation rows, else weight rows)
-  auto issue_piece = [&](int q, int s, int soff, int tap, int buf) {
+  auto issue_piece = [&](int q, int boff, int soff, int tap, int buf) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + BM * ROWB;
     if (q < A_PER) {
       const int instr = wid * A_PER + q;
       bufld16(rsrc_x, sa + instr * 1024, ((a_valid[q] >> tap) & 1u) ? a_voff[q] : OOB_VOFF, soff);
     } else {
-      bufld16(rsrc_w, sb + b_instr[q - A_PER] * 1024, b_voff[q - A_PER], s * (BK * 2));
+      bufld16(rsrc_w, sb + b_instr[q - A_PER] * 1024, b_voff[q - A_PER], boff);
     }
   };
 
@@ -194,12 +205,13 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
     STAMP(t_c);
     const bool pf = s + D < ksteps;
     const int pbuf = buf == 0 ? NST - 1 : buf - 1;
-    int il_soff = 0, il_tap = 0;
+    int il_soff = 0, il_tap = 0, il_boff = 0;
     if (!ILV) {
       if (pf && ABL != 1) stage(s + D, pbuf);
     } else if (pf) {
       il_tap = pf_t;
-      il_soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + pf_c * (BK * 2);
+      il_soff = __builtin_amdgcn_readfirstlane(s_toff[pf_t]) + c0b + pf_c * (BK * 2);
+      il_boff = pf_t * (p.Cin * 2) + c0b + pf_c * (BK * 2);
       if (++pf_c == cin_steps) {
         pf_c = 0;
         ++pf_t;
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
             // then overlap with this wave's own MFMAs still running in the matrix pipe
             const int cnt = ks * TN * TM + i * TM + j + 1;
             if (cnt % G == 0 && cnt / G - 1 < PER) {
-              if (pf) issue_piece(cnt / G - 1, s + D, il_soff, il_tap, pbuf);
+              if (pf) issue_piece(cnt / G - 1, il_boff, il_soff, il_tap, pbuf);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();               // the epilogue reuses smem
 
-  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0);
+  igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, NT, true, wm, wn, lane, mt, n0, m0, EPI == EPI_F32 ? sp * p.ysplit : 0ll);
 }
 
 // ---- 3x3 stride-1 form with shared pixel tiles ("dx reuse") ----------------------------------------------------------
@@ -818,7 +830,7 @@ int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
   if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
+  hipLaunchKernelGGL(k, dim3(gm * gn * (p.ksplit > 1 ? p.ksplit : 1)), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm");
 }
 
@@ -907,7 +919,7 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t st) {
     case 54: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 4, EPI>(p, st); break;                                     // 128x128x32 ring 4 (64 KB, 2 workgroups/CU)
     case 55: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 64, 3, EPI>(p, st); break;                                     // 128x128x64 ring 3 (96 KB, 1 workgroup/CU)
     case 56: if (EPI == EPI_STATS) return launch_cfg<2, 2, 4, 4, 32, 6, EPI>(p, st); break;                                     // 128x128x32 ring 6 (96 KB)
-    case 40: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF)) return igemm8_launch(EPI, p, st); break;   // phase-staggered 256x256x64, 8 waves
+    case 40: if (igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF || EPI == EPI_F32)) return igemm8_launch(EPI, p, st); break;   // phase-staggered 256x256x64, 8 waves
     case 15: if (dx_applicable(p)) return launch_dx<2, 2, 4, 4, EPI>(p, st); break;             // 3x3 s1: shared pixel tiles (dx reuse), 128x128
     case 16: if (dx_applicable(p)) return launch_dx<4, 2, 4, 4, EPI>(p, st); break;             // dx reuse 256x128, 8 waves, 1 workgroup/CU
     case 17: if (dx_applicable(p) && p.CoutPad % 256 == 0) return launch_dx<2, 4, 4, 4, EPI>(p, st); break;   // dx reuse 128x256, 8 waves
@@ -1005,7 +1017,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
     static const bool small_lds = getenv("MI355DET_DGRAD_BIG_LDS") == nullptr;
     if (small_lds && (EPI == EPI_PLAIN || EPI == EPI_RES) && (cfg == 3 || cfg == 6 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 26 || cfg == 27 || cfg == 28)) continue;
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
-    if (cfg == 40 && !(igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF))) continue;
+    if (cfg == 40 && !(igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF || EPI == EPI_F32))) continue;
     if (cfg >= 15 && (!dx_applicable(p) || ((cfg == 17 || cfg == 18 || cfg == 28) && p.CoutPad % 256 != 0))) continue;
     int e = run_cfg<EPI>(cfg, p, st);
     if (e) return e;
@@ -1555,6 +1567,100 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
 int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
                         void* stream) {
   return conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, nullptr, 0, nullptr, 0.f, nullptr, stream);
+}
+
+// ---- split-K data gradient: few output pixels, very deep reduction (the 1204-class RetinaNet head on the small pyramid levels:
+//      8 x 7 x 7 pixels against K = 9 x 10 880).  The plain form leaves 8-80 workgroups walking 1530 k-steps each; here the channel axis
+//      is cut into `ksplit` ranges, every (tile, range) is a workgroup writing an fp32 partial tile, and splitk_reduce_kernel adds the
+//      ranges in a fixed order (deterministic), adds the residual and rounds to bf16 once.
+static int dgrad_ksplit(const mi355det_conv_shape* s) {
+  if (!s || s->stride != 1 || s->ksize * s->ksize > MAX_TAPS) return 0;
+  const int cin_pad = (s->cin + 31) / 32 * 32;
+  if (cin_pad % 128 != 0 || s->cout % 64 != 0 || s->in_ld % 8 != 0) return 0;
+  const long long M = (long long)s->n * s->h * s->w, K = (long long)s->ksize * s->ksize * s->cout;
+  const long long tiles = (M + 127) / 128 * (cin_pad / 128);
+  if (tiles > 96 || K < 8192) return 0;
+  const int chunks = s->cout / 64;
+  int best = 0;
+  for (int d = 2; d <= chunks; ++d)
+    if (chunks % d == 0 && tiles * d <= 512 && chunks / d >= 4) best = d;
+  return best;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long long sstride, bf16_t* __restrict__ dx, int ld,
+                                                            const bf16_t* __restrict__ res, int ldres, long long M, int C, int CP) {
+  const int c8 = C / 8;
+  const long long total = M * c8;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / c8;
+    const int c = (int)(i - m * c8) * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* src = part + m * CP + c;
+    for (int sp = 0; sp < S; ++sp) {
+      const float4 v0 = *(const float4*)(src + sp * sstride), v1 = *(const float4*)(src + sp * sstride + 4);
+      a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w;
+      a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+    }
+    if (res) {
+      const uint4 r = *(const uint4*)(res + m * ldres + c);
+      const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[2 * k] += bf2f((unsigned short)(rr[k] & 0xFFFFu));
+        a[2 * k + 1] += bf2f((unsigned short)(rr[k] >> 16));
+      }
+    }
+    uint4 o;
+    o.x = f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
+    o.y = f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
+    o.z = f2bf(a[4]) | ((unsigned)f2bf(a[5]) << 16);
+    o.w = f2bf(a[6]) | ((unsigned)f2bf(a[7]) << 16);
+    *(uint4*)(dx + m * ld + c) = o;
+  }
+}
+
+size_t mi355det_conv_dgrad_workspace(const mi355det_conv_shape* s) {
+  const int ks = dgrad_ksplit(s);
+  if (ks < 2) return 0;
+  const int cin_pad = (s->cin + 31) / 32 * 32;
+  return (size_t)ks * (size_t)s->n * s->h * s->w * cin_pad * sizeof(float);
+}
+
+int mi355det_conv_dgrad_ws(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  const int ks = dgrad_ksplit(s);
+  if (ks < 2 || !workspace || g_autotune_mode) return conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, nullptr, 0, nullptr, 0.f, nullptr, stream);
+  if (int e = check_shape(s, "conv_dgrad_ws")) return e;
+  if (int e = ensure_zero_page()) return e;
+  if (!dy || !wt || !dx) return fail(MI355DET_EINVAL, "%s: null argument", "conv_dgrad_ws");
+  if (workspace_bytes < mi355det_conv_dgrad_workspace(s)) return fail(MI355DET_EINVAL, "%s: workspace too small (%zu < %zu bytes)", "conv_dgrad_ws", workspace_bytes, mi355det_conv_dgrad_workspace(s));
+  if (s->cin % 8 != 0 || (residual && residual_ld % 8 != 0)) return fail(MI355DET_EINVAL, "%s: cin and the residual pitch must be multiples of 8", "conv_dgrad_ws");
+  const int cin_pad = (s->cin + 31) / 32 * 32;
+  IgemmParams p{};
+  int ft[9];
+  p.T = dgrad_taps(s, 0, 0, ft, p.dy, p.dx);
+  p.x = (const bf16_t*)dy;
+  p.w = (const bf16_t*)wt;
+  p.y = workspace;
+  p.zero = g_zero_page;
+  p.MH = s->h; p.MW = s->w; p.so = 1;
+  p.M = s->n * p.MH * p.MW;
+  p.Hin = s->ho; p.Win = s->wo; p.ldin = s->out_ld; p.Cin = s->cout; p.sin = 1;
+  p.Hout = s->h; p.Wout = s->w; p.ldout = cin_pad;
+  p.ynstride = (long long)s->h * s->w * cin_pad;
+  p.Cout = cin_pad; p.CoutPad = cin_pad;                          // the padded channels of the partial tiles are exact zeros (zero weight rows)
+  p.ksplit = ks;
+  p.ysplit = (long long)p.M * cin_pad;
+  p.dMW = make_fastdiv((unsigned)p.MW);
+  p.dMH = make_fastdiv((unsigned)p.MH);
+  set_tap_pad(p);
+  p.lin_in = p.T == 1 && p.dy[0] == 0 && p.dx[0] == 0 && p.sin == 1 && p.MH == p.Hin && p.MW == p.Win;
+  p.lin_out = 1;
+  if (int e = launch_cfg<2, 2, 4, 4, 64, 2, EPI_F32>(p, S(stream))) return e;
+  const long long total = (long long)p.M * (s->cin / 8);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)min((long long)2048, (total + 255) / 256)), dim3(256), 0, S(stream), (const float*)workspace, ks, p.ysplit,
+                     (bf16_t*)dx, s->in_ld, (const bf16_t*)residual, residual_ld, (long long)p.M, s->cin, cin_pad);
+  return check_launch("conv_dgrad_ws");
 }
 
 int mi355det_conv_dgrad_bn_rows(const mi355det_conv_shape* s) {

@@ -512,6 +512,7 @@ int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st) {
     case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st);
     case EPI_RES: return launch8<EPI_RES>(p, st);
     case EPI_AFF: return launch8<EPI_AFF>(p, st);
+    case EPI_F32: return launch8<EPI_F32>(p, st);      // fp32 head outputs (the 1204-class cls_logits: Cout padded to 256)
     default: break;
   }
   return fail(MI355DET_EINVAL, "%s: epilogue not built for the phase-staggered kernel", "igemm8");

@@ -51,6 +51,9 @@ struct IgemmParams {
   FastDiv dMW, dMH;
   int tap_pad;           // elements: -min over taps of (dy*Win+dx)*ldin, >= 0 (keeps scalar tap offsets non-negative)
   unsigned long long dy_pack, dx_pack;   // 4-bit fields (value+2) per tap: the tap table in two scalar registers
+  int ksplit;            // > 1: split-K over the channel axis (igemm_kernel, EPI_F32 only): grid = tiles * ksplit, split sp reduces channels
+                         //      [sp*Cin/ksplit, (sp+1)*Cin/ksplit) of every tap and writes its fp32 partial tile at y + sp * ysplit
+  long long ysplit;      // elements between the partial outputs of two splits
   int lin_in, lin_out;   // 1: lattice pixel m IS the input pixel (single centred tap, unit stride) / the output pixel: no divisions per row
   unsigned long long* dbg;   // diagnostic build only (PROF): per-wave phase cycle sums
 };
@@ -157,7 +160,7 @@ __device__ __forceinline__ void write_partial_rows(const IgemmParams& p, const f
 //      takes part in the barrier and the final statistics write)
 template <int WM, int WN, int TM, int TN, int EPI>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&acc)[TN][TM], char* smem, int tid, int nthreads, bool consumer,
-                                               int wm, int wn, int lane, int mt, int n0, int m0) {
+                                               int wm, int wn, int lane, int mt, int n0, int m0, long long yoff = 0) {
   constexpr int BN = WN * TN * 16;
   const int fr = lane & 15, fq = lane >> 4;
   // ---- epilogue: lane holds channels co = n0 + wn*TN*16 + i*16 + fq*4 + r (r=0..3) of pixel
@@ -199,7 +202,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
       const int oy = yy * p.so + p.oy0, ox = xx * (p.sox ? p.sox : p.so) + p.ox0;
       if (oy >= p.Hout || ox >= p.Wout) continue;
-      float* orow = (float*)p.y + (long long)n * p.ynstride + (long long)(oy * p.Wout + ox) * p.ldout;
+      float* orow = (float*)p.y + yoff + (long long)n * p.ynstride + (long long)(oy * p.Wout + ox) * p.ldout;
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int co = n0 + wn * (TN * 16) + i * 16 + fq * 4;

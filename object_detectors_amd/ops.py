@@ -268,6 +268,8 @@ def pad_to(v, m):
 
 
 def cout_pad_of(cout):
+    if cout >= 2048:
+        return pad_to(cout, 256)        # very wide outputs (the 1204-class RetinaNet head: 10 836): whole 256-channel tiles for igemm8
     return pad_to(cout, 128) if cout >= 128 or cout % 32 else cout
 
 
@@ -410,12 +412,29 @@ def upsample_nearest_bwd(g, hw, accumulate=None):
 
 
 def retina_loss(cls_logits, bbox_regression, anchors, matched, gt_boxes, gt_labels, gt_offsets, k=None, class_scale=None, alpha=0.25, gamma=2.0,
-                want_grad=True, grad_scale=1.0, grad_logits=None, grad_regression=None):
-    """Batched RetinaNetHead.compute_loss.  -> (losses[2] = (classification, bbox_regression), num_fg [N], grad_logits, grad_regression)."""
+                want_grad=True, grad_scale=1.0, grad_logits=None, grad_regression=None, cls_levels=None, anchors_per_pixel=None):
+    """Batched RetinaNetHead.compute_loss.  -> (losses[2] = (classification, bbox_regression), num_fg [N], grad_logits, grad_regression).
+    cls_levels (list of bf16 [n, h, w, ld] buffers, one per pyramid level, + anchors_per_pixel): the class gradient is written there in the
+    head convolution's layout instead of an fp32 grad_logits (returned as None)."""
     n, rows, k = cls_logits.shape
     dev = cls_logits.device
     losses = torch.empty(2, device=dev)
     nfg = torch.empty(n, device=dev)
+    if cls_levels is not None:
+        from ._lib import LevelGrads
+        if len(cls_levels) > 8 or not anchors_per_pixel:
+            raise ValueError("retina_loss: at most 8 levels, and anchors_per_pixel is required with cls_levels")
+        lv = LevelGrads()
+        lv.n_levels, lv.anchors_per_pixel = len(cls_levels), int(anchors_per_pixel)
+        for q, t in enumerate(cls_levels):
+            if t.dtype != torch.bfloat16 or t.dim() != 4 or t.shape[0] != n or not t.is_contiguous():
+                raise ValueError("retina_loss: cls_levels must be contiguous bf16 [n, h, w, ld] tensors")
+            lv.pixels[q], lv.grad[q], lv.grad_ld[q] = t.shape[1] * t.shape[2], t.data_ptr(), t.shape[3]
+        grad_regression = torch.empty_like(bbox_regression) if grad_regression is None else grad_regression
+        check(lib().mi355det_retina_loss_lv(ptr(cls_logits), ptr(bbox_regression), ptr(anchors), ptr(matched), ptr(gt_boxes), ptr(gt_labels),
+                                            ptr(gt_offsets), ptr(class_scale), n, rows, k, float(alpha), float(gamma), float(grad_scale), ptr(nfg),
+                                            ptr(losses), C.byref(lv), ptr(grad_regression), stream_ptr()), "retina_loss_lv")
+        return losses, nfg, None, grad_regression
     if want_grad:
         grad_logits = torch.empty_like(cls_logits) if grad_logits is None else grad_logits
         grad_regression = torch.empty_like(bbox_regression) if grad_regression is None else grad_regression

@@ -14,6 +14,7 @@ FrozenBatchNorm2d (utilities/resnet.py:87-143,230-240; backbone_utils.py:67-110)
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -299,10 +300,18 @@ class RetinaNetEngine:
             gt_labels = torch.cat([t["labels"].reshape(-1).long() for t in targets])
         else:
             gt_boxes, gt_labels = torch.zeros((1, 4), device=self.device), torch.zeros(1, dtype=torch.int64, device=self.device)
-        losses, nfg, _, _ = ops.retina_loss(p.logits, p.bbox_reg, p.anchors, p.matched, gt_boxes, gt_labels, offs, class_scale=class_scale,
-                                            grad_scale=grad_scale, grad_logits=p.glogits, grad_regression=p.gbbox)
+        # the class gradient goes straight into the bf16 per-level buffers the cls_logits backward reads (no fp32 gradient tensor, no cast);
+        # MI355DET_HEAD_GRAD_FP32=1 keeps the round-2 route (fp32 glogits + cast_rows) for A/B
+        if os.environ.get("MI355DET_HEAD_GRAD_FP32", "0") == "1":
+            losses, nfg, _, _ = ops.retina_loss(p.logits, p.bbox_reg, p.anchors, p.matched, gt_boxes, gt_labels, offs, class_scale=class_scale,
+                                                grad_scale=grad_scale, grad_logits=p.glogits, grad_regression=p.gbbox)
+            p.load_head_grads()
+        else:
+            levels = [p.head_grads[("cls_logits", lvl)] for lvl in range(len(p.level_sizes))]
+            losses, nfg, _, _ = ops.retina_loss(p.logits, p.bbox_reg, p.anchors, p.matched, gt_boxes, gt_labels, offs, class_scale=class_scale,
+                                                grad_scale=grad_scale, grad_regression=p.gbbox, cls_levels=levels, anchors_per_pixel=self.na)
+            p.load_head_grads(cls=False)
         self.last_num_foreground = nfg
-        p.load_head_grads()
         p.run_backward()
         return losses
 
@@ -522,15 +531,18 @@ class RetinaPlan:
         A, K, n = eng.na, eng.nc, self.n
         # bf16 head-gradient buffers per level (padded channel pitch), filled from the fp32 loss gradients by cast_rows
         self.head_grads = {}
-        self.cast = []
+        self.cast, self.cast_box = [], []
         for lvl, (h, w) in enumerate(self.level_sizes):
             row0 = sum(self.level_rows[:lvl])
             for key, src, k in (("cls_logits", self.glogits, K), ("bbox_reg", self.gbbox, 4)):
                 ld = ops.pad_to(A * k, 64)          # = Conv.cout_store of the head convolutions
                 gbuf = torch.zeros((n, h, w, ld), device=dev, dtype=bf)
                 self.head_grads[(key, lvl)] = gbuf
-                self.cast.append((L.mi355det_cast_rows_bf16, (C.c_void_p(src.data_ptr() + 4 * row0 * k), self.rows * k, A * k, n, h * w, A * k, 1.0,
-                                                              _vp(gbuf), ld, self.stream)))
+                call = (L.mi355det_cast_rows_bf16, (C.c_void_p(src.data_ptr() + 4 * row0 * k), self.rows * k, A * k, n, h * w, A * k, 1.0,
+                                                    _vp(gbuf), ld, self.stream))
+                self.cast.append(call)
+                if key == "bbox_reg":
+                    self.cast_box.append(call)
         dz_elems = max(r["shp"].n * r["shp"].ho * r["shp"].wo * r["shp"].cout for r in self.ops if r["kind"] == "conv")
         self.dz2 = [torch.zeros(dz_elems, device=dev, dtype=bf) for _ in range(2)]
         self.side = torch.cuda.Stream(device=dev)
@@ -559,6 +571,16 @@ class RetinaPlan:
             else:
                 x.parts.append(t)
 
+        # split-K data gradients (few pixels, deep reduction: the LVIS cls_logits on the small levels) share one fp32 workspace; they run
+        # one after the other on the main stream
+        dws_need = max(L.mi355det_conv_dgrad_workspace(C.byref(r["shp"])) for r in self.ops if r["kind"] == "conv")
+        self.dgrad_ws = torch.empty(max(dws_need, 16), device=dev, dtype=torch.uint8) if dws_need else None
+
+        def dgrad_call(shp, dy_ptr, wd, g, rptr, rld):
+            if self.dgrad_ws is not None and L.mi355det_conv_dgrad_workspace(C.byref(shp)):
+                return (L.mi355det_conv_dgrad_ws, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, rptr, rld, _vp(self.dgrad_ws), self.dgrad_ws.numel(), self.stream))
+            return (L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, rptr, rld, self.stream))
+
         def add_dgrad(x, shp, dy_ptr, wd):
             if not x.needs_grad:
                 return
@@ -566,10 +588,10 @@ class RetinaPlan:
                 x.grad = dense(x)
             g = x.grad
             if x.grad_written:
-                self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, g.ptr, g.ld, self.stream)))
+                self.bwd.append(dgrad_call(shp, dy_ptr, wd, g, g.ptr, g.ld))
             else:
                 r = x.parts.pop(0) if x.parts else None
-                self.bwd.append((L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, r.ptr if r else None, r.ld if r else 0, self.stream)))
+                self.bwd.append(dgrad_call(shp, dy_ptr, wd, g, r.ptr if r else None, r.ld if r else 0))
                 x.grad_written = True
                 while x.parts:
                     t = x.parts.pop(0)
@@ -752,8 +774,15 @@ class RetinaPlan:
         self._run(self.pack)
         self._run(self.fwd)
 
-    def load_head_grads(self):
-        self._run(self.cast)
+    def head_gradient(self, key="cls_logits"):
+        """The bf16 head gradient the backward consumes, re-assembled as fp32 [n, rows, k] (tests / diagnostics)."""
+        A = self.eng.na
+        k = self.eng.nc if key == "cls_logits" else 4
+        parts = [self.head_grads[(key, lvl)][..., :A * k].float().reshape(self.n, -1, k) for lvl in range(len(self.level_sizes))]
+        return torch.cat(parts, dim=1)
+
+    def load_head_grads(self, cls=True):
+        self._run(self.cast if cls else self.cast_box)
 
     def run_backward(self):
         self.eng.flat_g.zero_()

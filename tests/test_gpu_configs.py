@@ -127,7 +127,8 @@ def test_config5_r101_lvis_train_step(r101):
     cl, rl, mis, (gc, gr) = tv.retinanet_loss(p.logits.cpu().numpy(), p.bbox_reg.cpu().numpy(), p.anchors.cpu().numpy(), gts, tfidf=tfidf)
     assert np.array_equal(p.matched.cpu().numpy(), np.stack(mis))
     np.testing.assert_allclose(losses.cpu().numpy(), [cl, rl], rtol=5e-4)
-    np.testing.assert_allclose(p.glogits.cpu().numpy(), gc, rtol=3e-3, atol=1e-7)
+    # the fused focal kernel writes the class gradient as bf16 into the level buffers of the cls_logits backward (no fp32 tensor)
+    np.testing.assert_allclose(p.head_gradient("cls_logits").cpu().numpy(), gc, rtol=6e-3, atol=1e-7)
     np.testing.assert_allclose(p.gbbox.cpu().numpy(), gr, rtol=1e-5, atol=1e-9)
     # parameter gradients of the R101 body / FPN / heads vs fp32 autograd of the oracle driven by the oracle's loss gradient
     sdg = {k: v.clone() for k, v in sd.items()}

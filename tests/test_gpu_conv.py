@@ -614,3 +614,54 @@ def test_stride2_dgrad_class_concatenated_form(case, with_res):
     assert float((outs[0] - want).abs().max()) <= 2e-2 * scale
     assert float((outs[1] - want).abs().max()) <= 2e-2 * scale
     assert float((outs[1] - outs[0]).abs().max()) <= 1e-2 * scale
+
+
+@pytest.mark.parametrize("case", [(2, 7, 7, 256, 1024, 3), (1, 13, 13, 128, 2176, 3), (3, 5, 9, 256, 8192, 1)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_dgrad_split_k_small_maps(case, with_res):
+    """Data gradient with few output pixels and a deep reduction (the 1204-class RetinaNet head on the small pyramid levels,
+    retinanet.py:75-105): mi355det_conv_dgrad_ws splits the channel axis over workgroups (fp32 partial tiles, fixed-order sum, one rounding)
+    - against the plain launch and against PyTorch fp32; the workspace query is 0 where the form does not apply, and conv_dgrad_ws is then
+    conv_dgrad; a short workspace is refused."""
+    import ctypes as C
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    n, h, w, cin, cout, k = case
+    x = rnd((n, cin, h, w), 41)
+    wt = rnd((cout, cin, k, k), 42, (2.0 / (cin * k * k)) ** 0.5)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt, stride=1, padding=k // 2)
+    gy = rnd(tuple(y_ref.shape), 43)
+    y_ref.backward(gy)
+    res = rnd((n, cin, h, w), 44)
+    want = xr.grad + (res if with_res else 0)
+    shape = ops.conv_shape(n, h, w, cin, cout, k, 1)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    gyd = nhwc(gy)
+    resd = nhwc(res) if with_res else None
+    L = lib()
+    need = L.mi355det_conv_dgrad_workspace(C.byref(shape))
+    assert need > 0 and need % (n * h * w * cin * 4) == 0          # a whole number of fp32 partial tensors
+    ws = torch.empty(need, device=dev(), dtype=torch.uint8)
+    dx_s = torch.full((n, h, w, cin), 7.0, device=dev(), dtype=torch.bfloat16)
+    check(L.mi355det_conv_dgrad_ws(C.byref(shape), ptr(gyd), ptr(wd), ptr(dx_s), ptr(resd), cin if with_res else 0, ptr(ws), ws.numel(), stream_ptr()),
+          "conv_dgrad_ws")
+    dx_p = torch.full((n, h, w, cin), 7.0, device=dev(), dtype=torch.bfloat16)
+    ops.conv_dgrad(shape, gyd, wd, dx_p, residual=resd, residual_ld=cin if with_res else 0)
+    torch.cuda.synchronize()
+    a, b = dx_s.float().cpu().permute(0, 3, 1, 2), dx_p.float().cpu().permute(0, 3, 1, 2)
+    scale = float(want.abs().max())
+    assert float((a - want).abs().max()) <= 2e-2 * scale
+    assert float((b - want).abs().max()) <= 2e-2 * scale
+    assert float((a - b).abs().max()) <= 1e-2 * scale
+    # deterministic: a second run is bit-identical
+    dx_2 = torch.empty_like(dx_s)
+    check(L.mi355det_conv_dgrad_ws(C.byref(shape), ptr(gyd), ptr(wd), ptr(dx_2), ptr(resd), cin if with_res else 0, ptr(ws), ws.numel(), stream_ptr()),
+          "conv_dgrad_ws")
+    torch.cuda.synchronize()
+    assert torch.equal(dx_2, dx_s)
+    with pytest.raises(ValueError):
+        check(L.mi355det_conv_dgrad_ws(C.byref(shape), ptr(gyd), ptr(wd), ptr(dx_2), None, 0, ptr(ws), 1024, stream_ptr()), "conv_dgrad_ws")
+    # a big map is not split: no workspace, and the _ws entry falls through to the plain launch
+    big = ops.conv_shape(2, 64, 64, 128, 256, 3, 1)
+    assert L.mi355det_conv_dgrad_workspace(C.byref(big)) == 0

@@ -201,3 +201,48 @@ def test_retina_loss_batched_vs_oracle(golden):
         np.testing.assert_allclose(losses.cpu().numpy(), [cl, rl], rtol=2e-4)
         np.testing.assert_allclose(glog.cpu().numpy(), gc, rtol=2e-3, atol=1e-7)
         np.testing.assert_allclose(greg.cpu().numpy(), gr, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("K", [91, 36])
+def test_retina_loss_level_gradients_equal_the_cast_of_the_fp32_gradient(golden, K):
+    """mi355det_retina_loss_lv writes the class gradient as bf16 straight into the per-level NHWC buffers of the cls_logits backward
+    (channel a*K + c of a pixel): bit-identical to casting the fp32 gradient of mi355det_retina_loss row by row (what the engine did
+    before), same losses, padding channels untouched.  K = 91 (rows straddle the 4-element vector groups) and K = 36 (K % 4 == 0)."""
+    from object_detectors_amd import ops
+    from object_detectors_amd.tvision._utils import Matcher
+    from tests.test_oracle_tv import build_anchors
+    g = golden("g5_7_tvision")
+    anchors = build_anchors(g, "retina_small")
+    N, b, A = anchors.shape[0], 3, 9
+    assert N % A == 0
+    pix = N // A
+    parts = [pix - pix // 3 - pix // 7, pix // 3, pix // 7]            # three "levels" of h = 1
+    gts = []
+    for i in range(b):
+        m = [4, 1, 6][i]
+        side = detrand.uniform(150 + i, (m, 2), 16, 90)
+        tl = detrand.uniform(160 + i, (m, 2), 0, 1) * (np.array([160, 128], np.float32) - side)
+        gts.append((np.concatenate([tl, tl + side], 1).astype(np.float32), detrand.randint(170 + i, (m,), 1, K)))
+    logits = T(detrand.uniform(180, (b, N, K), -6, 2))
+    reg = T(detrand.uniform(181, (b, N, 4), -1, 1))
+    mt = Matcher(0.5, 0.4, True)
+    matched = torch.stack([mt.match_boxes(T(bx), T(anchors)) for bx, _ in gts])
+    gt_boxes = T(np.concatenate([bx for bx, _ in gts]))
+    gt_labels = T(np.concatenate([lb for _, lb in gts]).astype(np.int64))
+    offs = T(np.cumsum([0] + [len(lb) for _, lb in gts]).astype(np.int32))
+    losses, nfg, glog, greg = ops.retina_loss(logits, reg, T(anchors), matched, gt_boxes, gt_labels, offs)
+    ld = ops.pad_to(A * K, 64)
+    levels = [torch.full((b, 1, p, ld), 3.0, device=logits.device, dtype=torch.bfloat16) for p in parts]
+    losses2, nfg2, none, greg2 = ops.retina_loss(logits, reg, T(anchors), matched, gt_boxes, gt_labels, offs, cls_levels=levels, anchors_per_pixel=A)
+    torch.cuda.synchronize()
+    assert none is None
+    assert torch.equal(nfg, nfg2) and torch.equal(greg, greg2)
+    np.testing.assert_allclose(losses2.cpu().numpy(), losses.cpu().numpy(), rtol=1e-5)      # the loss word is an atomic sum: order may differ
+    row0 = 0
+    for p, buf in zip(parts, levels):
+        want = glog[:, row0:row0 + p * A, :].reshape(b, 1, p, A * K).to(torch.bfloat16)
+        assert torch.equal(buf[..., :A * K], want)
+        assert bool((buf[..., A * K:] == 3.0).all())                                         # padding channels are not written
+        row0 += p * A
+    with pytest.raises(ValueError):
+        ops.retina_loss(logits, reg, T(anchors), matched, gt_boxes, gt_labels, offs, cls_levels=levels[:2], anchors_per_pixel=A)   # rows do not add up

@@ -152,12 +152,14 @@ def test_train_step_losses_and_matching(setup):
     cl, rl, mis, (gc, gr) = tv.retinanet_loss(p.logits.cpu().numpy(), p.bbox_reg.cpu().numpy(), anchors, gts)
     assert np.array_equal(p.matched.cpu().numpy(), np.stack(mis))
     np.testing.assert_allclose(losses.cpu().numpy(), [cl, rl], rtol=3e-4)
-    np.testing.assert_allclose(p.glogits.cpu().numpy(), gc, rtol=2e-3, atol=1e-7)
     np.testing.assert_allclose(p.gbbox.cpu().numpy(), gr, rtol=1e-5, atol=1e-9)
-    # the bf16 level buffers hold exactly those gradients (cast_rows): level 0 of the classification head
-    g0 = p.head_grads[("cls_logits", 0)][..., :9 * 91].float().reshape(BS, -1, 91).cpu()
-    ref0 = p.glogits[:, :p.level_rows[0]].bfloat16().float().cpu()
-    assert torch.equal(g0, ref0)
+    # the class gradient is written by the loss kernel straight into the bf16 level buffers of the cls_logits backward (no fp32 tensor):
+    # every level holds the bf16 rounding of the oracle's gradient rows
+    row0 = 0
+    for lvl, rows in enumerate(p.level_rows):
+        gl = p.head_grads[("cls_logits", lvl)][..., :9 * 91].float().reshape(BS, -1, 91).cpu().numpy()
+        np.testing.assert_allclose(gl, gc[:, row0:row0 + rows], rtol=5e-3, atol=1e-7)
+        row0 += rows
     assert float(eng.flat_g.abs().sum()) > 0
 
 
