@@ -314,6 +314,17 @@ int mi355det_stem_bwd_apply_wgrad(const float* img, const void* w, const float* 
                                   const void* da, int32_t da_ld, float* slab, float* dw, float* dgamma, float* dbeta,
                                   int32_t n, int32_t h, int32_t wd, void* stream);
 
+/* The stem's backward in ONE pass over the activation gradient instead of stem_bwd_reduce + stem_bwd_apply_wgrad (same reference lines:
+ * the autograd of darknet.py:41-43,74-76).  stem_bwd_fused accumulates, on MFMA over the pixels, A[32][32] = dy^T [im2col | 1] and the Gram
+ * matrix G[32][32] = [im2col | 1]^T [im2col | 1] into slab[rows][2][32][32] (rows = mi355det_stem_rows), folds them into ag[2][32][32] and
+ * derives sums[64] = (sum dy, sum dy*xhat) from A (sum dy = A[:,27], sum dy*z = <W, A>).  stem_bwd_finish then forms, from ag and the -
+ * possibly rank-averaged, SyncBN - sums, dW += scale*(A - mean(dy)*B - mean(dy*xhat)*invstd*(W G - mean*B)) with B = G[27,:], and adds
+ * dgamma += sums[32:], dbeta += sums[:32] (both nullable together).  count = n*h*w of THIS rank.  dw is [32][32] fp32 (k padded). */
+int mi355det_stem_bwd_fused(const float* img, const void* w, const float* scale_shift, float slope, const void* da, int32_t da_ld,
+                            float* slab, float* ag, float* sums, int32_t n, int32_t h, int32_t wd, void* stream);
+int mi355det_stem_bwd_finish(const void* w, const float* scale_shift, const float* ag, const float* sums, int64_t count, float* dw,
+                             float* dgamma, float* dbeta, void* stream);
+
 /* Data gradient: dx = conv_transpose(dy, w); wt packed for dgrad by mi355det_pack_weights.
  * residual != NULL adds a bf16 tensor (same shape as dx) in the epilogue (residual-block skip). */
 int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx,

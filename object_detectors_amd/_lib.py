@@ -102,6 +102,8 @@ PROTOTYPES = {
     "mi355det_stem_fwd_apply": (C.c_int, [vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]),
     "mi355det_stem_bwd_reduce": (C.c_int, [vp, vp, vp, f32, vp, i32, vp, i32, i32, i32, vp]),
     "mi355det_stem_bwd_apply_wgrad": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mi355det_stem_bwd_fused": (C.c_int, [vp, vp, vp, f32, vp, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "mi355det_stem_bwd_finish": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp, vp]),
     "mi355det_bn_finalize": (C.c_int, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "mi355det_bn_eval_scale_shift": (C.c_int, [i32, vp, vp, vp, vp, f32, vp, vp]),
     "mi355det_bn_fold_partials_f64": (C.c_int, [vp, i32, i32, i32, vp, vp]),

@@ -11,6 +11,10 @@
 //   MODE 2  stem_bwd_reduce       dy = da * lrelu'(.), sum dy, sum dy*xhat         -> partial rows (bn_bwd_sum_partials makes the sums)
 //   MODE 3  stem_bwd_apply_wgrad  dz = scale*(dy - mean dy - xhat*mean dy*xhat)    -> dW[32][32] += dz^T * im2col (MFMA over pixels: dz goes
 //                                 through a wave-private LDS tile and comes back transposed with ds_read_b64_tr_b16); dz never exists in HBM
+//   MODE 4  stem_bwd_fused        ONE backward pass instead of MODE 2 + MODE 3: A[32][32] = dy^T * [im2col | 1] and the Gram matrix
+//                                 G[32][32] = [im2col | 1]^T * [im2col | 1] (both on MFMA over pixels).  Everything the stem's backward
+//                                 needs is linear in them (stem_bwd_finish_kernel): sum dy = A[:,27], sum dy*z = <W, A>, and
+//                                 dW = scale*(A - mean(dy)*B - mean(dy*xhat)*invstd*(W*G - mean*B)) with B = G[27,:] = sum im2col
 //
 // Channel order trick: MFMA row r of weight fragment i stands for channel (r/4)*8 + i*4 + r%4, so that a lane's two accumulator quads
 // are the 8 CONSECUTIVE channels fq*8 .. fq*8+7 of its pixel: loads and stores of the activation / gradient tensors are 16 bytes per lane
@@ -36,8 +40,10 @@ constexpr int P = 36;                      // LDS row pitch of the halo tile (bf
 constexpr int IMG_ELEMS = 3 * HR * P;      // 1080
 constexpr int ZBASE = IMG_ELEMS * 2;        // 128 zero bytes behind the halo tile: the padded k columns 27..31 read them at every fragment offset
 constexpr int DUMP = ZBASE + 128;           // where the surplus lanes of the halo fetch (1020 values on 1024 lanes) put their value
-constexpr int IMG_BYTES = DUMP + 16;
+constexpr int ONES = DUMP + 16;             // 96 bytes of bf16 1.0: the k = 27 column of MODE 4's im2col operand (sum dy and sum im2col come out of the same MFMAs)
+constexpr int IMG_BYTES = ONES + 96;
 static_assert(ZBASE % 16 == 0 && (P + 16) * 2 + 2 <= 128 && (P + 7) * 2 + 2 <= 128, "zero slot covers every fragment offset");
+static_assert(IMG_BYTES % 16 == 0 && (P + 7) * 2 + 2 <= 96, "ones slot covers every wgrad operand offset");
 constexpr int HALO = 3 * HR * HC;          // 1020 values to fetch per tile
 constexpr int PER_T = (HALO + 255) / 256;  // 4 per thread
 constexpr int DZ_WAVE = 2 * TW * 64;       // wave-private dz tile: 2 rows x 32 pixels x 32 channels bf16
@@ -49,7 +55,7 @@ struct StemParams {
   const float* sums;      // [2*32] sum dy, sum dy*xhat (MODE 3)
   const bf16_t* da;       // gradient of the activation (MODE 2, 3), pitch ld
   bf16_t* a;              // activation out (MODE 1), pitch ld
-  float* partial;         // MODE 0 / 2: [grid][2][32]; MODE 3: slab [grid][32][32]
+  float* partial;         // MODE 0 / 2: [grid][2][32]; MODE 3: slab [grid][32][32]; MODE 4: slab [grid][2][32][32] (A, G)
   int ld;
   int n, H, W, tiles_x, tiles_y, ntiles;
   int rows_total;         // rows the caller allocated (mi355det_stem_rows): the rows beyond this launch's grid are zero-filled
@@ -75,7 +81,7 @@ __device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const StemParams p) {
+__global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem_kernel(const StemParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [2 image buffers][MODE 3: 4 wave-private dz tiles][end-of-kernel reduction scratch aliases the front]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -126,20 +132,24 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
   float s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) s1[k] = s2[k] = 0.f;
-  f32x4_t accw[2][2];
+  f32x4_t accw[2][2], accg[MODE == 4 ? 2 : 1][MODE == 4 ? 2 : 1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) accw[i][j] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) {
+      accw[i][j] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (MODE == 4) accg[i][j] = {0.f, 0.f, 0.f, 0.f};
+    }
 
-  // wgrad B operand (MODE 3): lane = k column fr of block jb, pixels fq*8 .. fq*8+7 of a tile row -> 8 consecutive halo elements
+  // wgrad B operand (MODE 3, 4): lane = k column fr of block jb, pixels fq*8 .. fq*8+7 of a tile row -> 8 consecutive halo elements;
+  // MODE 4: column 27 reads the ones slot
   int wb_addr[2];
-  if (MODE == 3) {
+  if (MODE >= 3) {
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
       const int k = jb * 16 + fr;
       const int t = k / 3, c = k - t * 3, kh = t / 3, kw = t - kh * 3;
-      wb_addr[jb] = k < 27 ? (((c * HR + kh + 2 * wid) * P) + kw + fq * 8) * 2 : ZBASE;
+      wb_addr[jb] = k < 27 ? (((c * HR + kh + 2 * wid) * P) + kw + fq * 8) * 2 : (MODE == 4 && k == 27 ? ONES : ZBASE);
     }
   }
   char* const dzt = smem + 2 * IMG_BYTES + wid * DZ_WAVE;
@@ -199,8 +209,9 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
       gv[s_][f] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_act, act_lane, frag_soff(b, y0, x0, f), 0));
   };
 
-  // the zero slots behind both image buffers (store_halo never touches them)
+  // the zero slots behind both image buffers (store_halo never touches them), and the ones slots
   if (tid < 64) *(unsigned*)(smem + (tid >> 5) * IMG_BYTES + ZBASE + (tid & 31) * 4) = 0u;
+  if (tid >= 64 && tid < 112) *(unsigned*)(smem + ((tid - 64) / 24) * IMG_BYTES + ONES + ((tid - 64) % 24) * 4) = 0x3F803F80u;
 
   typedef std::integral_constant<int, 0> S0;
   typedef std::integral_constant<int, 1> S1;
@@ -284,8 +295,8 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
           s2[k] += dy * (z * ca[k] + cb[k]);
         }
       }
-      if (MODE == 3) {
-        // dz -> wave-private LDS tile [pixel row 0..63][32 channels], 32-byte blocks XOR-swizzled by bit 3 of the pixel row
+      if (MODE >= 3) {
+        // dz (MODE 4: dy) -> wave-private LDS tile [pixel row 0..63][32 channels], 32-byte blocks XOR-swizzled by bit 3 of the pixel row
         const unsigned gi[4] = {gv[s_][f].x, gv[s_][f].y, gv[s_][f].z, gv[s_][f].w};
         unsigned short o[8];
 #pragma unroll
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
           const float gg = __uint_as_float((k & 1) ? (gi[k >> 1] & 0xFFFF0000u) : (gi[k >> 1] << 16));
           const float y = z * sc[k] + sh[k];
           const float dy = y > 0.f ? gg : gg * p.slope;
-          o[k] = f2bf(ca[k] * dy + (cb[k] * z + cc[k]));
+          o[k] = f2bf(MODE == 4 ? dy : ca[k] * dy + (cb[k] * z + cc[k]));
         }
         uint4 w4;
         w4.x = o[0] | ((unsigned)o[1] << 16);
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
       }
     }
     if (MODE >= 2 && nxt2 < p.ntiles) fetch_grad(nxt2, SLOT);      // this slot's gradient registers are consumed: refill them two tiles ahead
-    if (MODE == 3) {
+    if (MODE >= 3) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       // dW[co][k] += sum over the 32 pixels of each of the wave's two tile rows
@@ -344,6 +355,13 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb) accw[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[jb], accw[i][jb], 0, 0, 0);
+        if constexpr (MODE == 4) {
+          // Gram matrix of the (im2col | 1) operand: the B fragment of columns ja*16 + fr IS the A fragment of rows ja*16 + fr of its transpose
+#pragma unroll
+          for (int ja = 0; ja < 2; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) accg[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ja], bfr[jb], accg[ja][jb], 0, 0, 0);
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
   __syncthreads();
   float* red = (float*)smem;
   {
-    const int rowf = MODE == 3 ? 1024 : 64;
+    const int rowf = MODE == 4 ? 2048 : MODE == 3 ? 1024 : 64;
     for (int r = blockIdx.x + gridDim.x; r < p.rows_total; r += gridDim.x)
       for (int i = tid; i < rowf; i += 256) p.partial[(long long)r * rowf + i] = 0.f;
   }
@@ -400,6 +418,81 @@ __global__ __launch_bounds__(256, (MODE >= 2 ? 3 : 4)) void stem_kernel(const St
     __syncthreads();
     float* dst = p.partial + (long long)blockIdx.x * 1024;
     for (int i = tid; i < 1024; i += 256) dst[i] = (red[i] + red[1024 + i]) + (red[2048 + i] + red[3072 + i]);
+  }
+  if constexpr (MODE == 4) {
+    // per wave [A 32x32 | G 32x32]; A rows = plain channels i*16 + fq*4 + r, G rows = k index ja*16 + fq*4 + r; columns = k index jb*16 + fr
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[wid * 2048 + (i * 16 + fq * 4 + r) * 32 + jb * 16 + fr] = accw[i][jb][r];
+          red[wid * 2048 + 1024 + (i * 16 + fq * 4 + r) * 32 + jb * 16 + fr] = accg[i][jb][r];
+        }
+    __syncthreads();
+    float* dst = p.partial + (long long)blockIdx.x * 2048;
+    for (int i = tid; i < 2048; i += 256) dst[i] = (red[i] + red[2048 + i]) + (red[4096 + i] + red[6144 + i]);
+  }
+}
+
+// ---- MODE 4 tail, part 1: AG[2][32][32] = sum of the workgroup slabs (fixed order: 8 row parts per column, LDS tree), 32 columns per block
+__global__ __launch_bounds__(256) void stem_bwd_fold_kernel(const float* __restrict__ slab, int rows, float* __restrict__ ag) {
+  __shared__ float red[8][32];
+  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + col;
+  float s0 = 0.f, s1 = 0.f;
+  int r = part;
+  for (; r + 8 < rows; r += 16) {
+    s0 += slab[(long long)r * 2048 + i];
+    s1 += slab[(long long)(r + 8) * 2048 + i];
+  }
+  if (r < rows) s0 += slab[(long long)r * 2048 + i];
+  red[part][col] = s0 + s1;
+  __syncthreads();
+  if (part == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][col];
+    ag[i] = t;
+  }
+}
+// the BatchNorm-backward sums A implies: sums[c] = sum dy_c = A[c][27];  sums[32 + c] = sum dy_c * xhat_c = invstd_c * (<W[c], A[c]> - mean_c * A[c][27])
+__global__ __launch_bounds__(64) void stem_bwd_sums_kernel(const float* __restrict__ ag, const bf16_t* __restrict__ w, const float* __restrict__ ss,
+                                                           float* __restrict__ sums) {
+  const int c = threadIdx.x;
+  if (c >= 32) return;
+  float dot = 0.f;
+  for (int j = 0; j < 27; ++j) dot += bf2f(w[c * 32 + j]) * ag[c * 32 + j];
+  const float sdy = ag[c * 32 + 27];
+  sums[c] = sdy;
+  sums[32 + c] = ss[96 + c] * (dot - ss[64 + c] * sdy);
+}
+
+// ---- MODE 4 tail, part 2 (after the optional cross-rank average of `sums`): with m1 = sums[c] / count, m2 = sums[32 + c] / count,
+//      B[j] = G[27][j] = sum im2col_j and sum xhat_c * im2col_j = invstd_c * ((W G)[c][j] - mean_c * B[j]):
+//      dW[c][j] += scale_c * (A[c][j] - m1 * B[j] - m2 * invstd_c * ((W G)[c][j] - mean_c * B[j]));  dgamma += sums[32 + c];  dbeta += sums[c]
+__global__ __launch_bounds__(1024) void stem_bwd_finish_kernel(const float* __restrict__ ag, const float* __restrict__ sums, const bf16_t* __restrict__ w,
+                                                               const float* __restrict__ ss, float inv_count, float* __restrict__ dw,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float g_s[1024];
+  __shared__ float w_s[1024];
+  const int t = threadIdx.x;
+  g_s[t] = ag[1024 + t];
+  w_s[t] = bf2f(w[t]);
+  __syncthreads();
+  const int c = t >> 5, j = t & 31;
+  if (j < 27) {
+    float wg = 0.f;
+    for (int q = 0; q < 27; ++q) wg += w_s[c * 32 + q] * g_s[q * 32 + j];
+    const float bj = g_s[27 * 32 + j];
+    const float m1 = sums[c] * inv_count, m2 = sums[32 + c] * inv_count;
+    const float sc = ss[c], mu = ss[64 + c], is = ss[96 + c];
+    dw[t] += sc * (ag[t] - m1 * bj - m2 * is * (wg - mu * bj));
+  }
+  if (t < 32 && dgamma) {
+    dbeta[t] += sums[t];
+    dgamma[t] += sums[32 + t];
   }
 }
 
@@ -466,10 +559,10 @@ StemParams stem_params(const float* img, const void* w, int n, int h, int wd) {
 
 template <int MODE>
 int stem_launch(const char* what, const StemParams& p, hipStream_t st) {
-  constexpr int lds_loop = 2 * IMG_BYTES + (MODE == 3 ? 4 * DZ_WAVE : 0);
-  constexpr int lds_end = MODE == 3 ? 4 * 1024 * 4 : 4 * 32 * 2 * 4;
+  constexpr int lds_loop = 2 * IMG_BYTES + (MODE >= 3 ? 4 * DZ_WAVE : 0);
+  constexpr int lds_end = MODE == 4 ? 4 * 2048 * 4 : MODE == 3 ? 4 * 1024 * 4 : 4 * 32 * 2 * 4;
   constexpr int lds = lds_loop > lds_end ? lds_loop : lds_end;
-  hipLaunchKernelGGL(stem_kernel<MODE>, dim3(stem_grid(p.ntiles, MODE >= 2 ? 3 : 4)), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(stem_kernel<MODE>, dim3(stem_grid(p.ntiles, MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)), dim3(256), lds, st, p);
   return check_launch(what);
 }
 
@@ -535,6 +628,31 @@ int mi355det_stem_bwd_apply_wgrad(const float* img, const void* w, const float* 
   if (int e = stem_launch<3>("stem_bwd_apply_wgrad", p, S(stream))) return e;
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(32), dim3(256), 0, S(stream), slab, stem_grid(p.ntiles), dw, sums, dgamma, dbeta);
   return check_launch("stem_wgrad_reduce");
+}
+
+int mi355det_stem_bwd_fused(const float* img, const void* w, const float* scale_shift, float slope, const void* da, int32_t da_ld, float* slab,
+                            float* ag, float* sums, int32_t n, int32_t h, int32_t wd, void* stream) {
+  if (int e = stem_check("stem_bwd_fused", n, h, wd)) return e;
+  if (!img || !w || !scale_shift || !da || !slab || !ag || !sums || da_ld < 32 || da_ld % 8) return fail(MI355DET_EINVAL, "%s: bad argument", "stem_bwd_fused");
+  if (!(slope > 0.f && slope < 1.f)) return fail(MI355DET_EINVAL, "%s: LeakyReLU slope must be in (0, 1)", "stem_bwd_fused");
+  if ((long long)n * h * wd * da_ld * 2 >= 0x7FFFFFF0ll) return fail(MI355DET_EINVAL, "%s: tensor too large (32-bit byte offsets)", "stem_bwd_fused");
+  StemParams p = stem_params(img, w, n, h, wd);
+  p.ss = scale_shift;
+  p.slope = slope;
+  p.da = (const bf16_t*)da;
+  p.ld = da_ld;
+  p.partial = slab;
+  if (int e = stem_launch<4>("stem_bwd_fused", p, S(stream))) return e;
+  hipLaunchKernelGGL(stem_bwd_fold_kernel, dim3(64), dim3(256), 0, S(stream), slab, stem_grid(p.ntiles), ag);
+  hipLaunchKernelGGL(stem_bwd_sums_kernel, dim3(1), dim3(64), 0, S(stream), ag, (const bf16_t*)w, scale_shift, sums);
+  return check_launch("stem_bwd_fold");
+}
+
+int mi355det_stem_bwd_finish(const void* w, const float* scale_shift, const float* ag, const float* sums, int64_t count, float* dw, float* dgamma,
+                             float* dbeta, void* stream) {
+  if (!w || !scale_shift || !ag || !sums || !dw || count <= 0 || (!dgamma) != (!dbeta)) return fail(MI355DET_EINVAL, "%s: bad argument", "stem_bwd_finish");
+  hipLaunchKernelGGL(stem_bwd_finish_kernel, dim3(1), dim3(1024), 0, S(stream), ag, sums, (const bf16_t*)w, scale_shift, 1.0f / (float)count, dw, dgamma, dbeta);
+  return check_launch("stem_bwd_finish");
 }
 
 }  // extern "C"

@@ -663,17 +663,31 @@ class Plan:
                 wf, _ = eng.packed[name]
                 sums = self.sums_all[sum_off[0]:sum_off[0] + 64]
                 sum_off[0] += 64
-                part = torch.zeros((rows + 64, 2, 32), device=dev, dtype=torch.float32)
-                slab = torch.zeros((rows, 1024), device=dev, dtype=torch.float32)
-                self.keep += [part, slab]
-                self.bwd.append(img_call(L.mi355det_stem_bwd_reduce, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(part), self.n, self.H, self.W,
-                                                                      self.stream)))
-                self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), rows, 32, 32, _vp(sums), self.stream)))
-                if self.sync_world > 1:
-                    py(self._sync_avg, sums)
-                self.bwd.append(img_call(L.mi355det_stem_bwd_apply_wgrad, (_vp(wf), _vp(ss), _vp(sums), SLOPE, g.ptr, g.ld, _vp(slab),
-                                                                           _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
-                                                                           _vp(eng.grads[b + ".bias"]), self.n, self.H, self.W, self.stream)))
+                if os.environ.get("MI355DET_STEM_BWD_TWO_PASS", "0") == "1":
+                    # round-3 first form: two passes over the activation gradient (BN sums, then dz into the weight-gradient MFMA)
+                    part = torch.zeros((rows + 64, 2, 32), device=dev, dtype=torch.float32)
+                    slab = torch.zeros((rows, 1024), device=dev, dtype=torch.float32)
+                    self.keep += [part, slab]
+                    self.bwd.append(img_call(L.mi355det_stem_bwd_reduce, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(part), self.n, self.H, self.W,
+                                                                          self.stream)))
+                    self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), rows, 32, 32, _vp(sums), self.stream)))
+                    if self.sync_world > 1:
+                        py(self._sync_avg, sums)
+                    self.bwd.append(img_call(L.mi355det_stem_bwd_apply_wgrad, (_vp(wf), _vp(ss), _vp(sums), SLOPE, g.ptr, g.ld, _vp(slab),
+                                                                               _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
+                                                                               _vp(eng.grads[b + ".bias"]), self.n, self.H, self.W, self.stream)))
+                else:
+                    # ONE pass: A = dy^T [im2col | 1] and the Gram matrix of [im2col | 1] on MFMA; the BN sums and dW are linear in them
+                    slab = torch.zeros((rows, 2048), device=dev, dtype=torch.float32)
+                    ag = torch.zeros(2048, device=dev, dtype=torch.float32)
+                    self.keep += [slab, ag]
+                    self.bwd.append(img_call(L.mi355det_stem_bwd_fused, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(slab), _vp(ag), _vp(sums),
+                                                                         self.n, self.H, self.W, self.stream)))
+                    if self.sync_world > 1:
+                        py(self._sync_avg, sums)
+                    self.bwd.append((L.mi355det_stem_bwd_finish, (_vp(wf), _vp(ss), _vp(ag), _vp(sums), self.n * self.H * self.W,
+                                                                  _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
+                                                                  _vp(eng.grads[b + ".bias"]), self.stream)))
                 ev_stem = torch.cuda.Event()
                 py(ev_stem.record, main)                  # the stem's gradients come from the main stream: the side stream (last
                 py(self.side.wait_event, ev_stem)         # gradient bucket) must see them

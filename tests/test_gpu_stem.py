@@ -112,6 +112,35 @@ def test_stem_forward_and_backward_match_fp32_reference(shape):
                                           n, h, w, st), "stem_bwd_apply_wgrad")
     torch.cuda.synchronize()
     assert torch.equal(part3[:rows], part2[:rows]) and torch.equal(dw2, dw)
+    # ---- the single-pass form (stem_bwd_fused + stem_bwd_finish): A = dy^T [im2col | 1] and the Gram matrix on MFMA, sums and dW from them
+    slab4 = torch.zeros((rows, 2048), device=dev())
+    ag, sums4 = torch.zeros(2048, device=dev()), torch.zeros(64, device=dev())
+    dw4, dg4, db4 = torch.zeros((32, 32), device=dev()), torch.zeros(32, device=dev()), torch.zeros(32, device=dev())
+    check(L.mi355det_stem_bwd_fused(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(dad), 32, _vp(slab4), _vp(ag), _vp(sums4), n, h, w, st), "stem_bwd_fused")
+    check(L.mi355det_stem_bwd_finish(_vp(wp), _vp(ss), _vp(ag), _vp(sums4), count, _vp(dw4), _vp(dg4), _vp(db4), st), "stem_bwd_finish")
+    torch.cuda.synchronize()
+    s4 = sums4.cpu().double()
+    torch.testing.assert_close(s4[:32], ref["dbeta"], rtol=2e-3, atol=tol)
+    torch.testing.assert_close(s4[32:], ref["dgamma"], rtol=2e-3, atol=tol)
+    torch.testing.assert_close(dg4.cpu().double(), s4[32:], rtol=0, atol=0)
+    torch.testing.assert_close(db4.cpu().double(), s4[:32], rtol=0, atol=0)
+    # the Gram matrix: sum of im2col columns in row 27, pixel count in [27][27], symmetric
+    G = ag[1024:].reshape(32, 32).cpu().double()
+    col = F.unfold(img.double(), 3, padding=1).reshape(n, 3, 9, h * w).permute(0, 3, 2, 1).reshape(-1, 27)          # k = (kh*3+kw)*3 + c
+    torch.testing.assert_close(G[27, :27], col.sum(0), rtol=1e-4, atol=1e-3 * count ** 0.5)
+    assert abs(float(G[27, 27]) - count) <= 1e-6 * count and float((G - G.T).abs().max()) <= 1e-6 * float(G.abs().max())
+    torch.testing.assert_close(G[:27, :27], col.T @ col, rtol=1e-4, atol=1e-5 * count)
+    got4 = dw4.cpu().double()
+    assert float(got4[:, 27:].abs().max()) == 0.0
+    assert float((got4[:, :27] - want).abs().max()) <= 1.5e-2 * float(want.abs().max())
+    assert float((got4[:, :27] * want).sum() / (got4[:, :27].norm() * want.norm())) > 0.9999
+    assert float((got4 - gotw).abs().max()) <= 1e-2 * float(want.abs().max())                 # the two forms agree (different rounding points)
+    dw5 = torch.zeros((32, 32), device=dev())
+    slab5, ag5, sums5 = torch.zeros_like(slab4), torch.zeros_like(ag), torch.zeros_like(sums4)
+    check(L.mi355det_stem_bwd_fused(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(dad), 32, _vp(slab5), _vp(ag5), _vp(sums5), n, h, w, st), "stem_bwd_fused")
+    check(L.mi355det_stem_bwd_finish(_vp(wp), _vp(ss), _vp(ag5), _vp(sums5), count, _vp(dw5), None, None, st), "stem_bwd_finish")
+    torch.cuda.synchronize()
+    assert torch.equal(ag5, ag) and torch.equal(sums5, sums4) and torch.equal(dw5, dw4)      # fixed order: bit-reproducible
 
 
 def test_stem_rejects_unsupported_sizes():

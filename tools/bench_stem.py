@@ -38,6 +38,10 @@ calls = {
     "stem_bwd_apply_wgrad": (lambda: L.mi355det_stem_bwd_apply_wgrad(vp(img), vp(wp), vp(ss), vp(sums), 0.1, vp(da), 32, vp(slab), vp(dw), vp(dg),
                                                                     vp(db), n, px, px, st), pix * (12 + 64)),
 }
+slab4, ag4 = torch.zeros((rows, 2048), device=dev), torch.zeros(2048, device=dev)
+calls["stem_bwd_fused (one pass: replaces reduce + apply_wgrad)"] = (lambda: L.mi355det_stem_bwd_fused(vp(img), vp(wp), vp(ss), 0.1, vp(da), 32, vp(slab4), vp(ag4),
+                                                                                                   vp(sums), n, px, px, st), pix * (12 + 64))
+calls["stem_bwd_finish"] = (lambda: L.mi355det_stem_bwd_finish(vp(wp), vp(ss), vp(ag4), vp(sums), pix, vp(dw), vp(dg), vp(db), st), 0)
 from object_detectors_amd import ops  # noqa: E402
 shp1 = ops.conv_shape(n, px, px, 32, 64, 3, 2)
 wf1, _ = ops.pack_weights(shp1, torch.randn(64, 32, 3, 3, device=dev) * 0.08)
