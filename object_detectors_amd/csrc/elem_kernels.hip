@@ -3,6 +3,8 @@
 // channel slice (yolohead.py:32,80-81), layout converters.  NHWC bf16, 16-byte vector accesses.
 #include "common.h"
 
+#include <cstdlib>
+
 using namespace mi355;
 
 namespace {
@@ -57,6 +59,76 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     for (int r = 1; r < 8; ++r) {
       s1 += sh[r][cl][0];
       s2 += sh[r][cl][1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * invstd;
+    ss[ch] = sc;
+    ss[c + ch] = beta[ch] - (float)mean * sc;
+    ss[2 * c + ch] = (float)mean;
+    ss[3 * c + ch] = invstd;
+    if (rmean) {
+      rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * (float)mean;
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * (float)unb;
+    }
+  }
+}
+
+// The same finalisation in ONE launch for 256 < rows <= 2048 (49 of the 72 YOLOv3 layers at batch 32 / 640 px): 16 channels x 64 row parts
+// per workgroup, every thread's loads independent (<= 32 rows each), double accumulation, fixed-order LDS fold.  The two-launch form below
+// (bn_partial_kernel + bn_finalize_kernel) costs 6 + 7 us of pure launch latency per layer in the forward chain conv -> statistics ->
+// activation, where nothing else can run; this one 4-5 us.
+__global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, double count,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                float* __restrict__ ss) {
+  __shared__ double sh[64][16][2];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  double s1 = 0, s2 = 0;
+  if (ch < c) {
+    int r = rl;
+    for (; r + 192 < rows; r += 256) {
+      const float a0 = partial[(size_t)r * 2 * c_pad + ch], b0 = partial[(size_t)r * 2 * c_pad + c_pad + ch];
+      const float a1 = partial[(size_t)(r + 64) * 2 * c_pad + ch], b1 = partial[(size_t)(r + 64) * 2 * c_pad + c_pad + ch];
+      const float a2 = partial[(size_t)(r + 128) * 2 * c_pad + ch], b2 = partial[(size_t)(r + 128) * 2 * c_pad + c_pad + ch];
+      const float a3 = partial[(size_t)(r + 192) * 2 * c_pad + ch], b3 = partial[(size_t)(r + 192) * 2 * c_pad + c_pad + ch];
+      s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; r < rows; r += 64) {
+      s1 += (double)partial[(size_t)r * 2 * c_pad + ch];
+      s2 += (double)partial[(size_t)r * 2 * c_pad + c_pad + ch];
+    }
+  }
+  sh[rl][cl][0] = s1;
+  sh[rl][cl][1] = s2;
+  __syncthreads();
+  // fold 64 -> 8 in parallel (8 threads per channel), then 8 -> 1
+  double t1 = 0, t2 = 0;
+  if (rl < 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      t1 += sh[rl * 8 + q][cl][0];
+      t2 += sh[rl * 8 + q][cl][1];
+    }
+  }
+  __syncthreads();
+  if (rl < 8) {
+    sh[rl][cl][0] = t1;
+    sh[rl][cl][1] = t2;
+  }
+  __syncthreads();
+  if (rl == 0 && ch < c) {
+    s1 = 0;
+    s2 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s1 += sh[q][cl][0];
+      s2 += sh[q][cl][1];
     }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -610,6 +682,12 @@ extern "C" {
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
+  static const bool wide_off = getenv("MI355DET_BN_FINALIZE_TWO_STAGE") != nullptr;     // A/B knob
+  if (rows > 256 && rows <= 2048 && !wide_off) {
+    hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3((c + 15) / 16), dim3(1024), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
+                       momentum, running_mean, running_var, scale_shift);
+    return check_launch("bn_finalize");
+  }
   if (rows > 256) {
     // two stages (deterministic): 64 row-chunks reduced in parallel into the 64 spare rows behind the partials.  (One launch whose
     // last workgroup per channel slab finalises was measured too: the device-scope stores / loads it needs make it 15 us against
