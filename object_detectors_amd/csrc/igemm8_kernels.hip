@@ -99,7 +99,22 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     const int lrow = lane >> 3, cpos = lane & 7;
     const int fr = lane & 15, fq = lane >> 4;
     const int fsw = (fr >> 1) & 7;
-    const int mt = tile / ntn, nt = tile - mt * ntn;
+    int mt = tile / ntn, nt = tile - mt * ntn;
+    if (ntn > 8) {
+      // very wide outputs (the 1204-class head: 43 channel tiles): the 32 workgroups an XCD runs at once would be ONE pixel tile x 32 weight
+      // tiles (33 operand tiles through its L2 per round).  Order the tiles so that 32 consecutive ones form an 8 x 4 block (12 operand
+      // tiles): channel-tile groups of 4 (the last group may be narrower), inside a group panels of 8 pixel tiles.
+      const int gmt = (p.M + kBM - 1) / kBM;
+      const int full = gmt * 4, ngrp = (ntn + 3) / 4;
+      int g = tile / full;
+      if (g > ngrp - 1) g = ngrp - 1;
+      const int t2 = tile - g * full;
+      const int w = (g == ngrp - 1 && (ntn & 3)) ? (ntn & 3) : 4;
+      const int panel = t2 / (8 * w), r = t2 - panel * 8 * w;
+      const int rr = __builtin_amdgcn_readfirstlane(r / w);
+      mt = panel * 8 + rr;
+      nt = g * 4 + (r - rr * w);
+    }
     const int m0 = mt * kBM, n0 = nt * kBN;
 
     const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);

@@ -533,7 +533,9 @@ def test_stride2_dgrad_single_launch_full_size():
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 256, 3, 1), (2, 9, 11, 128, 256, 3, 1), (1, 20, 20, 512, 1024, 3, 1), (2, 40, 40, 256, 512, 3, 1),
                                   (3, 13, 13, 512, 256, 1, 1), (1, 26, 26, 256, 512, 3, 2), (2, 1, 1, 256, 256, 3, 1), (5, 2, 1, 64, 256, 3, 1),
-                                  (1, 8, 8, 768, 256, 1, 1), (4, 20, 20, 512, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (8, 80, 80, 128, 256, 3, 1)])
+                                  (1, 8, 8, 768, 256, 1, 1), (4, 20, 20, 512, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (8, 80, 80, 128, 256, 3, 1),
+                                  # more than 8 channel tiles: the blocked tile order (8 x 4 blocks per XCD round; 10 and 11 tiles: narrow last group)
+                                  (3, 24, 28, 64, 2560, 3, 1), (1, 50, 50, 64, 2816, 1, 1)])
 def test_phase_staggered_kernel_matches_default(case):
     """Tile configuration 40 (igemm8_kernels.hip: 256x256x64, four phases per k-step, SIMD partners one barrier apart) against PyTorch fp32
     and the default configuration: forward (+ BN partial statistics), data gradient (+ residual); image edges, tile tails, one- and many-step K."""

@@ -57,7 +57,7 @@ print('totals ms: fwd %.2f dgrad %.2f wgrad %.2f' % tuple(t / 1e3 for t in tot))
 stem = collections.OrderedDict()
 for r in last:
     if 'stem_' in r['Kernel_Name'] and 'stem_l1_kernel' not in r['Kernel_Name']:
-        n = r['Kernel_Name'].split('(')[0].replace('void (anonymous namespace)::', '')
+        n = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
         stem[n] = stem.get(n, 0.0) + dur(r)
 if fused: print('  32->  64 k3 s2 @320 fwd = stem_l1_kernel: stem activation (recomputed from the image) + this convolution + its BN statistics in one launch')
 print('stem 3->32 k3 s1 @640 (recompute kernels, us): ' + ', '.join(f'{k} {v:.1f}' for k, v in stem.items()) + f'; total {sum(stem.values()) / 1e3:.2f} ms')
