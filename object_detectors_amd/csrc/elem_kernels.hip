@@ -77,29 +77,30 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-// The same finalisation in ONE launch for 256 < rows <= 2048 (49 of the 72 YOLOv3 layers at batch 32 / 640 px): 16 channels x 64 row parts
-// per workgroup, every thread's loads independent (<= 32 rows each), double accumulation, fixed-order LDS fold.  The two-launch form below
-// (bn_partial_kernel + bn_finalize_kernel) costs 6 + 7 us of pure launch latency per layer in the forward chain conv -> statistics ->
-// activation, where nothing else can run; this one 4-5 us.
+// The same finalisation in ONE launch for 256 < rows <= 8192 (54 of the 72 YOLOv3 layers at batch 32 / 640 px): 8 channels x 128 row parts
+// per workgroup, every thread's loads independent (<= 16 rows each, 4 in flight), double accumulation, fixed-order LDS fold.  The
+// two-launch form below (bn_partial_kernel + bn_finalize_kernel) costs 6 + 7 us of pure launch latency per layer in the forward chain
+// conv -> statistics -> activation, where nothing else can run.
 __global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(const float* __restrict__ partial, int rows, int c, int c_pad, double count,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
                                                                 float* __restrict__ ss) {
-  __shared__ double sh[64][16][2];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int ch = blockIdx.x * 16 + cl;
+  constexpr int CB = 8, PARTS = 1024 / CB;
+  __shared__ double sh[PARTS][CB][2];
+  const int cl = threadIdx.x & (CB - 1), rl = threadIdx.x / CB;
+  const int ch = blockIdx.x * CB + cl;
   double s1 = 0, s2 = 0;
   if (ch < c) {
     int r = rl;
-    for (; r + 192 < rows; r += 256) {
+    for (; r + 3 * PARTS < rows; r += 4 * PARTS) {
       const float a0 = partial[(size_t)r * 2 * c_pad + ch], b0 = partial[(size_t)r * 2 * c_pad + c_pad + ch];
-      const float a1 = partial[(size_t)(r + 64) * 2 * c_pad + ch], b1 = partial[(size_t)(r + 64) * 2 * c_pad + c_pad + ch];
-      const float a2 = partial[(size_t)(r + 128) * 2 * c_pad + ch], b2 = partial[(size_t)(r + 128) * 2 * c_pad + c_pad + ch];
-      const float a3 = partial[(size_t)(r + 192) * 2 * c_pad + ch], b3 = partial[(size_t)(r + 192) * 2 * c_pad + c_pad + ch];
+      const float a1 = partial[(size_t)(r + PARTS) * 2 * c_pad + ch], b1 = partial[(size_t)(r + PARTS) * 2 * c_pad + c_pad + ch];
+      const float a2 = partial[(size_t)(r + 2 * PARTS) * 2 * c_pad + ch], b2 = partial[(size_t)(r + 2 * PARTS) * 2 * c_pad + c_pad + ch];
+      const float a3 = partial[(size_t)(r + 3 * PARTS) * 2 * c_pad + ch], b3 = partial[(size_t)(r + 3 * PARTS) * 2 * c_pad + c_pad + ch];
       s1 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
       s2 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    for (; r < rows; r += 64) {
+    for (; r < rows; r += PARTS) {
       s1 += (double)partial[(size_t)r * 2 * c_pad + ch];
       s2 += (double)partial[(size_t)r * 2 * c_pad + c_pad + ch];
     }
@@ -107,13 +108,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_wide_kernel(const float* __r
   sh[rl][cl][0] = s1;
   sh[rl][cl][1] = s2;
   __syncthreads();
-  // fold 64 -> 8 in parallel (8 threads per channel), then 8 -> 1
+  // fold PARTS -> 8 in parallel (8 threads per channel), then 8 -> 1
   double t1 = 0, t2 = 0;
   if (rl < 8) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      t1 += sh[rl * 8 + q][cl][0];
-      t2 += sh[rl * 8 + q][cl][1];
+    for (int q = 0; q < PARTS / 8; ++q) {
+      t1 += sh[rl * (PARTS / 8) + q][cl][0];
+      t2 += sh[rl * (PARTS / 8) + q][cl][1];
     }
   }
   __syncthreads();
@@ -683,8 +684,8 @@ int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
   static const bool wide_off = getenv("MI355DET_BN_FINALIZE_TWO_STAGE") != nullptr;     // A/B knob
-  if (rows > 256 && rows <= 2048 && !wide_off) {
-    hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3((c + 15) / 16), dim3(1024), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
+  if (rows > 256 && rows <= 8192 && !wide_off) {
+    hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3((c + 7) / 8), dim3(1024), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale_shift);
     return check_launch("bn_finalize");
   }
