@@ -146,6 +146,12 @@ int mi355det_nms(const float* boxes, const float* scores, const int64_t* idxs, i
                  float iou_thr, int64_t* keep, int32_t* keep_count, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* The same NMS for `bs` independent box sets of `n` boxes each in ONE launch sequence (replaces the per-image loop around
+ * box_ops.batched_nms in RegionProposalNetwork.filter_proposals, tvision/rpn.py:259-280): boxes [bs,n,4], scores [bs,n], idxs [bs,n] or
+ * NULL, keep [bs,n] (the first keep_count[b] entries of row b are defined), keep_count [bs].  Workspace: mi355det_nms_workspace(bs, n). */
+int mi355det_nms_batch(const float* boxes, const float* scores, const int64_t* idxs, int32_t bs, int32_t n, float iou_thr, int64_t* keep,
+                       int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* box_iou + Matcher.__call__ (+ set_low_quality_matches_) fused, never materialising [M,N]
  * (tvision/_utils.py:271-344 after retinanet.py:409).  gt [M,4], anchors [N,4] xyxy.
  * out matches [N] int64 in {-2,-1,0..M-1}; gt_best [M] uint32 scratch. */

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "mi355det_nms_majority": (C.c_int, [vp, vp, i32, i32, f32, i32, vp, vp, vp, vp, sz, vp]),
     "mi355det_box_iou": (C.c_int, [vp, vp, vp, i64, i64, vp]),
     "mi355det_nms": (C.c_int, [vp, vp, vp, i32, f32, vp, vp, vp, sz, vp]),
+    "mi355det_nms_batch": (C.c_int, [vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, sz, vp]),
     "mi355det_match_anchors": (C.c_int, [vp, vp, i32, i64, f32, f32, C.c_int, vp, vp, vp]),
     "mi355det_box_encode": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, f32, vp]),
     "mi355det_box_decode": (C.c_int, [vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, vp]),

@@ -61,6 +61,10 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(const float* __r
   int npad = CHUNK ? RADIX_MIN_N : 64;
   while (npad < n) npad <<= 1;
   const float* P = boxes + (size_t)b * max_n * (MODE == 0 ? 6 : 4);
+  if (MODE == 1) {            // batched form (mi355det_nms_batch): image b owns rows [b*max_n, (b+1)*max_n) of scores / idxs too
+    scores += (size_t)b * max_n;
+    if (idxs) idxs += (size_t)b * max_n;
+  }
   for (int i = threadIdx.x; i < npad; i += SORT_THREADS) {
     unsigned long long k = 0;
     if (i < n) {
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(256) void nms_merge_kernel(const float* __restrict_
     } else {
       float4 v = *(const float4*)(P + (size_t)src * 4);
       if (idxs) {
-        const float o = (float)idxs[src] * off_scale;
+        const float o = (float)idxs[(size_t)b * max_n + src] * off_scale;
         v.x += o; v.y += o; v.z += o; v.w += o;
       }
       sbox[rank] = v;
@@ -581,13 +585,15 @@ __global__ __launch_bounds__(VOTE_WAVES* WAVE) void nms_vote_kernel(const float*
   }
 }
 
-__global__ void nms_keep_kernel(char* __restrict__ ws_base, NmsWs L, long long* __restrict__ keep, int* __restrict__ keep_count) {
-  char* ws = ws_base;
+__global__ void nms_keep_kernel(char* __restrict__ ws_base, NmsWs L, long long* __restrict__ keep, int* __restrict__ keep_count, int max_n) {
+  const int b = blockIdx.y;                                   // batched form: image b writes keep[b*max_n ...], keep_count[b]
+  char* ws = ws_base + (size_t)b * L.stride;
   const int kc = ((const int*)(ws + L.misc))[1];
   const int* kept = (const int*)(ws + L.kept);
   const int* sorted_idx = (const int*)(ws + L.sorted_idx);
+  keep += (size_t)b * max_n;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < kc; k += gridDim.x * blockDim.x) keep[k] = sorted_idx[kept[k]];
-  if (blockIdx.x == 0 && threadIdx.x == 0) keep_count[0] = kc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) keep_count[b] = kc;
 }
 
 // ---- torchvision box_iou ----------------------------------------------------------------------
@@ -985,8 +991,20 @@ int mi355det_nms(const float* boxes, const float* scores, const int64_t* idxs, i
   if (int e = launch_nms_common(1, boxes, scores, (const long long*)idxs, nullptr, n, 1, n, iou_thr, workspace, workspace_bytes, keep_count,
                                 S(stream), L))
     return e;
-  hipLaunchKernelGGL(nms_keep_kernel, dim3(min(64, (n + 255) / 256)), dim3(256), 0, S(stream), (char*)workspace, L, (long long*)keep, keep_count);
+  hipLaunchKernelGGL(nms_keep_kernel, dim3(min(64, (n + 255) / 256), 1), dim3(256), 0, S(stream), (char*)workspace, L, (long long*)keep, keep_count, n);
   return check_launch("nms");
+}
+
+int mi355det_nms_batch(const float* boxes, const float* scores, const int64_t* idxs, int32_t bs, int32_t n, float iou_thr, int64_t* keep,
+                       int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream) {
+  if (bs <= 0 || n <= 0) return fail(MI355DET_EINVAL, "%s: bs and n must be positive", "nms_batch");
+  if (!boxes || !scores || !keep || !keep_count) return fail(MI355DET_EINVAL, "%s: null argument", "nms_batch");
+  NmsWs L;
+  if (int e = launch_nms_common(1, boxes, scores, (const long long*)idxs, nullptr, n, bs, n, iou_thr, workspace, workspace_bytes, keep_count,
+                                S(stream), L))
+    return e;
+  hipLaunchKernelGGL(nms_keep_kernel, dim3(min(64, (n + 255) / 256), bs), dim3(256), 0, S(stream), (char*)workspace, L, (long long*)keep, keep_count, n);
+  return check_launch("nms_batch");
 }
 
 int mi355det_box_iou(const float* boxes1, const float* boxes2, float* out, int64_t m, int64_t n, void* stream) {

@@ -179,6 +179,23 @@ def nms_raw(boxes, scores, iou_threshold, idxs=None):
     return keep, cnt
 
 
+def nms_batch(boxes, scores, iou_threshold, idxs=None):
+    """`bs` independent NMS problems of the same size in one launch sequence: boxes [bs,n,4], scores [bs,n], idxs [bs,n] (categories, as
+    batched_nms) or None -> (keep [bs,n] int64 - the first counts[b] entries of row b are defined -, counts [bs] int32 on the device)."""
+    boxes, scores = _f32c(boxes), _f32c(scores)
+    bs, n = scores.shape
+    if idxs is not None:
+        idxs = idxs.to(torch.int64).contiguous()
+    keep = torch.zeros((bs, max(n, 1)), device=boxes.device, dtype=torch.int64)
+    cnt = torch.zeros(bs, device=boxes.device, dtype=torch.int32)
+    if n and bs:
+        wsb = lib().mi355det_nms_workspace(bs, n)
+        ws = torch.empty(wsb, device=boxes.device, dtype=torch.uint8)
+        check(lib().mi355det_nms_batch(ptr(boxes), ptr(scores), ptr(idxs), bs, n, float(iou_threshold), ptr(keep), ptr(cnt), ptr(ws), wsb,
+                                       stream_ptr()), "nms_batch")
+    return keep, cnt
+
+
 def nms(boxes, scores, iou_threshold, idxs=None):
     boxes, scores = _f32c(boxes), _f32c(scores)
     n = boxes.shape[0]

@@ -12,6 +12,22 @@ from . import boxes as box_ops
 from ._utils import BoxCoder
 
 
+_CLIP_LIMITS = {}
+
+
+def _clip_limits(image_shapes, device, dtype):
+    """[N, 1, 4] tensor (w, h, w, h) of the image sizes; cached per size tuple: building it from a Python list is a blocking host-to-device
+    copy in the middle of the proposal filter (0.9 ms of a 14.8 ms step waiting for the device)."""
+    key = (tuple((int(s[0]), int(s[1])) for s in image_shapes), str(device), dtype)
+    t = _CLIP_LIMITS.get(key)
+    if t is None:
+        if len(_CLIP_LIMITS) > 64:
+            _CLIP_LIMITS.clear()
+        hw = torch.tensor([[float(s[1]), float(s[0])] for s in image_shapes], device=device, dtype=dtype)
+        t = _CLIP_LIMITS[key] = hw.repeat(1, 2)[:, None, :]
+    return t
+
+
 def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level, pre_nms_top_n, post_nms_top_n,
                          nms_thresh=0.7, score_thresh=0.0, min_size=1e-3):
     """proposals [N, A, 4] decoded boxes, objectness [N, A] logits -> (list of boxes [<=post,4], list of scores)."""
@@ -34,20 +50,16 @@ def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_le
     # never suppress one, and in the kept list (descending score) the survivors come first - the result is the reference's, but nothing has
     # a data-dependent shape until the very end, and the counts of ALL images are read with one device-to-host transfer (the per-image
     # compactions cost three synchronisations per image: 3.1 ms of a 17 ms step at batch 4).
-    hw = torch.tensor([[float(s[1]), float(s[0])] for s in image_shapes], device=props.device, dtype=props.dtype)      # (w, h) per image
-    lim = hw.repeat(1, 2)[:, None, :]                                                                                   # [N, 1, 4] = w, h, w, h
+    lim = _clip_limits(image_shapes, props.device, props.dtype)                                                        # [N, 1, 4] = w, h, w, h
     boxes = torch.minimum(props.clamp(min=0), lim)
     ws, hs = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
     valid = (ws >= min_size) & (hs >= min_size) & (obj >= score_thresh)
     masked = torch.where(valid, obj, torch.full_like(obj, float("-inf")))
-    keeps, counts = [], []
-    ar = torch.arange(boxes.shape[1], device=props.device)
-    for i in range(num_images):
-        keep, cnt = ops.nms_raw(boxes[i], masked[i], nms_thresh, idxs=levels[i])
-        good = (ar < cnt) & valid[i][keep.clamp(max=boxes.shape[1] - 1)]
-        keeps.append(keep)
-        counts.append(good.sum())
-    counts = torch.stack(counts).clamp(max=post_nms_top_n).tolist()           # the one synchronisation of the proposal filter
+    # all images in ONE launch sequence (sort / mask / scan per image side by side in the grid)
+    keeps, cnt = ops.nms_batch(boxes, masked, nms_thresh, idxs=levels)
+    ar = torch.arange(boxes.shape[1], device=props.device)[None, :]
+    good = (ar < cnt[:, None]) & torch.gather(valid, 1, keeps.clamp(max=boxes.shape[1] - 1))
+    counts = good.sum(1).clamp(max=post_nms_top_n).tolist()                   # the one synchronisation of the proposal filter
     final_boxes, final_scores = [], []
     for i in range(num_images):
         k = keeps[i][:counts[i]]

@@ -171,3 +171,25 @@ def test_retinanet_cls_loss_gpu(golden):
         loss.backward()
         np.testing.assert_allclose(loss.item(), cl, rtol=1e-4)
         np.testing.assert_allclose(lt.grad.cpu().numpy(), gc, rtol=2e-3, atol=1e-7)
+
+
+def test_nms_batch_equals_per_image_nms():
+    """mi355det_nms_batch: `bs` independent NMS problems side by side in one launch sequence == mi355det_nms per image (keep order and
+    counts), with and without per-box categories; covers the bitonic (n < 4096), radix and chunked (n > 16384) sorts."""
+    from object_detectors_amd import ops
+    for n, bs, seed in ((300, 3, 1), (4750, 4, 2), (20000, 2, 3)):
+        g = torch.Generator().manual_seed(seed)
+        ctr = torch.rand((bs, n, 2), generator=g) * 400
+        wh = torch.rand((bs, n, 2), generator=g) * 60 + 2
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).cuda()
+        scores = torch.rand((bs, n), generator=g).cuda()
+        scores[0, : n // 7] = float("-inf")                                   # masked entries rank last (rpn_filter_proposals)
+        cats = torch.randint(0, 5, (bs, n), generator=g).cuda()
+        for idxs in (None, cats):
+            keep, cnt = ops.nms_batch(boxes, scores, 0.6, idxs=idxs)
+            torch.cuda.synchronize()
+            for b in range(bs):
+                k1, c1 = ops.nms_raw(boxes[b], scores[b], 0.6, idxs=None if idxs is None else idxs[b])
+                c = int(c1.item())
+                assert int(cnt[b].item()) == c
+                assert torch.equal(keep[b, :c], k1[:c])
