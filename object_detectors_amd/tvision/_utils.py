@@ -82,20 +82,34 @@ class BalancedPositiveNegativeSampler(object):
         self.positive_fraction = positive_fraction
 
     def __call__(self, matched_idxs):
+        """Same draws as the reference loop (`torch.where` + `torch.randperm(count)` per image, positives then negatives, in image order:
+        _utils.py:38-73), but with ONE device-to-host read for the whole batch instead of three per image: the positive / negative counts of
+        all images are read together, `randperm` is then called with exactly the sizes and in exactly the order of the reference, and the
+        index lists come from `nonzero_static` (ascending, like `where`), whose size is already known."""
+        pos_masks = [m >= 1 for m in matched_idxs]
+        neg_masks = [m == 0 for m in matched_idxs]
+        if not matched_idxs:
+            return [], []
+        counts = torch.stack([pm.sum() for pm in pos_masks] + [nm.sum() for nm in neg_masks]).tolist()
+        n_img = len(matched_idxs)
         pos_idx, neg_idx = [], []
-        for m in matched_idxs:
-            positive = torch.where(m >= 1)[0]
-            negative = torch.where(m == 0)[0]
-            num_pos = min(positive.numel(), int(self.batch_size_per_image * self.positive_fraction))
-            num_neg = min(negative.numel(), self.batch_size_per_image - num_pos)
-            perm1 = torch.randperm(positive.numel(), device=positive.device)[:num_pos]
-            perm2 = torch.randperm(negative.numel(), device=negative.device)[:num_neg]
+        for i, m in enumerate(matched_idxs):
+            cp, cn = int(counts[i]), int(counts[n_img + i])
+            positive = torch.nonzero_static(pos_masks[i], size=cp).squeeze(1)
+            negative = torch.nonzero_static(neg_masks[i], size=cn).squeeze(1)
+            num_pos = min(cp, int(self.batch_size_per_image * self.positive_fraction))
+            num_neg = min(cn, self.batch_size_per_image - num_pos)
+            perm1 = torch.randperm(cp, device=m.device)[:num_pos]
+            perm2 = torch.randperm(cn, device=m.device)[:num_neg]
             pm = torch.zeros_like(m, dtype=torch.uint8)
             nm = torch.zeros_like(m, dtype=torch.uint8)
             pm[positive[perm1]] = 1
             nm[negative[perm2]] = 1
             pos_idx.append(pm)
             neg_idx.append(nm)
+        self.last_counts = [(min(int(counts[i]), int(self.batch_size_per_image * self.positive_fraction)),
+                             min(int(counts[n_img + i]), self.batch_size_per_image - min(int(counts[i]), int(self.batch_size_per_image * self.positive_fraction))))
+                            for i in range(n_img)]
         return pos_idx, neg_idx
 
 

@@ -77,6 +77,10 @@ class RoIHeadTargets:
 
     def subsample(self, labels):
         pos, neg = self.fg_bg_sampler(labels)
+        sizes = getattr(self.fg_bg_sampler, "last_counts", None)
+        if sizes is not None and len(sizes) == len(pos):
+            # the sampler already knows how many it drew per image: no read-back for the index lists (roi_heads.py:654-662)
+            return [torch.nonzero_static(p | n, size=a + b).squeeze(1) for p, n, (a, b) in zip(pos, neg, sizes)]
         return [torch.nonzero(p | n).squeeze(1) for p, n in zip(pos, neg)]
 
     @staticmethod

@@ -51,8 +51,13 @@ class RPNTargets:
         labels, matched = self.assign_targets_to_anchors(anchors, targets)
         reg = self.box_coder.encode(matched, anchors)
         pos, neg = self.fg_bg_sampler(labels)
-        pos = torch.where(torch.cat(pos, dim=0))[0]
-        neg = torch.where(torch.cat(neg, dim=0))[0]
+        sizes = getattr(self.fg_bg_sampler, "last_counts", None)
+        if sizes is not None and len(sizes) == len(pos):      # the sampler knows how many it drew: index lists without a read-back
+            pos = torch.nonzero_static(torch.cat(pos, dim=0), size=sum(a for a, _ in sizes)).squeeze(1)
+            neg = torch.nonzero_static(torch.cat(neg, dim=0), size=sum(b for _, b in sizes)).squeeze(1)
+        else:
+            pos = torch.where(torch.cat(pos, dim=0))[0]
+            neg = torch.where(torch.cat(neg, dim=0))[0]
         return dict(pos=pos, sampled=torch.cat([pos, neg], dim=0), labels=torch.cat(labels, dim=0), reg=torch.cat(reg, dim=0))
 
     def losses_prepared(self, objectness, pred_bbox_deltas, prep):
