@@ -342,6 +342,14 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
  * over channel ranges into fp32 partial tiles in `workspace` and added in a fixed order (deterministic; the bf16 rounding happens once,
  * after the sum and the residual).  mi355det_conv_dgrad_workspace returns the bytes that form needs, 0 when it does not apply; with a
  * NULL / zero workspace or a shape it does not apply to, conv_dgrad_ws IS conv_dgrad. */
+/* Data gradient with the FrozenBatchNorm2d / ReLU backward of the layer that produced the convolution's input folded into the epilogue
+ * (replaces, for a bottleneck's conv1 -> conv2 -> conv3 chain and the head towers, the autograd steps of F.relu and of the frozen affine,
+ * utilities/resnet.py:107-125, tvision/backbone_utils.py:33-50, between two conv2d_input calls):
+ *   dx = bf16(conv2d_input(dy)) * scale[c] * (act > 0)   (relu != 0)   |   bf16(conv2d_input(dy)) * scale[c]   (relu == 0)
+ * act = the stored activation of that layer [n,h,w,cin] (pitch act_ld), scale [cin] or NULL.  Bit-identical to mi355det_conv_dgrad followed
+ * by mi355det_relu_affine_bwd.  Stride-1 convolutions only. */
+int mi355det_conv_dgrad_mask(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* act, int32_t act_ld,
+                             const float* scale, int32_t relu, void* stream);
 size_t mi355det_conv_dgrad_workspace(const mi355det_conv_shape* s);
 int mi355det_conv_dgrad_ws(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
                            void* workspace, size_t workspace_bytes, void* stream);

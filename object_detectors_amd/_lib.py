@@ -82,6 +82,7 @@ PROTOTYPES = {
     "mi355det_topk": (C.c_int, [vp, i32, i64, i64, i32, f32, vp, vp, vp, vp]),
     "mi355det_conv_fwd": (C.c_int, [P(ConvShape), vp, vp, vp, vp, C.c_int, vp, i32, vp]),
     "mi355det_conv_dgrad": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp]),
+    "mi355det_conv_dgrad_mask": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp, i32, vp]),
     "mi355det_conv_dgrad_workspace": (sz, [P(ConvShape)]),
     "mi355det_conv_dgrad_ws": (C.c_int, [P(ConvShape), vp, vp, vp, vp, i32, vp, sz, vp]),
     "mi355det_conv_wgrad_workspace": (sz, [P(ConvShape)]),

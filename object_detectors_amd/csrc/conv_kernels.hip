@@ -1569,6 +1569,42 @@ int mi355det_conv_dgrad(const mi355det_conv_shape* s, const void* dy, const void
   return conv_dgrad_impl(s, dy, wt, dx, residual, residual_ld, nullptr, 0, nullptr, 0.f, nullptr, stream);
 }
 
+// Data gradient + the FrozenBN / ReLU backward of the layer that PRODUCED the convolution's input, in the epilogue:
+//   dx = bf16(conv2d_input(dy)) * scale[c] * (act > 0)        (relu != 0; scale may be NULL)
+// i.e. what mi355det_conv_dgrad followed by mi355det_relu_affine_bwd(g = dx, a = act, scale) stores, without the pass over g and act
+// (6 B per element) and its launch.  Stride-1 shapes only (the stride-2 forms write parity classes / class-concatenated views).
+int mi355det_conv_dgrad_mask(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* act, int32_t act_ld,
+                             const float* scale, int32_t relu, void* stream) {
+  if (int e = check_shape(s, "conv_dgrad_mask")) return e;
+  if (int e = ensure_zero_page()) return e;
+  if (!dy || !wt || !dx || !act) return fail(MI355DET_EINVAL, "%s: null argument", "conv_dgrad_mask");
+  if (s->stride != 1) return fail(MI355DET_EINVAL, "%s: stride-1 convolutions only", "conv_dgrad_mask");
+  if (s->cout % 32 != 0) return fail(MI355DET_EINVAL, "%s: Cout (the dgrad reduction dim) must be a multiple of 32 (got %lld)", "conv_dgrad_mask", s->cout);
+  if (s->cin % 8 != 0 || act_ld % 8 != 0 || act_ld < s->cin) return fail(MI355DET_EINVAL, "%s: cin and the activation pitch must be multiples of 8", "conv_dgrad_mask");
+  const int cin_pad = (s->cin + 31) / 32 * 32;
+  IgemmParams p{};
+  int ft[9];
+  p.T = dgrad_taps(s, 0, 0, ft, p.dy, p.dx);
+  p.x = (const bf16_t*)dy;
+  p.w = (const bf16_t*)wt;
+  p.y = dx;
+  p.res = (const bf16_t*)act;
+  p.ldres = act_ld;
+  p.scale = scale;
+  p.relu = relu ? 3 : 4;
+  p.zero = g_zero_page;
+  p.MH = s->h; p.MW = s->w; p.so = 1;
+  p.M = s->n * p.MH * p.MW;
+  p.Hin = s->ho; p.Win = s->wo; p.ldin = s->out_ld; p.Cin = s->cout; p.sin = 1;
+  p.Hout = s->h; p.Wout = s->w; p.ldout = s->in_ld;
+  p.Cout = s->cin; p.CoutPad = cin_pad;
+  p.dMW = make_fastdiv((unsigned)p.MW);
+  p.dMH = make_fastdiv((unsigned)p.MH);
+  set_tap_pad(p);
+  const int e = dispatch_igemm<EPI_RES>(p, S(stream));
+  return e < 0 ? e : 0;
+}
+
 // ---- split-K data gradient: few output pixels, very deep reduction (the 1204-class RetinaNet head on the small pyramid levels:
 //      8 x 7 x 7 pixels against K = 9 x 10 880).  The plain form leaves 8-80 workgroups walking 1530 k-steps each; here the channel axis
 //      is cut into `ksplit` ranges, every (tile, range) is a workgroup writing an fp32 partial tile, and splitk_reduce_kernel adds the

@@ -33,6 +33,9 @@ struct IgemmParams {
   const float* bias;     // EPI_F32 / EPI_AFF: per-channel shift
   const float* scale;    // EPI_F32 / EPI_AFF: per-channel multiplier on the accumulator or null (FrozenBatchNorm2d folded into the conv)
   int relu;              // EPI_F32 / EPI_AFF: 1 = ReLU after (scale, shift, residual); 2 = LeakyReLU(slope) BEFORE the residual (Darknet)
+                         // EPI_RES: 3 / 4 = MASK mode: `res` is not added, it is the ACTIVATION a of the layer whose gradient is being written and
+                         //          out = bf16(acc) * scale[c] * (a > 0) (3) or bf16(acc) * scale[c] (4): the FrozenBN + ReLU backward of that layer
+                         //          (mi355det_relu_affine_bwd) folded into the data gradient that produces its input
   long long ynstride;    // EPI_F32: elements between images of y (heads write straight into the level-concatenated tensor)
   const bf16_t* z;       // EPI_BNRED: pre-BN output of the layer whose activation gradient this dgrad writes
   const float* ss;       // EPI_BNRED: that layer's [4*Cout] scale, shift, mean, invstd
@@ -260,6 +263,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
   }
   const int ch = lane % CH16, rsub = lane / CH16;
   const int co = n0 + wn * CW + ch * 8;
+  // EPI_RES mask mode: per-channel multipliers of this lane's 8 channels
+  float msc[EPI == EPI_RES ? 8 : 1];
+  const bool mask_mode = EPI == EPI_RES && p.relu >= 3;
+  if (EPI == EPI_RES) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) msc[k] = (mask_mode && p.scale && co + k < p.Cout) ? p.scale[co + k] : 1.f;
+  }
   constexpr int NPASS = 64 / RPP;
   constexpr bool kReadsSide = EPI == EPI_RES || EPI == EPI_AFF || EPI == EPI_BNRED;    // residual and / or z tiles are read back
 #pragma unroll
@@ -333,6 +343,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
           for (int q = 0; q < 4; ++q) {
             float lo = bf2f((bf16_t)(vi[q] & 0xFFFF)) + bf2f((bf16_t)(ri[q] & 0xFFFF));
             float hi = bf2f((bf16_t)(vi[q] >> 16)) + bf2f((bf16_t)(ri[q] >> 16));
+            if (EPI == EPI_RES && mask_mode) {
+              const float alo = bf2f((bf16_t)(ri[q] & 0xFFFF)), ahi = bf2f((bf16_t)(ri[q] >> 16));
+              lo = (p.relu == 4 || alo > 0.f) ? bf2f((bf16_t)(vi[q] & 0xFFFF)) * msc[EPI == EPI_RES ? 2 * q : 0] : 0.f;
+              hi = (p.relu == 4 || ahi > 0.f) ? bf2f((bf16_t)(vi[q] >> 16)) * msc[EPI == EPI_RES ? 2 * q + 1 : 0] : 0.f;
+            }
             if (relu) {
               lo = fmaxf(lo, 0.f);
               hi = fmaxf(hi, 0.f);

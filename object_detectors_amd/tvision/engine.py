@@ -581,12 +581,46 @@ class RetinaPlan:
                 return (L.mi355det_conv_dgrad_ws, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, rptr, rld, _vp(self.dgrad_ws), self.dgrad_ws.numel(), self.stream))
             return (L.mi355det_conv_dgrad, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, rptr, rld, self.stream))
 
+        # ---- FrozenBN / ReLU backward folded into the data gradient that produces its input (mi355det_conv_dgrad_mask): possible when the
+        #      activation has exactly ONE consumer, a stride-1 convolution, and its producer is a plain conv (+affine) (+ReLU) without a
+        #      residual - conv1 -> conv2 -> conv3 inside a bottleneck, the head towers, FPN laterals.  MI355DET_DGRAD_MASK=0 keeps the pass.
+        uses = {}
+        for r in self.ops:
+            for key in ("x", "res", "lat", "top"):
+                t = r.get(key)
+                if t is not None:
+                    uses[id(t)] = uses.get(id(t), 0) + 1
+        for f in self.features:                        # the heads (and, Faster R-CNN, RoIAlign) read the pyramid levels as well
+            uses[id(f)] = uses.get(id(f), 0) + (1 if getattr(self, "roi_grads", None) else 0)
+        producer = {id(r["a"]): r for r in self.ops if r["kind"] == "conv" and r.get("a") is not None}
+        fuse_ok = os.environ.get("MI355DET_DGRAD_MASK", "1") != "0"
+
+        def mask_fusable(x, shp):
+            pr = producer.get(id(x))
+            if not fuse_ok or pr is None or uses.get(id(x), 0) != 1 or shp.stride != 1 or x.parts or x.grad_written:
+                return None
+            ps = pr["spec"]
+            if ps.head or pr["res"] is not None or not (ps.relu or pr["scale"] is not None):
+                return None
+            if not (ps.trainable or pr["x"].needs_grad):
+                return None
+            if self.dgrad_ws is not None and L.mi355det_conv_dgrad_workspace(C.byref(shp)):
+                return None                            # the split-K form keeps its own epilogue
+            return pr
+
         def add_dgrad(x, shp, dy_ptr, wd):
             if not x.needs_grad:
                 return
             if x.grad is None:
                 x.grad = dense(x)
             g = x.grad
+            pr = mask_fusable(x, shp)
+            if pr is not None:
+                self.bwd.append((L.mi355det_conv_dgrad_mask, (C.byref(shp), dy_ptr, _vp(wd), g.ptr, x.ptr, x.ld, _vp(pr["scale"]), int(pr["spec"].relu),
+                                                              self.stream)))
+                x.grad_written = True
+                pr["dz_fused"] = True                  # x.grad now holds dz of the producer, not the activation gradient
+                return
             if x.grad_written:
                 self.bwd.append(dgrad_call(shp, dy_ptr, wd, g, g.ptr, g.ld))
             else:
@@ -680,7 +714,9 @@ class RetinaPlan:
                 if not (need_dz or need_gm):
                     continue
                 scale = rec["scale"]
-                if s.relu or scale is not None:
+                if rec.get("dz_fused"):
+                    dy_ptr, fresh_dz = g.ptr, None         # the consumer's data gradient already applied scale and mask: g IS dz
+                elif s.relu or scale is not None:
                     gm = dense(a) if need_gm else None
                     fresh_dz = None
                     if need_dz:

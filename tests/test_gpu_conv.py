@@ -667,3 +667,39 @@ def test_dgrad_split_k_small_maps(case, with_res):
     # a big map is not split: no workspace, and the _ws entry falls through to the plain launch
     big = ops.conv_shape(2, 64, 64, 128, 256, 3, 1)
     assert L.mi355det_conv_dgrad_workspace(C.byref(big)) == 0
+
+
+@pytest.mark.parametrize("case", [(2, 25, 25, 64, 256, 3), (1, 50, 38, 256, 64, 1), (3, 13, 13, 256, 256, 3), (2, 40, 40, 512, 512, 3), (8, 20, 20, 128, 1024, 1)])
+@pytest.mark.parametrize("relu,with_scale", [(1, True), (1, False), (0, True)])
+def test_dgrad_with_relu_affine_backward_in_the_epilogue(case, relu, with_scale):
+    """mi355det_conv_dgrad_mask (the FrozenBN / ReLU backward of the producing layer folded into the data gradient's epilogue) stores exactly
+    what mi355det_conv_dgrad followed by mi355det_relu_affine_bwd stores; every tile configuration the autotuner may pick is covered through
+    mi355det_debug_set(0, cfg) (1 = 128x128, 3 = 256x256, 15 = shared pixel tiles, 40 = phase-staggered)."""
+    import ctypes as C
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    n, h, w, cin, cout, k = case
+    wt = rnd((cout, cin, k, k), 52, (2.0 / (cin * k * k)) ** 0.5)
+    shape = ops.conv_shape(n, h, w, cin, cout, k, 1)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    gyd = nhwc(rnd((n, cout, h, w), 53))
+    act = nhwc(rnd((n, cin, h, w), 54))                                # the producing layer's stored activation (sign = ReLU mask)
+    scale = (1.0 + 0.5 * rnd((cin,), 55)).to(dev()) if with_scale else None
+    L = lib()
+    g = torch.empty((n, h, w, cin), device=dev(), dtype=torch.bfloat16)
+    ops.conv_dgrad(shape, gyd, wd, g)
+    want = ops.relu_affine_bwd(g, act, scale=scale, relu=bool(relu))
+    cfgs = [0, 1] + ([3, 40] if cin % 256 == 0 and cout % 64 == 0 else []) + ([15] if k == 3 and cout % 64 == 0 and cin % 128 == 0 else [])
+    try:
+        for cfg in cfgs:
+            L.mi355det_debug_set(0, cfg)
+            ops.conv_dgrad(shape, gyd, wd, g)                              # the same tile configuration for both sides
+            want = ops.relu_affine_bwd(g, act, scale=scale, relu=bool(relu))
+            got = torch.full((n, h, w, cin), 7.0, device=dev(), dtype=torch.bfloat16)
+            check(L.mi355det_conv_dgrad_mask(C.byref(shape), ptr(gyd), ptr(wd), ptr(got), ptr(act), cin, ptr(scale), relu, stream_ptr()), "conv_dgrad_mask")
+            torch.cuda.synchronize()
+            assert torch.equal(got.float(), want.float()), cfg              # value-equal (a masked entry is +0 here, -0 * scale there)
+    finally:
+        L.mi355det_debug_set(0, 0)
+    s2 = ops.conv_shape(n, h - h % 2, w - w % 2, cin, cout, 3, 2)
+    assert L.mi355det_conv_dgrad_mask(C.byref(s2), ptr(gyd), ptr(wd), ptr(got), ptr(act), cin, None, 1, stream_ptr()) == -1      # stride 2 refused

@@ -48,7 +48,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 plan = eng._last_plan
 L = lib()
-kinds = [(L.mi355det_conv_fwd_ex, "fwd"), (L.mi355det_conv_fwd, "fwd"), (L.mi355det_conv_dgrad, "dgrad"), (L.mi355det_conv_dgrad_ws, "dgrad"), (L.mi355det_conv_wgrad, "wgrad")]
+kinds = [(L.mi355det_conv_fwd_ex, "fwd"), (L.mi355det_conv_fwd, "fwd"), (L.mi355det_conv_dgrad, "dgrad"), (L.mi355det_conv_dgrad_ws, "dgrad"), (L.mi355det_conv_dgrad_mask, "dgrad"), (L.mi355det_conv_wgrad, "wgrad")]
 # layer family of a launch: from the conv shape (the heads' shapes are unique: cin 256, cout = 9*K or 36)
 name_of = {}
 for rec in plan.ops:
