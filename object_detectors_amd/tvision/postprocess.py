@@ -70,30 +70,44 @@ def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_le
 
 def retinanet_postprocess_detections(cls_logits_per_level, bbox_reg_per_level, anchors_per_level, image_shapes, tfidf_post=None,
                                      score_thresh=0.05, topk_candidates=1000, nms_thresh=0.5, detections_per_img=300):
-    """cls_logits_per_level: list of [N, HWA, K]; bbox_reg_per_level: list of [N, HWA, 4]; anchors_per_level: list of [HWA, 4]."""
+    """cls_logits_per_level: list of [N, HWA, K]; bbox_reg_per_level: list of [N, HWA, 4]; anchors_per_level: list of [HWA, 4].
+    retinanet.py:414-472 for the WHOLE batch with one device-to-host read: per level the thresholded top-k of every image in one call, the
+    candidates below the threshold kept as masked entries (score -inf, box 0: they rank last, never suppress anything, and do not move the
+    per-category offsets of batched_nms), all images in one NMS launch sequence.  (The per-image / per-level form read a count back 5 times
+    per image: 13.8 ms of post-processing for a 10.4 ms network at batch 16 - with no detection at all.)"""
     coder = BoxCoder((1.0, 1.0, 1.0, 1.0))
     num_images = cls_logits_per_level[0].shape[0]
-    detections = []
+    dev = cls_logits_per_level[0].device
     # sigmoid is monotone: select on the (tf-idf scaled) logits with the threshold mapped to logit space
     thr_logit = math.log(score_thresh / (1.0 - score_thresh)) if 0.0 < score_thresh < 1.0 else float("-inf")
+    batch = torch.arange(num_images, device=dev)[:, None]
+    lb, ls, ll, lv = [], [], [], []
+    for logits, reg, anchors in zip(cls_logits_per_level, bbox_reg_per_level, anchors_per_level):
+        lg = logits if tfidf_post is None else logits * tfidf_post
+        K = lg.shape[-1]
+        flat = lg.reshape(num_images, -1)
+        k = min(topk_candidates, flat.shape[1])
+        val, idx, cnt = ops.topk_rows(flat, k, min_value=thr_logit)                       # every image of the level at once
+        valid = torch.arange(k, device=dev)[None, :] < cnt[:, None]
+        a_idx, lab = idx // K, idx % K
+        bx = coder.decode_single(reg[batch, a_idx].reshape(-1, 4), anchors[a_idx].reshape(-1, 4)).reshape(num_images, k, 4)
+        lb.append(bx)
+        ls.append(torch.sigmoid(val))
+        ll.append(lab)
+        lv.append(valid)
+    b, sc, l, valid = torch.cat(lb, 1), torch.cat(ls, 1), torch.cat(ll, 1), torch.cat(lv, 1)
+    lim = _clip_limits(image_shapes, dev, b.dtype)
+    b = torch.minimum(b.clamp(min=0), lim)                                                # clip_boxes_to_image
+    b = torch.where(valid[..., None], b, torch.zeros_like(b))
+    masked = torch.where(valid, sc, torch.full_like(sc, float("-inf")))
+    keeps, cnt = ops.nms_batch(b, masked, nms_thresh, idxs=l)
+    n_all = b.shape[1]
+    good = (torch.arange(n_all, device=dev)[None, :] < cnt[:, None]) & torch.gather(valid, 1, keeps.clamp(max=n_all - 1))
+    counts = good.sum(1).clamp(max=detections_per_img).tolist()                           # the one synchronisation
+    detections = []
     for i in range(num_images):
-        ib, isc, il = [], [], []
-        for logits, reg, anchors in zip(cls_logits_per_level, bbox_reg_per_level, anchors_per_level):
-            lg = logits[i] if tfidf_post is None else logits[i] * tfidf_post
-            K = lg.shape[-1]
-            flat = lg.reshape(1, -1)
-            k = min(topk_candidates, flat.shape[1])
-            val, idx, cnt = ops.topk_rows(flat, k, min_value=thr_logit)
-            c = int(cnt.item())
-            idx, val = idx[0, :c], val[0, :c]
-            a_idx, lab = idx // K, idx % K
-            bx = coder.decode_single(reg[i][a_idx], anchors[a_idx])
-            ib.append(box_ops.clip_boxes_to_image(bx, image_shapes[i]))
-            isc.append(torch.sigmoid(val))
-            il.append(lab)
-        b, s, l = torch.cat(ib), torch.cat(isc), torch.cat(il)
-        keep = box_ops.batched_nms(b, s, l, nms_thresh)[:detections_per_img]
-        detections.append({"boxes": b[keep], "scores": s[keep], "labels": l[keep]})
+        kp = keeps[i][:counts[i]]
+        detections.append({"boxes": b[i][kp], "scores": sc[i][kp], "labels": l[i][kp]})
     return detections
 
 
