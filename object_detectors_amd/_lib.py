@@ -118,6 +118,7 @@ PROTOTYPES = {
     "mi355det_retina_loss_lv": (C.c_int, [vp] * 8 + [i32, i64, i32, C.c_float, C.c_float, C.c_float, vp, vp, P(LevelGrads), vp, vp]),
     "mi355det_im2col_nchw": (C.c_int, [vp, vp, vp, vp] + [i32] * 8 + [vp]),
     "mi355det_maxpool3x3s2": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "mi355det_resnet_stem_fwd": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
     "mi355det_maxpool3x3s2_bwd": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mi355det_relu_affine_bwd": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, C.c_int, vp, i32, vp, i32, vp]),
     "mi355det_upsample_nearest_add": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp]),

@@ -32,6 +32,7 @@ SOURCES = [
     ("elem_kernels.hip", []),
     ("stem_kernels.hip", ["-fno-slp-vectorize"]),
     ("stem_l1_kernels.hip", ["-fno-slp-vectorize"]),     # packed fp32 adds cost more moves than they save (and 36 VGPRs)
+    ("rstem_kernels.hip", ["-fno-slp-vectorize"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-x", "hip"]
 

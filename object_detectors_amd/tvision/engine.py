@@ -445,11 +445,21 @@ class RetinaPlan:
 
         # ---- stem: normalise + im2col (7x7/2) -> GEMM + FrozenBN + ReLU -> max-pool     (resnet.py:232-235)
         h2, w2 = down(H, 1), down(W, 1)
-        self.col = new_act(n, h2, w2, STEM_K, False)
+        s1 = eng.by_name["backbone.body.conv1"]
         self.img_call = len(self.fwd)
-        self.fwd.append((L.mi355det_im2col_nchw, [None, _vp(eng.mean) if eng.normalize else None, _vp(eng.inv_std) if eng.normalize else None,
-                                                  self.col.ptr, n, 3, H, W, 7, 2, 3, STEM_K, self.stream]))
-        c1 = conv("backbone.body.conv1", self.col)
+        if not s1.trainable and H % 32 == 0 and W % 32 == 0 and os.environ.get("MI355DET_RSTEM", "1") != "0":
+            # frozen stem (the reference default, backbone_utils.py:89-104): one direct 7x7/2 convolution kernel, no im2col matrix
+            wf1, _ = eng.packed["backbone.body.conv1"]
+            aff1 = eng.affine[s1.bn]
+            c1 = new_act(n, h2, w2, 64, False)
+            self.fwd.append((L.mi355det_resnet_stem_fwd, [None, _vp(eng.mean) if eng.normalize else None, _vp(eng.inv_std) if eng.normalize else None,
+                                                          _vp(wf1), _vp(aff1[0]), _vp(aff1[1]), int(s1.relu), c1.ptr, c1.ld, n, H, W, self.stream]))
+            self.ops.append(dict(kind="rstem", a=c1))
+        else:
+            self.col = new_act(n, h2, w2, STEM_K, False)
+            self.fwd.append((L.mi355det_im2col_nchw, [None, _vp(eng.mean) if eng.normalize else None, _vp(eng.inv_std) if eng.normalize else None,
+                                                      self.col.ptr, n, 3, H, W, 7, 2, 3, STEM_K, self.stream]))
+            c1 = conv("backbone.body.conv1", self.col)
         x = new_act(n, down(h2, 1), down(w2, 1), 64, c1.needs_grad)       # only a trained stem needs the gradient through the max-pool
         self.fwd.append((L.mi355det_maxpool3x3s2, (c1.ptr, c1.ld, n, c1.h, c1.w, 64, x.ptr, x.ld, self.stream)))
         self.ops.append(dict(kind="maxpool", x=c1, a=x))
@@ -657,6 +667,8 @@ class RetinaPlan:
             f.parts.append(rg)                 # Faster R-CNN: gradient of P2..P5 coming back through RoIAlign
         for rec in reversed(self.ops):
             kind = rec["kind"]
+            if kind == "rstem":                # frozen stem: nothing flows back through it
+                continue
             if kind == "pool":
                 g = finalize(rec["a"])
                 if g is None:

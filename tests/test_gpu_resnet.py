@@ -246,3 +246,33 @@ def test_retina_loss_level_gradients_equal_the_cast_of_the_fp32_gradient(golden,
         row0 += p * A
     with pytest.raises(ValueError):
         ops.retina_loss(logits, reg, T(anchors), matched, gt_boxes, gt_labels, offs, cls_levels=levels[:2], anchors_per_pixel=A)   # rows do not add up
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 32, 32), (3, 128, 64)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_resnet_stem_direct_convolution(shape, normalize):
+    """mi355det_resnet_stem_fwd (7x7 / 2 / pad 3, 3 -> 64, FrozenBN affine, ReLU in one kernel, no im2col matrix) against PyTorch fp32 on
+    the same bf16-rounded operands, with the ImageNet normalisation folded in (padding is zero AFTER normalisation, transform.py:120-124,
+    224-240) or not; image borders on all four sides; sizes that are not multiples of 32 are refused."""
+    import ctypes as C
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    n, h, w = shape
+    g = torch.Generator().manual_seed(5 + h)
+    img = torch.rand((n, 3, h, w), generator=g)
+    wt = (torch.randn((64, 3, 7, 7), generator=g) * (2.0 / 147) ** 0.5).bfloat16().float()
+    scale, shift = 1.0 + 0.3 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    x = ((img - mean[None, :, None, None]) / std[None, :, None, None]) if normalize else img
+    x = x.bfloat16().float()                                              # the kernel stages the (normalised) image as bf16
+    want = torch.relu(F.conv2d(x, wt, stride=2, padding=3) * scale[None, :, None, None] + shift[None, :, None, None])
+    wp = torch.zeros((64, 160), dtype=torch.bfloat16, device="cuda")
+    wp[:, :147] = wt.permute(0, 2, 3, 1).reshape(64, 147).cuda().bfloat16()            # k = (kh*7+kw)*3 + c
+    out = torch.full((n, h // 2, w // 2, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    L = lib()
+    md, isd = (mean.cuda(), (1.0 / std).cuda()) if normalize else (None, None)
+    imgd, scd, shd = img.cuda(), scale.cuda(), shift.cuda()                # keep the device tensors alive across the launch
+    check(L.mi355det_resnet_stem_fwd(ptr(imgd), ptr(md), ptr(isd), ptr(wp), ptr(scd), ptr(shd), 1, ptr(out), 64, n, h, w, stream_ptr()), "resnet_stem_fwd")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert float((got - want).abs().max()) <= 1.5e-2 * float(want.abs().max())
+    assert L.mi355det_resnet_stem_fwd(ptr(imgd), None, None, ptr(wp), None, None, 1, ptr(out), 64, n, h + 8, w, stream_ptr()) == -1
