@@ -450,7 +450,8 @@ int mi355det_upsample2x_bwd(const void* g, int32_t g_ld, int32_t n, int32_t h, i
  * the normalisation of tvision/transform.py:120-124 when mean / inv_std are given): replaces mi355det_im2col_nchw + the 160-deep GEMM of
  * mi355det_conv_fwd_ex for the frozen stem (no im2col matrix: 819 MB written and re-read at batch 16 / 800 px).  img [n,3,h,w] fp32,
  * w = the forward pack [64][160] bf16 (k = (kh*7+kw)*3 + c), scale / shift [64] or NULL, out [n, h/2, w/2, 64] bf16 (pitch out_ld).
- * h and w multiples of 32 (what GeneralizedRCNNTransform.batch_images pads to). */
+ * h and w multiples of 32 (what GeneralizedRCNNTransform.batch_images pads to).  relu: bit 0 = ReLU; bits 1-3 are timing ablations of
+ * tools/bench_rstem.py (skip the fragment compute / the halo fetch / the halo LDS store: wrong results) and must be 0 otherwise. */
 int mi355det_resnet_stem_fwd(const float* img, const float* mean, const float* inv_std, const void* w, const float* scale,
                              const float* shift, int32_t relu, void* out, int32_t out_ld, int32_t n, int32_t h, int32_t wd,
                              void* stream);

@@ -27,11 +27,12 @@ constexpr int HC = STRIDE * (TW - 1) + KS;               // 37 halo columns
 constexpr int P = 38;                                    // LDS row pitch (bf16 elements)
 constexpr int IMG_ELEMS = 3 * HR * P;                    // 4218
 constexpr int ZBASE = (IMG_ELEMS * 2 + 15) / 16 * 16;    // zero slot: the padded k columns 147..159 read it at every fragment-row offset
-constexpr int ZSLOT = (STRIDE * 3 * P * 2 + 2 + 15) / 16 * 16;            // fragment rows 0..3 of a wave add up to STRIDE*3*P elements
+constexpr int ZSLOT = ((STRIDE * 15 * P + STRIDE * 15) * 2 + 2 + 15) / 16 * 16;      // the padded k columns read ZBASE + the pixel's own offset (rows 0..15, columns 0..15)
 constexpr int DUMP = ZBASE + ZSLOT;                      // where the surplus lanes of the halo fetch put their value
 constexpr int IMG_BYTES = DUMP + 16;
 constexpr int HALO = 3 * HR * HC;                        // 4107 values per tile
 constexpr int PER_T = (HALO + 255) / 256;                // 17 per thread
+constexpr int WP = 168;                                  // LDS row pitch of the weights (bf16 elements)
 
 struct RStemParams {
   const float* img;       // [n,3,H,W] fp32
@@ -52,83 +53,97 @@ __global__ __launch_bounds__(256, 2) void rstem_kernel(const RStemParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
+  // the fields the loop needs, as plain scalars (nothing below takes the argument struct by address)
+  const float* const img = p.img;
+  bf16_t* const outp = p.out;
+  const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo, ld = p.ld, relu = p.relu, tiles_x = p.tiles_x, tiles_y = p.tiles_y, ntiles = p.ntiles;
 
-  // ---- weight fragments (A operand): row fr of fragment i = channel (fr/4)*16 + i*4 + fr%4, k chunk q*32 + fq*8
-  bf16x8_t wf[4][NQ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ch = (fr >> 2) * 16 + i * 4 + (fr & 3);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) wf[i][q] = *(const bf16x8_t*)(p.w + ch * KPAD + q * 32 + fq * 8);
+  // ---- weights in LDS ([64][WP] bf16, row pitch 336 B: the 16 rows a fragment read touches fall on distinct banks); as 20 register-resident
+  //      A fragments per lane they left no room for the halo prefetch (the kernel spilled).  A operand: row fr of fragment i = channel
+  //      (fr/4)*16 + i*4 + fr%4, k chunk q*32 + fq*8
+  bf16_t* const wl = (bf16_t*)(smem + 2 * IMG_BYTES + 128 * 4 + KPAD * 4);
+  for (int i = tid; i < 64 * (KPAD / 8); i += 256) {
+    const int ch = i / (KPAD / 8), kc = i - ch * (KPAD / 8);
+    *(uint4*)(wl + ch * WP + kc * 8) = *(const uint4*)(p.w + ch * KPAD + kc * 8);
   }
-  // ---- im2col fragment (B operand): this lane's 8 k values of step q = 8 LDS byte offsets relative to the pixel's halo position
-  int kaddr[NQ][8];
+  int wrow[4];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = q * 32 + fq * 8 + e;
-      const int t = k / 3, c = k - t * 3, kh = t / KS, kw = t - kh * KS;
-      kaddr[q][e] = k < KVALID ? ((c * HR + kh) * P + kw) * 2 : -1;
-    }
+  for (int i = 0; i < 4; ++i) wrow[i] = (((fr >> 2) * 16 + i * 4 + (fr & 3)) * WP + fq * 8) * 2;
+  // ---- im2col fragment (B operand): byte offset of k column k relative to the pixel's halo position, as a 160-entry LDS table (40 per-lane
+  //      registers otherwise: the kernel spilled); the padded columns point at the zero slot
+  int* const ktab = (int*)(smem + 2 * IMG_BYTES + 128 * 4);
+  if (tid < KPAD) {
+    const int k = tid;
+    const int t = k / 3, c = k - t * 3, kh = t / KS, kw = t - kh * KS;
+    ktab[k] = k < KVALID ? ((c * HR + kh) * P + kw) * 2 : ZBASE;
+  }
   // pixel of fragment f (tile row 4*wid + f, column fr): halo byte offset
   const int pix_base = (STRIDE * (4 * wid) * P + STRIDE * fr) * 2;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) kaddr[q][e] = kaddr[q][e] >= 0 ? pix_base + kaddr[q][e] : ZBASE;
-
-  // ---- epilogue constants of this lane's 16 channels
-  float sc[16], sh[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    sc[k] = p.scale ? p.scale[fq * 16 + k] : 1.f;
-    sh[k] = p.shift ? p.shift[fq * 16 + k] : 0.f;
+  // ---- epilogue constants: scale | shift of the 64 channels behind the two image buffers (read back 16 + 16 per fragment: keeping them in
+  //      registers spilled)
+  float* const aff = (float*)(smem + 2 * IMG_BYTES);
+  if (tid < 64) {
+    aff[tid] = p.scale ? p.scale[tid] : 1.f;
+    aff[64 + tid] = p.shift ? p.shift[tid] : 0.f;
   }
 
-  // ---- halo fetch roles (as stem_kernels.hip): element e of the [3][HR][HC] halo, packed (channel << 24 | row << 12 | column); validity is
-  //      computed per tile from its origin (the image border cuts up to PAD rows / columns of halo)
-  int h_rc[PER_T];
-#pragma unroll
-  for (int i = 0; i < PER_T; ++i) {
+  // ---- halo fetch roles: element e = tid + i*256 of the [3][HR][HC] halo; (channel, row, column) are recomputed from e where they are needed
+  //      (constant divisors: a few multiplies) - as a 17-entry per-thread array they lived in scratch, and every scratch access waits on
+  //      the same counter as the halo loads in flight (the prefetch then stalled the compute: 610 us instead of ~200)
+  auto halo_elem = [&](int i, int& c, int& r, int& x) __attribute__((always_inline)) {
     const int e = tid + i * 256;
-    const int cr = e / HC, x = e - cr * HC, c = cr / HR, r = cr - c * HR;
-    h_rc[i] = e < HALO ? (c << 24) | (r << 12) | x : -1;
-  }
+    const int cr = e / HC;
+    x = e - cr * HC;
+    c = cr / HR;
+    r = cr - c * HR;
+    return e < HALO;
+  };
   const float m0 = p.mean ? p.mean[0] : 0.f, m1 = p.mean ? p.mean[1] : 0.f, m2 = p.mean ? p.mean[2] : 0.f;
   const float i0 = p.istd ? p.istd[0] : 1.f, i1 = p.istd ? p.istd[1] : 1.f, i2 = p.istd ? p.istd[2] : 1.f;
-  // base one PAD row / column in front of the image: scalar offset = tile origin (never negative)
-  const __amdgpu_buffer_rsrc_t rs_img = __builtin_amdgcn_make_buffer_rsrc((void*)(p.img - (PAD * p.W + PAD)), 0, 0x7FFFFFF0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7FFFFFF0, 0x00020000);
-  auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
-    const int tx = tile % p.tiles_x, t2 = tile / p.tiles_x;
-    const int ty = t2 % p.tiles_y;
-    b = t2 / p.tiles_y;
+  // Plain global loads / stores here, no buffer descriptors: in this kernel (249 VGPRs, long unrolled prologue) the compiler kept the
+  // descriptors in VECTOR registers and turned every buffer access into a readfirstlane "waterfall" loop (636 us instead of ~200).
+  // Image base one PAD row / column in front of the image: scalar offset = tile origin (never negative).
+  auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) __attribute__((always_inline)) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y;
+    b = t2 / tiles_y;
     oy0 = ty * TH;
     ox0 = tx * TW;
   };
+  // fetch = 17 UNCONDITIONAL loads (clamped address) + a validity mask; normalisation, zero padding and the LDS store happen after the
+  // tile's compute (store_halo).  Written as `ok ? (load - mean)*istd : 0` in one place the compiler made every load a branch of its own
+  // with a full wait behind it: 17 serialised round trips per tile (134 of 299 us).
   float hv[PER_T];
-  auto fetch_halo = [&](int tile) {
+  unsigned hok = 0;
+  auto fetch_halo = [&](int tile) __attribute__((always_inline)) {
     int b, oy0, ox0;
     tile_origin(tile, b, oy0, ox0);
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;       // image coordinates of halo element (0, 0)
-    const int soff = ((b * 3 * p.H + oy0 * STRIDE) * p.W + ox0 * STRIDE) * 4;
+    const float* base = img + (long long)b * 3 * H * W;
+    hok = 0;
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-      const int c = h_rc[i] >> 24, r = (h_rc[i] >> 12) & 0xFFF, x = h_rc[i] & 0xFFF;
-      const bool ok = h_rc[i] >= 0 && (unsigned)(iy0 + r) < (unsigned)p.H && (unsigned)(ix0 + x) < (unsigned)p.W;
-      const int rel = ((c * p.H + r) * p.W + x) * 4;
-      const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, ok ? rel : (int)0x80000000, soff, 0));
-      const float mu = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? i0 : (c == 1 ? i1 : i2);
-      hv[i] = ok ? (v - mu) * is : 0.f;                  // padding is zero AFTER normalisation (transform.py pads the normalised image)
+      int c, r, x;
+      const bool in = halo_elem(i, c, r, x);
+      const int iy = iy0 + r, ix = ix0 + x;
+      const bool ok = in && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      int idx = ok ? (c * H + iy) * W + ix : 0;
+      asm volatile("" : "+v"(idx));                        // opaque: the load below stays unconditional
+      hv[i] = base[idx];
+      hok |= ok ? (1u << i) : 0u;
     }
   };
-  auto store_halo = [&](int buf) {
+  auto store_halo = [&](int buf) __attribute__((always_inline)) {
     bf16_t* s = (bf16_t*)(smem + buf * IMG_BYTES);
 #pragma unroll
     for (int i = 0; i < PER_T; ++i) {
-      const int c = h_rc[i] >> 24, r = (h_rc[i] >> 12) & 0xFFF, x = h_rc[i] & 0xFFF;
-      s[h_rc[i] >= 0 ? (c * HR + r) * P + x : DUMP / 2] = f2bf(hv[i]);
+      int c, r, x;
+      const bool in = halo_elem(i, c, r, x);
+      // mean / 1/std of channel c without a lookup table (the compiler turns a select chain into one, in scratch)
+      const float f1 = c >= 1 ? 1.f : 0.f, f2 = c >= 2 ? 1.f : 0.f;
+      const float mu = m0 + f1 * (m1 - m0) + f2 * (m2 - m1), is = i0 + f1 * (i1 - i0) + f2 * (i2 - i1);
+      const float v = ((hok >> i) & 1u) ? (hv[i] - mu) * is : 0.f;     // padding is zero AFTER normalisation (transform.py pads the normalised image)
+      s[in ? (c * HR + r) * P + x : DUMP / 2] = f2bf(v);
     }
   };
   // zero slots behind both image buffers
@@ -137,61 +152,88 @@ __global__ __launch_bounds__(256, 2) void rstem_kernel(const RStemParams p) {
     *(unsigned*)(smem + b * IMG_BYTES + ZBASE + o * 4) = 0u;
   }
 
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   const int G = gridDim.x;
   int tile = blockIdx.x;
-  if (tile < p.ntiles) {
+  if (tile < ntiles) {
     fetch_halo(tile);
     store_halo(0);
   }
   __syncthreads();
   int buf = 0;
 #pragma nounroll
-  for (; tile < p.ntiles; tile += G) {
+  for (; tile < ntiles; tile += G) {
     const int nxt = tile + G;
-    const bool has_next = nxt < p.ntiles;
-    if (has_next) fetch_halo(nxt);                       // lands while this tile is computed
+    const bool has_next = nxt < ntiles;
+    if (has_next && !(relu & 4)) fetch_halo(nxt);                       // lands while this tile is computed
     const char* simg = smem + buf * IMG_BYTES;
     int b, oy0, ox0;
     tile_origin(tile, b, oy0, ox0);
 #pragma unroll 1
-    for (int f = 0; f < 4; ++f) {
-      const int foff = (STRIDE * f * P) * 2;
-      f32x4_t acc[4];
+    for (int f2 = 0; f2 < ((relu & 2) ? 0 : 2); ++f2) {
+      // two fragments (tile rows 4*wid + 2*f2 and + 1) per weight read
+      f32x4_t acc[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[u][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const char* spix = simg + pix_base + (STRIDE * (2 * f2) * P) * 2;
+      int wofs = 0;
+      asm volatile("" : "+v"(wofs));          // opaque zero: keeps the weight reads inside the loop (hoisted, they are 80 live registers again)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        unsigned short v[8];
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        const i32x4_t t0 = *(const i32x4_t*)(ktab + q * 32 + fq * 8), t1 = *(const i32x4_t*)(ktab + q * 32 + fq * 8 + 4);
+        const int ko[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        bf16x8_t xf[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *(const unsigned short*)(simg + kaddr[q][e] + foff);
-        uint4 u;
-        u.x = v[0] | ((unsigned)v[1] << 16);
-        u.y = v[2] | ((unsigned)v[3] << 16);
-        u.z = v[4] | ((unsigned)v[5] << 16);
-        u.w = v[6] | ((unsigned)v[7] << 16);
-        const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, u);
+        for (int u = 0; u < 2; ++u) {
+          unsigned short v[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][q], xf, acc[i], 0, 0, 0);
+          for (int e = 0; e < 8; ++e) v[e] = *(const unsigned short*)(spix + u * (STRIDE * P * 2) + ko[e]);
+          uint4 uu;
+          uu.x = v[0] | ((unsigned)v[1] << 16);
+          uu.y = v[2] | ((unsigned)v[3] << 16);
+          uu.z = v[4] | ((unsigned)v[5] << 16);
+          uu.w = v[6] | ((unsigned)v[7] << 16);
+          xf[u] = __builtin_bit_cast(bf16x8_t, uu);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8_t wfr = *(const bf16x8_t*)((const char*)wl + wrow[i] + wofs + q * 64);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr, xf[u], acc[u][i], 0, 0, 0);
+        }
       }
-      // lane = pixel (row 4*wid + f, column fr), channels fq*16 + i*4 + r
-      unsigned short o[16];
+      // lane = pixel (row 4*wid + 2*f2 + u, column fr), channels fq*16 + i*4 + r
+      float sc[16], sh[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        float y = acc[k >> 2][k & 3] * sc[k] + sh[k];
-        if (p.relu) y = fmaxf(y, 0.f);
-        o[k] = f2bf(y);
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const f32x4_t a = *(const f32x4_t*)(aff + fq * 16 + k4 * 4), c = *(const f32x4_t*)(aff + 64 + fq * 16 + k4 * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[k4 * 4 + r] = a[r];
+          sh[k4 * 4 + r] = c[r];
+        }
       }
-      const int oy = oy0 + 4 * wid + f, ox = ox0 + fr;
-      const int off = (((b * p.Ho + oy) * p.Wo + ox) * p.ld + fq * 16) * 2;
-      uint4 w0, w1;
-      w0.x = o[0] | ((unsigned)o[1] << 16); w0.y = o[2] | ((unsigned)o[3] << 16); w0.z = o[4] | ((unsigned)o[5] << 16); w0.w = o[6] | ((unsigned)o[7] << 16);
-      w1.x = o[8] | ((unsigned)o[9] << 16); w1.y = o[10] | ((unsigned)o[11] << 16); w1.z = o[12] | ((unsigned)o[13] << 16); w1.w = o[14] | ((unsigned)o[15] << 16);
-      // vector offset only (no SGPR soffset): see the store hazard note in stem_kernels.hip
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w0), rs_out, off, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, w1), rs_out, off + 16, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        unsigned short o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          float y = acc[u][k >> 2][k & 3] * sc[k] + sh[k];
+          if (relu & 1) y = fmaxf(y, 0.f);
+          o[k] = f2bf(y);
+        }
+        const int oy = oy0 + 4 * wid + 2 * f2 + u, ox = ox0 + fr;
+        uint4 w0, w1;
+        w0.x = o[0] | ((unsigned)o[1] << 16); w0.y = o[2] | ((unsigned)o[3] << 16); w0.z = o[4] | ((unsigned)o[5] << 16); w0.w = o[6] | ((unsigned)o[7] << 16);
+        w1.x = o[8] | ((unsigned)o[9] << 16); w1.y = o[10] | ((unsigned)o[11] << 16); w1.z = o[12] | ((unsigned)o[13] << 16); w1.w = o[14] | ((unsigned)o[15] << 16);
+        bf16_t* dst = outp + (long long)(((b * Ho + oy) * Wo + ox) * ld + fq * 16);
+        *(uint4*)dst = w0;
+        *(uint4*)(dst + 8) = w1;
+      }
     }
-    if (has_next) store_halo(buf ^ 1);
+    if (has_next && !(relu & 8)) store_halo(buf ^ 1);
     lds_barrier();
     buf ^= 1;
   }
@@ -225,7 +267,7 @@ int mi355det_resnet_stem_fwd(const float* img, const float* mean, const float* i
   p.n = n; p.H = h; p.W = wd; p.Ho = h / 2; p.Wo = wd / 2;
   p.tiles_x = p.Wo / TW; p.tiles_y = p.Ho / TH;
   p.ntiles = n * p.tiles_x * p.tiles_y;
-  constexpr int lds = 2 * IMG_BYTES;
+  constexpr int lds = 2 * IMG_BYTES + 128 * 4 + KPAD * 4 + 64 * WP * 2;
   const int g = rstem_cus() * 2;
   hipLaunchKernelGGL(rstem_kernel, dim3(p.ntiles < g ? p.ntiles : g), dim3(256), lds, S(stream), p);
   return check_launch("resnet_stem_fwd");
