@@ -507,19 +507,28 @@ __global__ __launch_bounds__(256) void colsum8p_kernel(const bf16_t* __restrict_
     }
   }
 }
+// 32 channels x 8 row parts per workgroup, fixed-order LDS fold (one thread per channel walking 512 rows alone took up to 220 us)
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, int rows, int c8, int c, float* __restrict__ out) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 3 < rows; r += 4) {
-    s0 += partial[(size_t)r * c8 + ch];
-    s1 += partial[(size_t)(r + 1) * c8 + ch];
-    s2 += partial[(size_t)(r + 2) * c8 + ch];
-    s3 += partial[(size_t)(r + 3) * c8 + ch];
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (ch < c) {
+    int r = part;
+    for (; r + 8 < rows; r += 16) {
+      s0 += partial[(size_t)r * c8 + ch];
+      s1 += partial[(size_t)(r + 8) * c8 + ch];
+    }
+    if (r < rows) s0 += partial[(size_t)r * c8 + ch];
   }
-  for (; r < rows; ++r) s0 += partial[(size_t)r * c8 + ch];
-  out[ch] += (s0 + s1) + (s2 + s3);
+  red[part][cl] = s0 + s1;
+  __syncthreads();
+  if (part == 0 && ch < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][cl];
+    out[ch] += t;
+  }
 }
 
 // vector form: 16-byte loads (8 channels per lane), rows spread over the lanes that do not fit a channel group
@@ -747,7 +756,7 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
     if (vec && gp > 1 && workspace && workspace_bytes >= (size_t)gp * groups * 8 * sizeof(float)) {
       // two stages, fixed order (the slabs at the head of the workspace are dead: their reduce ran on this stream above)
       hipLaunchKernelGGL(colsum8p_kernel, dim3(gp, (groups + 255) / 256), dim3(256), 0, S(stream), (const bf16_t*)dy, s->out_ld, s->cout, (long long)p.M, (float*)workspace);
-      hipLaunchKernelGGL(colsum_fold_kernel, dim3((s->cout + 255) / 256), dim3(256), 0, S(stream), (const float*)workspace, gp, groups * 8, s->cout, dbias);
+      hipLaunchKernelGGL(colsum_fold_kernel, dim3((s->cout + 31) / 32), dim3(256), 0, S(stream), (const float*)workspace, gp, groups * 8, s->cout, dbias);
     } else if (vec && groups <= 256) {
       // few workgroups: every one ends with c same-address atomics (1024 of them cost more than the reads)
       const int gx = (int)max(1ll, min((long long)128, ((long long)p.M + (long long)npl * 16 - 1) / ((long long)npl * 16)));
