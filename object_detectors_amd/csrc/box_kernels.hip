@@ -789,7 +789,8 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
   const long long nvec = vec ? total / 4 : total;
   for (long long q = blockIdx.x * (long long)NT + threadIdx.x; q < nvec; q += (long long)gridDim.x * NT) {
     const long long i0 = vec ? q * 4 : q;
-    if (TGT_MODE == 1 && lv.nlev > 0 && lv.fast && vec && !grad) {
+    if (TGT_MODE == 1 && lv.nlev > 0 && lv.fast && vec && !grad &&
+        (lv.fast == 1 || (unsigned)i0 - fdivu((unsigned)i0, lv.dk) * (unsigned)k + 3u < (unsigned)k)) {      // fast == 2: only groups inside one row
       // ---- training fast path (mi355det_retina_loss_lv): one row per group, 32-bit index arithmetic with multiply-shift divisions,
       //      the t = 0 form of the loss for groups that do not contain the row's label (all but one group in 301 at K = 1204).
       //      The general path below spends ~100 instructions per element on 64-bit divisions and per-element bookkeeping.
@@ -840,10 +841,15 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
           g4[e] = g * (sc * gscale * wimg);
         }
       }
-      uint2 o;
-      o.x = f2bf(g4[0]) | ((unsigned)f2bf(g4[1]) << 16);
-      o.y = f2bf(g4[2]) | ((unsigned)f2bf(g4[3]) << 16);
-      *(uint2*)dst = o;
+      if (lv.fast == 1 || (((unsigned long long)dst) & 7ull) == 0) {
+        uint2 o;
+        o.x = f2bf(g4[0]) | ((unsigned)f2bf(g4[1]) << 16);
+        o.y = f2bf(g4[2]) | ((unsigned)f2bf(g4[3]) << 16);
+        *(uint2*)dst = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = f2bf(g4[e]);
+      }
       continue;
     }
     long long r = total < (1ll << 31) ? (long long)((unsigned)i0 / (unsigned)k) : i0 / k;
@@ -1221,9 +1227,11 @@ int mi355det_retina_loss_lv(const float* cls_logits, const float* bbox_regressio
   if (at != rows_per_image) return fail(MI355DET_EINVAL, "%s: the levels hold %lld rows per image, the logits %lld", "retina_loss_lv", at, (long long)rows_per_image);
   {
     const long long rows_all = (long long)n_images * rows_per_image;
-    lv.fast = (rows_all * k < (1ll << 31) && k % 4 == 0 && lv.A * k % 4 == 0) ? 1 : 0;
+    // 1: every group of four lies in one row and is 8-byte aligned in the level buffers; 2: any k (groups that straddle a row take the general
+    // path, unaligned groups store element by element)
+    lv.fast = rows_all * k < (1ll << 31) ? ((k % 4 == 0 && lv.A * k % 4 == 0) ? 1 : 2) : 0;
     for (int q = 0; q < lv.nlev; ++q)
-      if (lv.ld[q] % 4 != 0 || (((uintptr_t)lv.dst[q]) & 7) != 0) lv.fast = 0;       // 8-byte stores of four bf16 gradients
+      if (lv.fast == 1 && (lv.ld[q] % 4 != 0 || (((uintptr_t)lv.dst[q]) & 7) != 0)) lv.fast = 2;
     lv.dk = focal_div((unsigned)k);
     lv.drpi = focal_div((unsigned)rows_per_image);
     lv.da = focal_div((unsigned)lv.A);
