@@ -310,6 +310,11 @@ int mi355det_stem_im2col(const float* img, void* out, int32_t n, int32_t h, int3
 int mi355det_stem_l1_rows(int32_t n, int32_t h, int32_t w);
 int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1, void* a0,
                          int32_t a0_ld, void* z1, int32_t z1_ld, float* stats, int32_t n, int32_t h, int32_t w, void* stream);
+/* Inference form of the same launch: stem activation (folded BN: scale_shift0 from mi355det_bn_eval_scale_shift) + layer1.ds_conv + ITS folded
+ * BN + LeakyReLU; a1 [n, h/2, w/2, 64] bf16 is the layer's ACTIVATION, the stem activation is never stored (839 MB written and read back at
+ * batch 32 / 640 px otherwise).  scale_shift1 = scale[64] | shift[64] of layer 1. */
+int mi355det_stem_l1_fwd_eval(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1,
+                              const float* scale_shift1, void* a1, int32_t a1_ld, int32_t n, int32_t h, int32_t w, void* stream);
 int mi355det_stem_rows(int32_t n, int32_t h, int32_t w);
 int mi355det_stem_fwd_stats(const float* img, const void* w, float* partial, int32_t n, int32_t h, int32_t wd, void* stream);
 int mi355det_stem_fwd_apply(const float* img, const void* w, const float* scale_shift, float slope, void* a, int32_t a_ld,

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mi355det_stem_rows": (C.c_int, [i32, i32, i32]),
     "mi355det_stem_l1_rows": (C.c_int, [i32, i32, i32]),
     "mi355det_stem_l1_fwd": (C.c_int, [vp, vp, vp, f32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "mi355det_stem_l1_fwd_eval": (C.c_int, [vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mi355det_stem_fwd_stats": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "mi355det_stem_fwd_apply": (C.c_int, [vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]),
     "mi355det_stem_bwd_reduce": (C.c_int, [vp, vp, vp, f32, vp, i32, vp, i32, i32, i32, vp]),

@@ -48,6 +48,7 @@ struct StemL1Params {
   bf16_t* a0;             // activation out or null, pitch a0_ld
   bf16_t* z1;             // pre-BN output, pitch z1_ld
   float* stats;           // [grid][2][64]
+  const float* ss1;       // inference form: scale | shift [2*64] of layer 1's folded BatchNorm -> z1 receives lrelu(z*scale + shift), no statistics
   int a0_ld, z1_ld;
   int n, H, W, tiles_x, tiles_y, ntiles;
   float slope;
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int ch_half = wid & 1, row_half = wid >> 1;          // convolution phase: 32 output channels x 4 output rows per wave
+  float* const aff1 = (float*)(smem + 2 * IMG_BYTES + A_BYTES + 64 * 16);      // inference form: scale | shift of layer 1 (128 floats)
+  if (p.ss1 && tid < 128) aff1[tid] = p.ss1[tid];
 
   // ---- stem weights (row fr of fragment i = channel (fr/4)*8 + i*4 + fr%4: a lane's accumulators are 8 consecutive channels)
   bf16x8_t wf0[2];
@@ -237,7 +240,13 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
       unsigned short o[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        o[k] = f2bf(acc[j][k >> 2][k & 3]);
+        float zz = acc[j][k >> 2][k & 3];
+        if (p.ss1) {                                   // inference: folded BN + LeakyReLU, the activation itself is stored
+          const int ch = ch_half * 32 + fq * 8 + k;
+          zz = zz * aff1[ch] + aff1[64 + ch];
+          zz = fmaxf(zz, zz * p.slope);
+        }
+        o[k] = f2bf(zz);
         const float v = bf2f(o[k]);                 // statistics of the STORED tensor (igemm_common.h, EPI_STATS)
         s1[k] += v;
         s2[k] += v * v;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
   if (tid < 128) {
     const int ch = tid & 63, which = tid >> 6;
     const int hf = ch >> 5, c = ch & 31;
-    p.stats[(long long)blockIdx.x * 128 + which * 64 + ch] = red[((hf) * 32 + c) * 2 + which] + red[((hf + 2) * 32 + c) * 2 + which];
+    if (p.stats) p.stats[(long long)blockIdx.x * 128 + which * 64 + ch] = red[((hf) * 32 + c) * 2 + which] + red[((hf + 2) * 32 + c) * 2 + which];
   }
 }
 
@@ -307,10 +316,10 @@ int mi355det_stem_l1_rows(int32_t n, int32_t h, int32_t w) {
   return l1_grid(n * (h / (2 * OT_H)) * (w / (2 * OT_W)));
 }
 
-int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1, void* a0, int32_t a0_ld, void* z1,
-                         int32_t z1_ld, float* stats, int32_t n, int32_t h, int32_t w, void* stream) {
+static int stem_l1_impl(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1, void* a0, int32_t a0_ld, void* z1,
+                        int32_t z1_ld, float* stats, const float* ss1, int32_t n, int32_t h, int32_t w, void* stream) {
   if (!l1_ok(n, h, w)) return fail(MI355DET_EINVAL, "%s: needs h %% 16 == 0 and w %% 32 == 0 (got %lld x %lld)", "stem_l1_fwd", h, w);
-  if (!img || !w0 || !scale_shift0 || !w1 || !z1 || !stats || z1_ld < 64 || z1_ld % 8 || (a0 && (a0_ld < 32 || a0_ld % 8)))
+  if (!img || !w0 || !scale_shift0 || !w1 || !z1 || (!stats && !ss1) || z1_ld < 64 || z1_ld % 8 || (a0 && (a0_ld < 32 || a0_ld % 8)))
     return fail(MI355DET_EINVAL, "%s: bad argument", "stem_l1_fwd");
   if (!(slope > 0.f && slope < 1.f)) return fail(MI355DET_EINVAL, "%s: LeakyReLU slope must be in (0, 1)", "stem_l1_fwd");
   if ((long long)n * h * w * (a0 ? a0_ld : 1) * 2 >= 0x7FFFFFF0ll || (long long)n * (h / 2) * (w / 2) * z1_ld * 2 >= 0x7FFFFFF0ll)
@@ -323,6 +332,7 @@ int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_sh
   p.a0 = (bf16_t*)a0;
   p.z1 = (bf16_t*)z1;
   p.stats = stats;
+  p.ss1 = ss1;
   p.a0_ld = a0_ld;
   p.z1_ld = z1_ld;
   p.n = n;
@@ -332,11 +342,23 @@ int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_sh
   p.tiles_y = h / (2 * OT_H);
   p.ntiles = n * p.tiles_x * p.tiles_y;
   p.slope = slope;
-  constexpr int lds = 2 * IMG_BYTES + A_BYTES + 64 * 16;
+  constexpr int lds = 2 * IMG_BYTES + A_BYTES + 64 * 16 + 128 * 4;
   static DeviceOnce once;
   if (once.first()) (void)hipFuncSetAttribute((const void*)stem_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(stem_l1_kernel, dim3(l1_grid(p.ntiles)), dim3(256), lds, S(stream), p);
   return check_launch("stem_l1_fwd");
+}
+
+int mi355det_stem_l1_fwd(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1, void* a0, int32_t a0_ld, void* z1,
+                         int32_t z1_ld, float* stats, int32_t n, int32_t h, int32_t w, void* stream) {
+  if (!stats) return fail(MI355DET_EINVAL, "%s: null statistics buffer", "stem_l1_fwd");
+  return stem_l1_impl(img, w0, scale_shift0, slope, w1, a0, a0_ld, z1, z1_ld, stats, nullptr, n, h, w, stream);
+}
+
+int mi355det_stem_l1_fwd_eval(const float* img, const void* w0, const float* scale_shift0, float slope, const void* w1, const float* scale_shift1,
+                              void* a1, int32_t a1_ld, int32_t n, int32_t h, int32_t w, void* stream) {
+  if (!scale_shift1) return fail(MI355DET_EINVAL, "%s: null scale / shift", "stem_l1_fwd_eval");
+  return stem_l1_impl(img, w0, scale_shift0, slope, w1, nullptr, 0, a1, a1_ld, nullptr, scale_shift1, n, h, w, stream);
 }
 
 }  // extern "C"

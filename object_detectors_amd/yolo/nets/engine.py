@@ -418,7 +418,10 @@ class Plan:
                 self.fwd_const.append((L.mi355det_bn_eval_scale_shift, (shp.cout, _vp(eng.params[b + ".weight"]), _vp(eng.params[b + ".bias"]),
                                                                   _vp(eng.buffers[b + ".running_mean"]),
                                                                   _vp(eng.buffers[b + ".running_var"]), BN_EPS, _vp(ss), self.stream)))
-                self.fwd.append((L.mi355det_conv_fwd_ex, (C.byref(shp), x.ptr, _vp(wf), C.byref(e), a.ptr, 0, cp, self.stream)))
+                if fused:
+                    fused[1](a, ss)            # stem activation + this convolution + its folded BN / LeakyReLU in one launch
+                else:
+                    self.fwd.append((L.mi355det_conv_fwd_ex, (C.byref(shp), x.ptr, _vp(wf), C.byref(e), a.ptr, 0, cp, self.stream)))
                 rec = dict(kind="cbl", name=name, spec=s, shp=shp, x=x, a=a, res=res, z=None, ss=ss, pixels=pixels)
                 a.producer = rec
                 self.ops.append(rec)
@@ -578,6 +581,13 @@ class Plan:
                 self.fwd.append(img_call(L.mi355det_stem_l1_fwd, (_vp(wf), _vp(ss), SLOPE, _vp(wf1), a.ptr, a.ld, _vp(z1), 64, _vp(stats1), n, H, W,
                                                                   self.stream)))
             fused = (l1_rows, emit)
+        elif not self.training and l1_rows > 0 and os.environ.get("MI355DET_STEM_L1", "1") != "0":
+            # inference: the same launch with layer 1's folded BN + LeakyReLU in its epilogue; the stem activation is never stored
+            wf1, _ = eng.packed["backbone.layer1.ds_conv"]
+
+            def emit_eval(a1, ss1):
+                self.fwd.append(img_call(L.mi355det_stem_l1_fwd_eval, (_vp(wf), _vp(ss), SLOPE, _vp(wf1), _vp(ss1), a1.ptr, a1.ld, n, H, W, self.stream)))
+            fused = (l1_rows, emit_eval)
         else:
             self.fwd.append(img_call(L.mi355det_stem_fwd_apply, (_vp(wf), _vp(ss), SLOPE, a.ptr, a.ld, n, H, W, self.stream)))
         rec = dict(kind="stem", name=name, spec=s, x=None, a=a, res=None, z=None, ss=ss, pixels=pixels, rows=rows, img_call=img_call, fused_l1=fused)

@@ -197,3 +197,13 @@ def test_fused_stem_and_first_downsampling_conv(shape):
     check(L.mi355det_stem_l1_fwd(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(wf1), None, 0, _vp(z1b), 64, _vp(stats), n, h, w, st), "stem_l1_fwd")
     torch.cuda.synchronize()
     assert torch.equal(z1b, z1)
+    # inference form: layer 1's folded BN + LeakyReLU in the epilogue, the stem activation never stored
+    g2 = torch.Generator().manual_seed(7)
+    sc1, sh1 = (1.0 + 0.3 * torch.randn(64, generator=g2)), 0.2 * torch.randn(64, generator=g2)
+    ss1 = torch.cat([sc1, sh1]).to(dev())
+    a1 = torch.full((n, h // 2, w // 2, 64), 5.0, dtype=torch.bfloat16, device=dev())
+    check(L.mi355det_stem_l1_fwd_eval(_vp(imgd), _vp(wp), _vp(ss), SLOPE, _vp(wf1), _vp(ss1), _vp(a1), 64, n, h, w, st), "stem_l1_fwd_eval")
+    torch.cuda.synchronize()
+    want1 = F.leaky_relu(zr * sc1[None, :, None, None] + sh1[None, :, None, None], SLOPE)
+    got1 = a1.float().cpu().permute(0, 3, 1, 2)
+    assert float((got1 - want1).abs().max()) <= 1.5e-2 * float(want1.abs().max())
