@@ -389,15 +389,19 @@ __device__ __forceinline__ void topk_select_digit(const unsigned* __restrict__ h
 __device__ __forceinline__ void topk_replay(const TopkState* st, int levels, unsigned k, unsigned* s_sel /* LDS [4] */) {
   const int shifts[3] = {21, 10, 0};
   const int bits[3] = {11, 11, 10};
-  unsigned prefix = 0, need = k, all = 0;
+  unsigned prefix = 0, need = k, all = 0, stop = 0;
   __shared__ unsigned s_tmp[3];
-  for (int l = 0; l < levels && !all; ++l) {
+  for (int l = 0; l < levels && !all && !stop; ++l) {
     if (threadIdx.x < WAVE) topk_select_digit(st->hist[l], 1 << bits[l], need, s_tmp);
     __syncthreads();
     all = s_tmp[2];
     if (!all) {
       prefix |= s_tmp[0] << shifts[l];
       need = s_tmp[1];
+      // Early stop: the keys above this bucket (k - need of them) plus the whole bucket fit the candidate buffer - the final sort picks the
+      // k best of them exactly, so the remaining histogram levels (a full pass over the row each) are skipped.  With a score threshold
+      // (RetinaNet post-processing) the first level usually decides: two passes over a 108 M-element row instead of four.
+      if ((k - need) + st->hist[l][s_tmp[0]] <= (unsigned)TOPK_MAXK - 64u) stop = (unsigned)l + 1u;
     }
     __syncthreads();
   }
@@ -405,6 +409,7 @@ __device__ __forceinline__ void topk_replay(const TopkState* st, int levels, uns
     s_sel[0] = prefix;
     s_sel[1] = need;
     s_sel[2] = all;
+    s_sel[3] = stop;      // > 0: `prefix` holds only the digits of levels < stop; every key >= prefix is a candidate
   }
   __syncthreads();
 }
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict
   const unsigned min_key = f2ord(min_value);
   for (int i = threadIdx.x; i < 2048; i += 1024) hist[i] = 0;
   topk_replay(st, LEVEL, (unsigned)k, s_sel);               // (ends with a barrier: hist zeroed too)
-  if (s_sel[2]) return;                                      // fewer than k valid keys in the row: no threshold to refine
+  if (s_sel[2] || s_sel[3]) return;                          // fewer than k valid keys in the row, or the candidates already fit: nothing to refine
   const unsigned prefix = s_sel[0];
   unsigned mask_hi = 0;
   for (int l = 0; l < LEVEL; ++l) mask_hi |= (unsigned)((1 << bits[l]) - 1) << shifts[l];
@@ -470,7 +475,9 @@ __global__ __launch_bounds__(1024) void topk_collect_kernel(const float* __restr
   const unsigned min_key = f2ord(min_value);
   topk_replay(st, 3, (unsigned)k, s_sel);
   const bool all = s_sel[2] != 0;
-  const unsigned thr = all ? min_key : s_sel[0];             // take key > thr, and (not all) keys == thr as tie candidates
+  const bool coarse = s_sel[3] != 0;                         // early stop: keys >= the coarse prefix are all candidates
+  const unsigned thr = all ? min_key : (coarse ? (s_sel[0] ? s_sel[0] - 1u : 0u) : s_sel[0]);   // take key > thr, and (exact form) keys == thr as ties
+  const bool take_zero = coarse && s_sel[0] == 0;           // prefix 0: key 0 itself is a candidate too (key > thr cannot express it)
   const long long per = (n + gridDim.x - 1) / gridDim.x;
   const long long lo = per * blockIdx.x, hi = min(n, lo + per);
   // 4096 elements per round (the LDS list cannot overflow): one 16-byte load per thread over the aligned body of the range
@@ -487,8 +494,8 @@ __global__ __launch_bounds__(1024) void topk_collect_kernel(const float* __restr
     __syncthreads();
     auto take = [&](long long i, float v) {
       const unsigned key = f2ord(v);
-      const bool gt = key > thr && key > min_key;
-      const bool tie = !all && key == thr && key > min_key;
+      const bool gt = (key > thr || take_zero) && key > min_key;
+      const bool tie = !all && !coarse && key == thr && key > min_key;
       if (gt || tie) {
         const unsigned p = atomicAdd(&s_cnt, 1u);
         s_keys[p] = ((unsigned long long)key << 32) | (0xFFFFFFFFu - (unsigned)(lo + i));
