@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-// The same finalisation in ONE launch for 256 < rows <= 8192 (54 of the 72 YOLOv3 layers at batch 32 / 640 px): 8 channels x 128 row parts
+// The same finalisation in ONE launch for 32 < rows <= 8192 (all but the three 320-px layers of YOLOv3 at batch 32 / 640 px): 8 channels x 128 row parts
 // per workgroup, every thread's loads independent (<= 16 rows each, 4 in flight), double accumulation, fixed-order LDS fold.  The
 // two-launch form below (bn_partial_kernel + bn_finalize_kernel) costs 6 + 7 us of pure launch latency per layer in the forward chain
 // conv -> statistics -> activation, where nothing else can run.
@@ -684,7 +684,7 @@ int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
   static const bool wide_off = getenv("MI355DET_BN_FINALIZE_TWO_STAGE") != nullptr;     // A/B knob
-  if (rows > 256 && rows <= 8192 && !wide_off) {
+  if (rows > 32 && rows <= 8192 && !wide_off) {
     hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3((c + 7) / 8), dim3(1024), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale_shift);
     return check_launch("bn_finalize");
