@@ -745,15 +745,23 @@ class Plan:
                 self.bwd.append((L.mi355det_bn_act_bwd_apply, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), _vp(sums), None, shp.cout,
                                                                pixels, SLOPE, _vp(dzb), shp.cout, _vp(eng.grads[b + ".weight"]),
                                                                _vp(eng.grads[b + ".bias"]), self.stream)))
-                ev_dz, ev_wg = torch.cuda.Event(), torch.cuda.Event()
-                py(ev_dz.record, main)
-                py(self.side.wait_event, ev_dz)
-                self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
-                                                         ws_ptr, ws_bytes, side_ptr)))
-                py(ev_wg.record, self.side)
-                wg_done[di] = ev_wg
-                _, wd = eng.packed[name]
-                emit_dgrad(shp, _vp(dzb), wd, x)
+                serial_hw = int(os.environ.get("MI355DET_WGRAD_SERIAL_HW", "0"))      # A/B: weight gradients of maps >= this size on the main stream
+                if serial_hw and shp.ho >= serial_hw:
+                    _, wd = eng.packed[name]
+                    emit_dgrad(shp, _vp(dzb), wd, x)
+                    self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
+                                                             ws_ptr, ws_bytes, self.stream)))
+                    wg_done[di] = None
+                else:
+                    ev_dz, ev_wg = torch.cuda.Event(), torch.cuda.Event()
+                    py(ev_dz.record, main)
+                    py(self.side.wait_event, ev_dz)
+                    self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
+                                                             ws_ptr, ws_bytes, side_ptr)))
+                    py(ev_wg.record, self.side)
+                    wg_done[di] = ev_wg
+                    _, wd = eng.packed[name]
+                    emit_dgrad(shp, _vp(dzb), wd, x)
             if rec["kind"] in ("out", "cbl", "stem"):
                 self.bwd_marks.append((len(self.bwd), first_off[rec["name"] + ".weight"]))
         ev_end = torch.cuda.Event()
