@@ -152,6 +152,20 @@ int mi355det_nms(const float* boxes, const float* scores, const int64_t* idxs, i
 int mi355det_nms_batch(const float* boxes, const float* scores, const int64_t* idxs, int32_t bs, int32_t n, float iou_thr, int64_t* keep,
                        int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream);
 
+/* RegionProposalNetwork.filter_proposals for the whole batch in one call (tvision/rpn.py:215-280, with the anchor decode of :336-351
+ * restricted to the selected anchors): per-level top-k of the objectness logits, decode (BoxCoder weights 1, clamp xform_clip), clip to
+ * clip_limits[img] = (w, h, w, h), boxes smaller than min_size or scoring below score_thresh masked out, per-level NMS, the first
+ * post_nms_top_n survivors of every image.  objectness [N, A] fp32 logits and deltas [N, A, 4], A = sum(level_counts) with the levels
+ * concatenated in pyramid order; anchors [A, 4] xyxy; level_counts [nlev] on the HOST (nlev <= 8).  Outputs: out_boxes [N, post, 4],
+ * out_scores [N, post] (sigmoid), out_counts [N] int32 on the device - rows beyond out_counts[img] are zero.  Results are those of
+ * mi355det_topk + mi355det_box_decode + the clip / mask chain + mi355det_nms_batch, bit for bit.
+ * Workspace: mi355det_rpn_proposals_workspace (0 for invalid arguments). */
+size_t mi355det_rpn_proposals_workspace(int32_t n_images, const int64_t* level_counts, int32_t nlev, int32_t pre_nms_top_n);
+int mi355det_rpn_proposals(const float* objectness, const float* deltas, const float* anchors, const float* clip_limits, int32_t n_images,
+                           const int64_t* level_counts, int32_t nlev, int32_t pre_nms_top_n, int32_t post_nms_top_n, float nms_thresh,
+                           float score_thresh, float min_size, float xform_clip, float* out_boxes, float* out_scores, int32_t* out_counts,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* box_iou + Matcher.__call__ (+ set_low_quality_matches_) fused, never materialising [M,N]
  * (tvision/_utils.py:271-344 after retinanet.py:409).  gt [M,4], anchors [N,4] xyxy.
  * out matches [N] int64 in {-2,-1,0..M-1}; gt_best [M] uint32 scratch. */
@@ -244,6 +258,15 @@ int mi355det_topk(const float* x, int32_t rows, int64_t n, int64_t row_stride, i
 size_t mi355det_topk_workspace(int32_t rows);
 int mi355det_topk_ws(const float* x, int32_t rows, int64_t n, int64_t row_stride, int32_t k, float min_value, int64_t* idx_out,
                      float* val_out, int32_t* count_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same selection for rows cut into up to 8 SEGMENTS (the pyramid levels of RegionProposalNetwork._get_top_n_idx, tvision/rpn.py:215-228):
+ * segment s of row r is x[r*row_stride + seg_start[s] ...][0..seg_n[s]), its k = seg_k[s] <= seg_n[s]; outputs per segment idx_out[s]
+ * [rows, k] (index WITHIN the segment), val_out[s] [rows, k] (val_out or its entries may be NULL), count_out[s] [rows].  Segments shorter
+ * than 65536 share ONE launch (a workgroup per row and segment), longer ones take the mi355det_topk_ws route.  seg_* and the pointer
+ * tables are HOST arrays.  workspace: mi355det_topk_workspace(rows) bytes. */
+int mi355det_topk_segments(const float* x, int32_t rows, int64_t row_stride, int32_t nseg, const int64_t* seg_start, const int64_t* seg_n,
+                           const int32_t* seg_k, float min_value, int64_t* const* idx_out, float* const* val_out, int32_t* const* count_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution path (yolo/nets/backbone/darknet.py:13-20,41-43,64-66; yolo/nets/yolohead.py:41-61):

@@ -22,6 +22,7 @@ SOURCES = [
     ("yolo_kernels.hip", ["-ffp-contract=off"]),
     ("box_kernels.hip", ["-ffp-contract=off"]),
     ("roi_kernels.hip", ["-ffp-contract=off"]),
+    ("proposal_kernels.hip", ["-ffp-contract=off"]),
     ("frcnn_kernels.hip", ["-ffp-contract=off"]),
     ("transform_kernels.hip", ["-ffp-contract=off"]),
     ("resnet_kernels.hip", []),

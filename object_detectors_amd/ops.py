@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory and the stream; every computatio
 in libmi355det.so.  All tensors must live on the GPU; nothing falls back to torch ops.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -196,6 +197,30 @@ def nms_batch(boxes, scores, iou_threshold, idxs=None):
     return keep, cnt
 
 
+def rpn_proposals(objectness, deltas, anchors, clip_limits, level_counts, pre_nms_top_n, post_nms_top_n, nms_thresh, score_thresh=0.0,
+                  min_size=1e-3, xform_clip=math.log(1000.0 / 16)):
+    """RegionProposalNetwork.filter_proposals (rpn.py:215-280) incl. the decode of the selected anchors, whole batch, one host call:
+    objectness [N,A] logits, deltas [N,A,4], anchors [A,4], clip_limits [N,4] = (w,h,w,h) -> (boxes [N,post,4], scores [N,post],
+    counts [N] int32 on the device; rows beyond counts[i] are zero)."""
+    objectness, deltas, anchors, clip_limits = _f32c(objectness), _f32c(deltas), _f32c(anchors), _f32c(clip_limits)
+    n, a = objectness.shape
+    if deltas.numel() != n * a * 4 or anchors.numel() != a * 4 or clip_limits.numel() != n * 4 or sum(level_counts) != a:
+        raise ValueError("rpn_proposals: objectness [N,A], deltas [N,A,4], anchors [A,4], clip_limits [N,4], sum(level_counts) == A")
+    lc = (C.c_int64 * len(level_counts))(*[int(v) for v in level_counts])
+    wsb = lib().mi355det_rpn_proposals_workspace(n, lc, len(level_counts), int(pre_nms_top_n))
+    if wsb == 0:
+        raise ValueError("rpn_proposals: need 1..8 non-empty levels, a positive batch and pre_nms_top_n")
+    dev = objectness.device
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    boxes = torch.empty((n, int(post_nms_top_n), 4), device=dev, dtype=torch.float32)
+    scores = torch.empty((n, int(post_nms_top_n)), device=dev, dtype=torch.float32)
+    counts = torch.empty(n, device=dev, dtype=torch.int32)
+    check(lib().mi355det_rpn_proposals(ptr(objectness), ptr(deltas), ptr(anchors), ptr(clip_limits), n, lc, len(level_counts), int(pre_nms_top_n),
+                                       int(post_nms_top_n), float(nms_thresh), float(score_thresh), float(min_size), float(xform_clip),
+                                       ptr(boxes), ptr(scores), ptr(counts), ptr(ws), wsb, stream_ptr()), "rpn_proposals")
+    return boxes, scores, counts
+
+
 def nms(boxes, scores, iou_threshold, idxs=None):
     boxes, scores = _f32c(boxes), _f32c(scores)
     n = boxes.shape[0]
@@ -373,6 +398,27 @@ def topk_rows(x, k, min_value=float("-inf")):
         return val, idx, cnt
     check(lib().mi355det_topk(ptr(x), rows, n, x.stride(0), k, float(min_value), ptr(idx), ptr(val), ptr(cnt), stream_ptr()), "topk")
     return val, idx, cnt
+
+
+def topk_segments(x, seg_counts, k, min_value=float("-inf")):
+    """x [rows, sum(seg_counts)] fp32: top-min(k, n_s) of every segment of every row in one call (RegionProposalNetwork._get_top_n_idx,
+    rpn.py:215-228) -> list per segment of (values [rows,k_s], indices within the segment [rows,k_s] i64, count [rows] i32)."""
+    x = _f32c(x)
+    rows, a = x.shape
+    if sum(seg_counts) != a or not 1 <= len(seg_counts) <= 8:
+        raise ValueError("topk_segments: 1..8 segments that add up to the row length")
+    ns = len(seg_counts)
+    ks = [int(min(k, n)) for n in seg_counts]
+    starts = [sum(seg_counts[:i]) for i in range(ns)]
+    outs = [(torch.zeros((rows, kk), device=x.device, dtype=torch.float32), torch.zeros((rows, kk), device=x.device, dtype=torch.int64),
+             torch.empty(rows, device=x.device, dtype=torch.int32)) for kk in ks]
+    wsb = lib().mi355det_topk_workspace(rows)
+    ws = torch.empty(wsb, device=x.device, dtype=torch.uint8)
+    i64a, i32a, vpa = C.c_int64 * ns, C.c_int32 * ns, C.c_void_p * ns
+    check(lib().mi355det_topk_segments(ptr(x), rows, x.stride(0), ns, i64a(*starts), i64a(*[int(n) for n in seg_counts]), i32a(*ks), float(min_value),
+                                       vpa(*[ptr(o[1]) for o in outs]), vpa(*[ptr(o[0]) for o in outs]), vpa(*[ptr(o[2]) for o in outs]),
+                                       ptr(ws), wsb, stream_ptr()), "topk_segments")
+    return outs
 
 
 # ------------------------------------------------------------------------------------ ResNet-FPN / RetinaNet companions

@@ -18,6 +18,8 @@ Where the work runs:
 Inputs as in tvision/retinanet.py: a list of [3,H,W] images goes through the GPU GeneralizedRCNNTransform (generalized_rcnn.py:78-79,110), a ready
 [N,3,H,W] batch skips it.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -25,11 +27,14 @@ from .. import ops
 from ._utils import BoxCoder
 from .linear import MfmaLinear
 from .engine import IMAGE_MEAN, IMAGE_STD, FasterRCNNEngine
-from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals
+from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals, rpn_proposals_fused
 from .roi_align import MultiScaleRoIAlign
 from .roi_heads import RoIHeadTargets, fastrcnn_loss, minibatch_tfidf
 from .rpn import RPNTargets
 from .transform import GeneralizedRCNNTransform
+
+
+_RPN_FUSED = os.environ.get("MI355DET_RPN_FUSED", "1") != "0"      # 0: box_decode of every anchor + the torch-composed filter (A/B, tests)
 
 
 class TwoMLPHead(nn.Module):
@@ -129,10 +134,14 @@ class FasterRCNN(nn.Module):
     def _proposals(self, out, plan, image_shapes):
         """rpn.py:336-351: decode every anchor with the (detached) deltas, then filter_proposals."""
         n = out["cls_logits"].shape[0]
+        mode = "training" if self.training else "testing"
+        if _RPN_FUSED:
+            return rpn_proposals_fused(out["bbox_regression"], out["cls_logits"], plan.anchors, image_shapes, plan.level_rows, self.rpn_pre[mode],
+                                       self.rpn_post[mode], self.rpn_nms_thresh, self.rpn_score_thresh,
+                                       xform_clip=self.rpn_coder.bbox_xform_clip)
         deltas = out["bbox_regression"].detach().reshape(-1, 4)
         anchors = plan.anchors.repeat(n, 1)
         proposals = ops.box_decode(deltas, anchors, (1.0, 1.0, 1.0, 1.0), self.rpn_coder.bbox_xform_clip).reshape(n, -1, 4)
-        mode = "training" if self.training else "testing"
         return rpn_filter_proposals(proposals, out["cls_logits"].detach().reshape(n, -1), image_shapes, plan.level_rows, self.rpn_pre[mode],
                                     self.rpn_post[mode], self.rpn_nms_thresh, self.rpn_score_thresh)
 

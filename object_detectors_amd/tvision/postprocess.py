@@ -23,8 +23,10 @@ def _clip_limits(image_shapes, device, dtype):
     if t is None:
         if len(_CLIP_LIMITS) > 64:
             _CLIP_LIMITS.clear()
-        hw = torch.tensor([[float(s[1]), float(s[0])] for s in image_shapes], device=device, dtype=dtype)
-        t = _CLIP_LIMITS[key] = hw.repeat(1, 2)[:, None, :]
+        host = torch.tensor([[float(s[1]), float(s[0])] * 2 for s in image_shapes], dtype=dtype)
+        if torch.device(device).type == "cuda":
+            host = host.pin_memory()                       # a miss (new image sizes) costs an asynchronous copy, not a device drain
+        t = _CLIP_LIMITS[key] = host.to(device, non_blocking=True)[:, None, :]
     return t
 
 
@@ -66,6 +68,20 @@ def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_le
         final_boxes.append(boxes[i][k])
         final_scores.append(obj[i][k])
     return final_boxes, final_scores
+
+
+def rpn_proposals_fused(deltas, objectness, anchors, image_shapes, num_anchors_per_level, pre_nms_top_n, post_nms_top_n, nms_thresh=0.7,
+                        score_thresh=0.0, min_size=1e-3, xform_clip=math.log(1000.0 / 16)):
+    """rpn.py:336-351 + filter_proposals (:215-280) from the RAW deltas [N, A, 4] and logits [N, A] in one host call
+    (`mi355det_rpn_proposals`: only the selected anchors are decoded) and one device-to-host read; same results as
+    `ops.box_decode` + `rpn_filter_proposals`, bit for bit (tests/test_gpu_proposals.py).  -> (list of boxes [<=post,4], list of scores)."""
+    n = objectness.shape[0]
+    lim = _clip_limits(image_shapes, objectness.device, torch.float32).reshape(n, 4)
+    boxes, scores, counts = ops.rpn_proposals(objectness.detach().reshape(n, -1), deltas.detach().reshape(n, -1, 4), anchors, lim,
+                                              list(num_anchors_per_level), pre_nms_top_n, post_nms_top_n, nms_thresh, score_thresh, min_size,
+                                              xform_clip)
+    counts = counts.tolist()                                                  # the one synchronisation of the proposal filter
+    return [boxes[i, :c] for i, c in enumerate(counts)], [scores[i, :c] for i, c in enumerate(counts)]
 
 
 def retinanet_postprocess_detections(cls_logits_per_level, bbox_reg_per_level, anchors_per_level, image_shapes, tfidf_post=None,

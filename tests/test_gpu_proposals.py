@@ -1,0 +1,107 @@
+"""mi355det_rpn_proposals (one host call for RegionProposalNetwork.filter_proposals, tvision/rpn.py:215-280 + the decode of :336-351)
+against the composed route (ops.box_decode of every anchor + postprocess.rpn_filter_proposals, itself pinned by the oracle in
+tests/test_gpu_frcnn.py): bit for bit."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(seed, n, levels, sizes):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    a = sum(levels)
+    obj = torch.randn((n, a), device=dev, generator=g) * 3
+    ctr = torch.rand((a, 2), device=dev, generator=g) * 900 - 50            # some anchors partly / fully outside the image
+    wh = torch.rand((a, 2), device=dev, generator=g) * 300 + 2
+    anchors = torch.cat([ctr - wh / 2, ctr + wh / 2], -1)
+    deltas = torch.randn((n, a, 4), device=dev, generator=g) * 0.5
+    deltas[:, ::97, 2:] = 9.0                                               # beyond bbox_xform_clip
+    deltas[:, ::53, 2:] = -20.0                                             # collapses to a box below min_size
+    return obj, deltas, anchors, sizes[:n]
+
+
+@pytest.mark.parametrize("n,levels,pre,post,score_thresh", [
+    (4, [200 * 200 * 3, 100 * 100 * 3, 50 * 50 * 3, 25 * 25 * 3, 13 * 13 * 3], 2000, 2000, 0.0),       # training, 800 px
+    (2, [200 * 200 * 3, 100 * 100 * 3, 50 * 50 * 3, 25 * 25 * 3, 13 * 13 * 3], 1000, 1000, 0.0),       # testing
+    (3, [300, 75, 21], 1000, 50, 0.0),                                                                 # k = whole level, cut at post
+    (2, [5000, 1200], 600, 300, 0.6),                                                                  # score threshold
+    (1, [4096], 4096, 1000, 0.0),
+])
+def test_rpn_proposals_matches_composed_route(n, levels, pre, post, score_thresh):
+    from object_detectors_amd import ops
+    from object_detectors_amd.tvision.postprocess import rpn_filter_proposals, rpn_proposals_fused
+    sizes = [(800, 800), (640, 768), (512, 800), (800, 600)]
+    obj, deltas, anchors, shapes = _inputs(5 + n + len(levels), n, levels, sizes)
+    clip = math.log(1000.0 / 16)
+    props = ops.box_decode(deltas.reshape(-1, 4), anchors.repeat(n, 1), (1.0, 1.0, 1.0, 1.0), clip).reshape(n, -1, 4)
+    rb, rs = rpn_filter_proposals(props, obj, shapes, levels, pre, post, 0.7, score_thresh)
+    fb, fs = rpn_proposals_fused(deltas, obj, anchors, shapes, levels, pre, post, 0.7, score_thresh, xform_clip=clip)
+    assert len(fb) == len(rb) == n
+    for i in range(n):
+        assert fb[i].shape == rb[i].shape and fb[i].shape[0] > 0, (i, fb[i].shape, rb[i].shape)
+        assert torch.equal(fb[i], rb[i]), (i, (fb[i] - rb[i]).abs().max())
+        assert torch.equal(fs[i], rs[i]), (i, (fs[i] - rs[i]).abs().max())
+
+
+def test_rpn_proposals_rows_with_few_finite_logits_and_bad_arguments():
+    from object_detectors_amd import ops
+    dev = torch.device("cuda:0")
+    obj, deltas, anchors, _ = _inputs(3, 2, [900, 100], [(400, 400)] * 2)
+    obj[0, :880] = float("-inf")                               # fewer than k finite logits in level 0 of image 0
+    lim = torch.tensor([[400.0, 400.0, 400.0, 400.0]] * 2, device=dev)
+    boxes, scores, counts = ops.rpn_proposals(obj, deltas, anchors, lim, [900, 100], 500, 200, 0.7)
+    c = counts.tolist()
+    assert 0 < c[0] <= 120 and 0 < c[1] <= 200
+    assert torch.isfinite(boxes).all() and (boxes[0, c[0]:] == 0).all() and (scores[0, c[0]:] == 0).all()
+    assert (boxes >= 0).all() and (boxes <= 400).all()
+    with pytest.raises(ValueError):
+        ops.rpn_proposals(obj, deltas, anchors, lim, [900, 99], 500, 200, 0.7)          # levels do not add up to A
+    with pytest.raises(ValueError):
+        ops.rpn_proposals(obj, deltas, anchors, lim, [100] * 10, 500, 200, 0.7)         # more than 8 levels
+
+
+@pytest.mark.parametrize("rows,segs,k", [
+    (4, [120000, 30000, 7500, 1875, 507], 2000),       # the RPN pyramid at 800 px (first segment: the many-workgroup route)
+    (3, [30001, 4099, 63], 1000),                      # unaligned starts, k = whole segment
+    (2, [65535, 17], 16384),                           # the longest short segment, the largest k
+    (5, [9000], 300),
+])
+def test_topk_segments_matches_topk_rows(rows, segs, k):
+    from object_detectors_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(rows * 7 + len(segs))
+    x = torch.randn((rows, sum(segs)), device=dev, generator=g)
+    x[0, : min(5000, segs[0])] = 0.25                  # a run of identical keys around / above the threshold
+    if rows > 1:
+        x[1] = torch.round(x[1] * 4) / 4               # heavy ties everywhere
+    outs = ops.topk_segments(x, segs, k)
+    off = 0
+    for (val, idx, cnt), n in zip(outs, segs):
+        rv, ri, rc = ops.topk_rows(x[:, off:off + n], k)
+        assert torch.equal(cnt, rc) and torch.equal(idx, ri) and torch.equal(val, rv), (n, (idx != ri).sum().item())
+        tv, ti = torch.sort(x[:, off:off + n], dim=1, descending=True, stable=True)
+        kk = min(k, n)
+        assert torch.equal(val, tv[:, :kk]) and torch.equal(idx, ti[:, :kk])
+        off += n
+
+
+def test_topk_segments_degenerate_rows_and_threshold():
+    from object_detectors_amd import ops
+    dev = torch.device("cuda:0")
+    x = torch.zeros((3, 40000 + 20000), device=dev)
+    x[0] = 1.5                                          # every key identical: more ties than the candidate list holds -> ordered fallback
+    x[1, ::3] = float("-inf")
+    x[1, 1::3] = torch.arange(20000, device=dev, dtype=torch.float32)
+    x[2] = torch.arange(60000, device=dev, dtype=torch.float32) % 7
+    outs = ops.topk_segments(x, [40000, 20000], 3000, min_value=0.5)
+    off = 0
+    for (val, idx, cnt), n in zip(outs, [40000, 20000]):
+        rv, ri, rc = ops.topk_rows(x[:, off:off + n], 3000, min_value=0.5)
+        assert torch.equal(cnt, rc)
+        for r in range(3):
+            c = int(cnt[r])
+            assert torch.equal(idx[r, :c], ri[r, :c]) and torch.equal(val[r, :c], rv[r, :c])
+        off += n
