@@ -166,6 +166,26 @@ int mi355det_rpn_proposals(const float* objectness, const float* deltas, const f
                            float score_thresh, float min_size, float xform_clip, float* out_boxes, float* out_scores, int32_t* out_counts,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* RoIHeads.select_training_samples for the whole batch (tvision/roi_heads.py:627-713), the two launches around the one host read its
+ * sampler needs.  Candidates of image i are its proposals (proposals [N, max_proposals, 4] padded, proposal_counts [N] on the device, as
+ * mi355det_rpn_proposals leaves them) followed by its ground truth (add_gt_proposals): gt_boxes [G,4] / gt_labels [G] of all images
+ * concatenated, gt_offsets [N+1] on the HOST (1..1024 boxes per image; at most 64 images, 8192 candidates per image).
+ *   mi355det_roi_match: box_iou + Matcher(fg_iou_thresh, bg_iou_thresh, no low-quality rescue) + assign_targets_to_proposals ->
+ *     matched [N, row_stride] (clamped at 0), labels [N, row_stride] (-1 between the thresholds, 0 background, else the class),
+ *     counts [N, 2] = positives (label >= 1), negatives (label == 0).
+ *   mi355det_roi_sample: perm_pos[i] / perm_neg[i] (HOST tables of device pointers) are `torch.randperm(positives_i)` /
+ *     `randperm(negatives_i)`, of which the first num_pos[i] / num_neg[i] (HOST) are used exactly as BalancedPositiveNegativeSampler
+ *     does (tvision/_utils.py:38-73); outputs for the sum(num_pos + num_neg) samples in image order, ascending candidate index inside an
+ *     image: rois [S, 5] = (image, box), out_labels [S], out_matched [S], out_regression_targets [S, 4] = BoxCoder(wx, wy, ww, wh).encode. */
+int mi355det_roi_match(const float* proposals, const int32_t* proposal_counts, int32_t n_images, int32_t max_proposals, const float* gt_boxes,
+                       const int64_t* gt_labels, const int32_t* gt_offsets, float fg_iou_thresh, float bg_iou_thresh, int32_t row_stride,
+                       int32_t* matched, int32_t* labels, int32_t* counts, void* stream);
+int mi355det_roi_sample(const float* proposals, const int32_t* proposal_counts, int32_t n_images, int32_t max_proposals, const float* gt_boxes,
+                        const int32_t* gt_offsets, int32_t row_stride, const int32_t* matched, const int32_t* labels,
+                        const int64_t* const* perm_pos, const int64_t* const* perm_neg, const int32_t* num_pos, const int32_t* num_neg, float wx,
+                        float wy, float ww, float wh, float* rois, int64_t* out_labels, int64_t* out_matched, float* out_regression_targets,
+                        void* stream);
+
 /* box_iou + Matcher.__call__ (+ set_low_quality_matches_) fused, never materialising [M,N]
  * (tvision/_utils.py:271-344 after retinanet.py:409).  gt [M,4], anchors [N,4] xyxy.
  * out matches [N] int64 in {-2,-1,0..M-1}; gt_best [M] uint32 scratch. */

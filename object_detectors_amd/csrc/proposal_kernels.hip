@@ -97,6 +97,160 @@ __global__ __launch_bounds__(256) void rpn_gather_kernel(const float* __restrict
   }
 }
 
+// ---- RoIHeads.select_training_samples (tvision/roi_heads.py:627-713) for the whole batch --------------------------------------------
+// Two launches around the one host read the sampler needs (its `torch.randperm` calls take the positive / negative counts as sizes and
+// stay in torch so that the draws are the reference's):
+//   roi_match_kernel   candidates of image i = its proposals followed by its ground-truth boxes (add_gt_proposals); box_iou + Matcher
+//                      (high = low threshold style, no low-quality rescue) + label assignment (assign_targets_to_proposals); counts of
+//                      positives (label >= 1) and negatives (label == 0) per image
+//   roi_sample_kernel  positive[perm_pos[:num_pos]] and negative[perm_neg[:num_neg]] (index lists in ascending order, as torch.where
+//                      gives them), the union in ascending order, gathers, BoxCoder.encode of the matched ground truth
+constexpr int ROI_MAX_IMAGES = 64;
+constexpr int ROI_MAX_GT = 1024;
+constexpr int ROI_MAX_CAND = 8192;
+constexpr int ROI_MAX_SAMPLES = 1024;
+
+struct RoiImages {
+  int n;
+  int gt_off[ROI_MAX_IMAGES + 1];
+};
+
+struct RoiSampleArgs {
+  int gt_off[ROI_MAX_IMAGES + 1], out_off[ROI_MAX_IMAGES + 1];
+  int num_pos[ROI_MAX_IMAGES], num_neg[ROI_MAX_IMAGES];
+  const long long* perm_pos[ROI_MAX_IMAGES];
+  const long long* perm_neg[ROI_MAX_IMAGES];
+};
+
+__device__ __forceinline__ float roi_iou(const float4 a, const float4 b) {      // torchvision box_iou(a = ground truth, b = candidate)
+  const float area_a = (a.z - a.x) * (a.w - a.y), area_b = (b.z - b.x) * (b.w - b.y);
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f), h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+  const float inter = w * h;
+  return inter / (area_a + area_b - inter);
+}
+
+__device__ __forceinline__ float4 roi_candidate(const float* __restrict__ props, const float* __restrict__ gt, int img, int P, int pc, int gt0, int j) {
+  return j < pc ? *(const float4*)(props + 4 * ((long long)img * P + j)) : *(const float4*)(gt + 4 * (long long)(gt0 + j - pc));
+}
+
+__global__ __launch_bounds__(256) void roi_match_kernel(const float* __restrict__ props, const int* __restrict__ pcount, int P,
+                                                        const float* __restrict__ gt, const long long* __restrict__ gt_labels, RoiImages I,
+                                                        float hi, float lo, int C, int* __restrict__ matched, int* __restrict__ label,
+                                                        int* __restrict__ counts) {
+  __shared__ float4 sg[ROI_MAX_GT];
+  __shared__ int s_pos, s_neg;
+  const int img = blockIdx.y, gt0 = I.gt_off[img], g = I.gt_off[img + 1] - gt0;
+  const int pc = min(pcount[img], P), c = pc + g;
+  if ((int)(blockIdx.x * blockDim.x) >= c) return;
+  for (int q = threadIdx.x; q < g; q += blockDim.x) sg[q] = *(const float4*)(gt + 4 * (long long)(gt0 + q));
+  if (threadIdx.x == 0) s_pos = s_neg = 0;
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int lab = -2;
+  if (j < c) {
+    const float4 b = roi_candidate(props, gt, img, P, pc, gt0, j);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int q = 0; q < g; ++q) {
+      const float v = roi_iou(sg[q], b);
+      if (q == 0 || v > best) {           // first maximum, as torch.max(dim=0)
+        best = v;
+        arg = q;
+      }
+    }
+    int m = arg;
+    if (best < lo) m = -1;                // Matcher.BELOW_LOW_THRESHOLD
+    else if (best < hi) m = -2;           // Matcher.BETWEEN_THRESHOLDS
+    const int cl = max(m, 0);             // roi_heads.py:640 clamp(min=0)
+    lab = m == -1 ? 0 : (m == -2 ? -1 : (int)gt_labels[gt0 + cl]);
+    matched[(long long)img * C + j] = cl;
+    label[(long long)img * C + j] = lab;
+  }
+  const unsigned long long bp = __ballot(lab >= 1), bn = __ballot(lab == 0);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    if (bp) atomicAdd(&s_pos, __popcll(bp));
+    if (bn) atomicAdd(&s_neg, __popcll(bn));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_pos) atomicAdd(counts + 2 * img, s_pos);
+    if (s_neg) atomicAdd(counts + 2 * img + 1, s_neg);
+  }
+}
+
+__global__ __launch_bounds__(1024) void roi_sample_kernel(const float* __restrict__ props, const int* __restrict__ pcount, int P,
+                                                          const float* __restrict__ gt, RoiSampleArgs A, int C, const int* __restrict__ matched,
+                                                          const int* __restrict__ label, float wx, float wy, float ww, float wh,
+                                                          float* __restrict__ rois, long long* __restrict__ out_labels,
+                                                          long long* __restrict__ out_matched, float* __restrict__ out_reg) {
+  __shared__ unsigned short posl[ROI_MAX_CAND], negl[ROI_MAX_CAND];      // candidate indices < 8192
+  __shared__ int chosen[ROI_MAX_SAMPLES];
+  __shared__ int wsp[16], wsn[16], s_runp, s_runn;
+  const int img = blockIdx.x, gt0 = A.gt_off[img], g = A.gt_off[img + 1] - gt0;
+  const int pc = min(pcount[img], P), c = pc + g;
+  const int* lab = label + (long long)img * C;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  if (threadIdx.x == 0) s_runp = s_runn = 0;
+  __syncthreads();
+  for (int base = 0; base < c; base += 1024) {          // index lists of the positives / negatives in ascending order (torch.where)
+    const int j = base + threadIdx.x;
+    const int l = j < c ? lab[j] : -2;
+    const unsigned long long bp = __ballot(l >= 1), bn = __ballot(l == 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) {
+      wsp[wid] = __popcll(bp);
+      wsn[wid] = __popcll(bn);
+    }
+    __syncthreads();
+    int op = s_runp, on = s_runn;
+    for (int w = 0; w < wid; ++w) op += wsp[w], on += wsn[w];
+    if (l >= 1) posl[op + __popcll(bp & below)] = (unsigned short)j;
+    if (l == 0) negl[on + __popcll(bn & below)] = (unsigned short)j;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int tp = 0, tn = 0;
+      for (int w = 0; w < 16; ++w) tp += wsp[w], tn += wsn[w];
+      s_runp += tp;
+      s_runn += tn;
+    }
+    __syncthreads();
+  }
+  const int np = A.num_pos[img], nn = A.num_neg[img], ns = np + nn;
+  int npad = 64;
+  while (npad < ns) npad <<= 1;
+  for (int q = threadIdx.x; q < npad; q += 1024)
+    chosen[q] = q < np ? (int)posl[A.perm_pos[img][q]] : (q < ns ? (int)negl[A.perm_neg[img][q - np]] : 0x7fffffff);
+  __syncthreads();
+  for (int kk = 2; kk <= npad; kk <<= 1)                 // ascending: the union mask of the reference read back with torch.where
+    for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+      const int q = threadIdx.x, x = q ^ jj;
+      if (q < npad && x > q) {
+        const int a = chosen[q], b = chosen[x];
+        if (((q & kk) == 0) ? a > b : a < b) {
+          chosen[q] = b;
+          chosen[x] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (int q = threadIdx.x; q < ns; q += 1024) {
+    const int j = chosen[q], m = matched[(long long)img * C + j];
+    const float4 p = roi_candidate(props, gt, img, P, pc, gt0, j), r = *(const float4*)(gt + 4 * (long long)(gt0 + m));
+    const long long o = A.out_off[img] + q;
+    rois[5 * o] = (float)img;
+    rois[5 * o + 1] = p.x;
+    rois[5 * o + 2] = p.y;
+    rois[5 * o + 3] = p.z;
+    rois[5 * o + 4] = p.w;
+    out_labels[o] = lab[j];
+    out_matched[o] = m;
+    // BoxCoder.encode_single (tvision/_utils.py:79-125), the operation order of box_encode_kernel
+    const float ew = p.z - p.x, eh = p.w - p.y, ecx = p.x + 0.5f * ew, ecy = p.y + 0.5f * eh;
+    const float gw = r.z - r.x, gh = r.w - r.y, gcx = r.x + 0.5f * gw, gcy = r.y + 0.5f * gh;
+    *(float4*)(out_reg + 4 * o) = make_float4(wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * logf(gw / ew), wh * logf(gh / eh));
+  }
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct ProposalWs {
@@ -193,6 +347,63 @@ int mi355det_rpn_proposals(const float* objectness, const float* deltas, const f
                      (const float*)(ws + W.scores), (const long long*)(ws + W.keep), (const int*)(ws + W.keep_cnt), W.K, post_nms_top_n, out_boxes,
                      out_scores, out_counts);
   return check_launch("rpn_proposals");
+}
+
+int mi355det_roi_match(const float* proposals, const int32_t* proposal_counts, int32_t n_images, int32_t max_proposals, const float* gt_boxes,
+                       const int64_t* gt_labels, const int32_t* gt_offsets, float fg_iou_thresh, float bg_iou_thresh, int32_t row_stride,
+                       int32_t* matched, int32_t* labels, int32_t* counts, void* stream) {
+  if (n_images <= 0 || n_images > ROI_MAX_IMAGES || max_proposals < 0 || !gt_offsets)
+    return fail(MI355DET_EINVAL, "%s: 1..64 images", "roi_match");
+  if (!proposals || !proposal_counts || !gt_boxes || !gt_labels || !matched || !labels || !counts) return fail(MI355DET_EINVAL, "%s: null argument", "roi_match");
+  RoiImages I{};
+  I.n = n_images;
+  int gmax = 0;
+  for (int i = 0; i <= n_images; ++i) I.gt_off[i] = gt_offsets[i];
+  for (int i = 0; i < n_images; ++i) {
+    const int g = gt_offsets[i + 1] - gt_offsets[i];
+    // the reference's Matcher raises on an image without ground truth (tvision/_utils.py:282-291): the Python mirror does that
+    if (g <= 0 || g > ROI_MAX_GT) return fail(MI355DET_EINVAL, "%s: 1..1024 ground-truth boxes per image", "roi_match");
+    gmax = g > gmax ? g : gmax;
+  }
+  if (row_stride < max_proposals + gmax) return fail(MI355DET_EINVAL, "%s: row_stride < max_proposals + ground-truth boxes", "roi_match");
+  if (hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * (size_t)n_images, S(stream)) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: memset failed", "roi_match");
+  hipLaunchKernelGGL(roi_match_kernel, dim3((max_proposals + gmax + 255) / 256, n_images), dim3(256), 0, S(stream), proposals, proposal_counts,
+                     max_proposals, gt_boxes, (const long long*)gt_labels, I, fg_iou_thresh, bg_iou_thresh, row_stride, matched, labels, counts);
+  return check_launch("roi_match");
+}
+
+int mi355det_roi_sample(const float* proposals, const int32_t* proposal_counts, int32_t n_images, int32_t max_proposals, const float* gt_boxes,
+                        const int32_t* gt_offsets, int32_t row_stride, const int32_t* matched, const int32_t* labels,
+                        const int64_t* const* perm_pos, const int64_t* const* perm_neg, const int32_t* num_pos, const int32_t* num_neg, float wx,
+                        float wy, float ww, float wh, float* rois, int64_t* out_labels, int64_t* out_matched, float* out_regression_targets,
+                        void* stream) {
+  if (n_images <= 0 || n_images > ROI_MAX_IMAGES || !gt_offsets || !perm_pos || !perm_neg || !num_pos || !num_neg)
+    return fail(MI355DET_EINVAL, "%s: 1..64 images", "roi_sample");
+  if (!proposals || !proposal_counts || !gt_boxes || !matched || !labels || !rois || !out_labels || !out_matched || !out_regression_targets)
+    return fail(MI355DET_EINVAL, "%s: null argument", "roi_sample");
+  RoiSampleArgs A{};
+  int gmax = 0, total = 0;
+  for (int i = 0; i <= n_images; ++i) A.gt_off[i] = gt_offsets[i];
+  for (int i = 0; i < n_images; ++i) {
+    const int g = gt_offsets[i + 1] - gt_offsets[i];
+    gmax = g > gmax ? g : gmax;
+    if (num_pos[i] < 0 || num_neg[i] < 0 || num_pos[i] + num_neg[i] > ROI_MAX_SAMPLES)
+      return fail(MI355DET_EINVAL, "%s: at most 1024 samples per image", "roi_sample");
+    if ((num_pos[i] && !perm_pos[i]) || (num_neg[i] && !perm_neg[i])) return fail(MI355DET_EINVAL, "%s: missing permutation", "roi_sample");
+    A.out_off[i] = total;
+    A.num_pos[i] = num_pos[i];
+    A.num_neg[i] = num_neg[i];
+    A.perm_pos[i] = (const long long*)perm_pos[i];
+    A.perm_neg[i] = (const long long*)perm_neg[i];
+    total += num_pos[i] + num_neg[i];
+  }
+  A.out_off[n_images] = total;
+  if (max_proposals + gmax > ROI_MAX_CAND || row_stride < max_proposals + gmax)
+    return fail(MI355DET_EINVAL, "%s: at most 8192 candidates (proposals + ground truth) per image", "roi_sample");
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(roi_sample_kernel, dim3(n_images), dim3(1024), 0, S(stream), proposals, proposal_counts, max_proposals, gt_boxes, A, row_stride,
+                     matched, labels, wx, wy, ww, wh, rois, (long long*)out_labels, (long long*)out_matched, out_regression_targets);
+  return check_launch("roi_sample");
 }
 
 }  // extern "C"

@@ -198,7 +198,7 @@ def nms_batch(boxes, scores, iou_threshold, idxs=None):
 
 
 def rpn_proposals(objectness, deltas, anchors, clip_limits, level_counts, pre_nms_top_n, post_nms_top_n, nms_thresh, score_thresh=0.0,
-                  min_size=1e-3, xform_clip=math.log(1000.0 / 16)):
+                  min_size=1e-3, xform_clip=math.log(1000.0 / 16), counts_out=None):
     """RegionProposalNetwork.filter_proposals (rpn.py:215-280) incl. the decode of the selected anchors, whole batch, one host call:
     objectness [N,A] logits, deltas [N,A,4], anchors [A,4], clip_limits [N,4] = (w,h,w,h) -> (boxes [N,post,4], scores [N,post],
     counts [N] int32 on the device; rows beyond counts[i] are zero)."""
@@ -214,11 +214,49 @@ def rpn_proposals(objectness, deltas, anchors, clip_limits, level_counts, pre_nm
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     boxes = torch.empty((n, int(post_nms_top_n), 4), device=dev, dtype=torch.float32)
     scores = torch.empty((n, int(post_nms_top_n)), device=dev, dtype=torch.float32)
-    counts = torch.empty(n, device=dev, dtype=torch.int32)
+    counts = counts_out if counts_out is not None else torch.empty(n, device=dev, dtype=torch.int32)
     check(lib().mi355det_rpn_proposals(ptr(objectness), ptr(deltas), ptr(anchors), ptr(clip_limits), n, lc, len(level_counts), int(pre_nms_top_n),
                                        int(post_nms_top_n), float(nms_thresh), float(score_thresh), float(min_size), float(xform_clip),
                                        ptr(boxes), ptr(scores), ptr(counts), ptr(ws), wsb, stream_ptr()), "rpn_proposals")
     return boxes, scores, counts
+
+
+def roi_match(proposals, proposal_counts, gt_boxes, gt_labels, gt_offsets, fg_iou_thresh, bg_iou_thresh, counts_out=None):
+    """RoIHeads.assign_targets_to_proposals over add_gt_proposals (roi_heads.py:627-652,664-668) for the whole batch, one launch: proposals
+    [N,P,4] padded + proposal_counts [N] i32 on the device, gt_boxes [G,4] / gt_labels [G] concatenated, gt_offsets host list [N+1] ->
+    (matched [N,C] i32, labels [N,C] i32, counts [N,2] i32 = positives / negatives), C = P + the largest ground-truth count."""
+    proposals, gt_boxes = _f32c(proposals), _f32c(gt_boxes)
+    n, p = proposals.shape[0], proposals.shape[1]
+    if len(gt_offsets) != n + 1 or any(b <= a for a, b in zip(gt_offsets, gt_offsets[1:])):
+        raise ValueError("No ground-truth boxes available for one of the images during training")          # Matcher, _utils.py:282-291
+    c = p + max(b - a for a, b in zip(gt_offsets, gt_offsets[1:]))
+    dev = proposals.device
+    matched = torch.empty((n, c), device=dev, dtype=torch.int32)
+    labels = torch.empty((n, c), device=dev, dtype=torch.int32)
+    counts = counts_out if counts_out is not None else torch.empty((n, 2), device=dev, dtype=torch.int32)
+    offs = (C.c_int32 * (n + 1))(*[int(v) for v in gt_offsets])
+    check(lib().mi355det_roi_match(ptr(proposals), ptr(proposal_counts), n, p, ptr(gt_boxes), ptr(gt_labels.to(torch.int64).contiguous()), offs,
+                                   float(fg_iou_thresh), float(bg_iou_thresh), c, ptr(matched), ptr(labels), ptr(counts), stream_ptr()), "roi_match")
+    return matched, labels, counts
+
+
+def roi_sample(proposals, proposal_counts, gt_boxes, gt_offsets, matched, labels, perm_pos, perm_neg, num_pos, num_neg, weights):
+    """BalancedPositiveNegativeSampler's selection from its `randperm` draws + the gathers and BoxCoder.encode of select_training_samples
+    (roi_heads.py:654-713), whole batch, one launch -> (rois [S,5], labels [S] i64, matched [S] i64, regression_targets [S,4])."""
+    n, p = proposals.shape[0], proposals.shape[1]
+    total = int(sum(num_pos) + sum(num_neg))
+    dev = proposals.device
+    rois = torch.empty((total, 5), device=dev, dtype=torch.float32)
+    out_l = torch.empty(total, device=dev, dtype=torch.int64)
+    out_m = torch.empty(total, device=dev, dtype=torch.int64)
+    reg = torch.empty((total, 4), device=dev, dtype=torch.float32)
+    vpa, i32a = C.c_void_p * n, C.c_int32 * n
+    offs = (C.c_int32 * (n + 1))(*[int(v) for v in gt_offsets])
+    check(lib().mi355det_roi_sample(ptr(proposals), ptr(proposal_counts), n, p, ptr(gt_boxes), offs, matched.shape[1], ptr(matched), ptr(labels),
+                                    vpa(*[ptr(t) for t in perm_pos]), vpa(*[ptr(t) for t in perm_neg]), i32a(*[int(v) for v in num_pos]),
+                                    i32a(*[int(v) for v in num_neg]), *[float(w) for w in weights], ptr(rois), ptr(out_l), ptr(out_m), ptr(reg),
+                                    stream_ptr()), "roi_sample")
+    return rois, out_l, out_m, reg
 
 
 def nms(boxes, scores, iou_threshold, idxs=None):

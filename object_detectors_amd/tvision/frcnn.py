@@ -35,6 +35,7 @@ from .transform import GeneralizedRCNNTransform
 
 
 _RPN_FUSED = os.environ.get("MI355DET_RPN_FUSED", "1") != "0"      # 0: box_decode of every anchor + the torch-composed filter (A/B, tests)
+_ROI_FUSED = os.environ.get("MI355DET_ROI_FUSED", "1") != "0"      # 0: the per-image torch-composed select_training_samples
 
 
 class TwoMLPHead(nn.Module):
@@ -131,14 +132,15 @@ class FasterRCNN(nn.Module):
                                             if k.startswith("roi_heads.box_predictor.")})
 
     # ------------------------------------------------------------------
-    def _proposals(self, out, plan, image_shapes):
-        """rpn.py:336-351: decode every anchor with the (detached) deltas, then filter_proposals."""
+    def _proposals(self, out, plan, image_shapes, counts_out=None):
+        """rpn.py:336-351: decode every anchor with the (detached) deltas, then filter_proposals.  With `counts_out` (int32 [N] on the
+        device) the padded form [N, post, 4] comes back and nothing is read by the host."""
         n = out["cls_logits"].shape[0]
         mode = "training" if self.training else "testing"
         if _RPN_FUSED:
             return rpn_proposals_fused(out["bbox_regression"], out["cls_logits"], plan.anchors, image_shapes, plan.level_rows, self.rpn_pre[mode],
                                        self.rpn_post[mode], self.rpn_nms_thresh, self.rpn_score_thresh,
-                                       xform_clip=self.rpn_coder.bbox_xform_clip)
+                                       xform_clip=self.rpn_coder.bbox_xform_clip, counts_out=counts_out)
         deltas = out["bbox_regression"].detach().reshape(-1, 4)
         anchors = plan.anchors.repeat(n, 1)
         proposals = ops.box_decode(deltas, anchors, (1.0, 1.0, 1.0, 1.0), self.rpn_coder.bbox_xform_clip).reshape(n, -1, 4)
@@ -183,7 +185,12 @@ class FasterRCNN(nn.Module):
             assert plan is plan0
             with torch.cuda.stream(self._tgt_stream):
                 rpn_side = self.rpn_targets.prepare([plan.anchors] * n, targets)
-        boxes, _scores = self._proposals(out, plan, image_shapes)
+        fused = self.training and _RPN_FUSED and _ROI_FUSED and self.roi_targets.fused_ok(n, self.rpn_post["training"], targets)
+        if fused:     # proposals stay padded on the device; their counts are read together with the sampler's counts (one host read in all)
+            meta = torch.empty(3 * n, device=images.device, dtype=torch.int32)
+            boxes, _scores = self._proposals(out, plan, image_shapes, counts_out=meta[:n])
+        else:
+            boxes, _scores = self._proposals(out, plan, image_shapes)
         feats = self.engine.feature_maps_nhwc(4)       # the engine's bf16 NHWC buffers themselves
         if not self.training:
             with torch.no_grad():
@@ -195,18 +202,23 @@ class FasterRCNN(nn.Module):
             if original_image_sizes is not None:
                 det = self.transform.postprocess(det, image_shapes, original_image_sizes)      # generalized_rcnn.py:110
             return det
-        # ---- training: RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient)
-        obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
-        dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
-        torch.cuda.current_stream(images.device).wait_stream(self._tgt_stream)
-        rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
         # ---- RoI heads (roi_heads.py:783-848): sample, pool, two FC layers, predictor, Fast R-CNN loss
-        proposals, _mi, labels, reg_targets = self.roi_targets.select_training_samples([b.detach() for b in boxes], targets)
+        if fused:
+            proposals, _mi, labels, reg_targets, _per_image = self.roi_targets.select_training_samples_fused(boxes, meta, targets)
+            labels, reg_targets = [labels], [reg_targets]
+        else:
+            proposals, _mi, labels, reg_targets = self.roi_targets.select_training_samples([b.detach() for b in boxes], targets)
         x = self.box_roi_pool.forward_nhwc(feats, proposals, image_shapes)
         cls, reg = self.box_predictor(self.box_head(x))
         # roi_heads.py:826-827: fastrcnn_loss(self.tfidf * class_logits, ..., weights=self.classification_weights, loss_type=...)
         loss_cls, loss_box = fastrcnn_loss(cls, reg, labels, reg_targets, weights=self.classification_weights, loss_type=self.loss_function_name,
                                            class_scale=self.tfidf)
+        # ---- RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient).  Issued AFTER the RoI branch:
+        # they do not feed it, and their host time then hides behind the RoI kernels instead of sitting in front of them with the device idle
+        obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
+        dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
+        torch.cuda.current_stream(images.device).wait_stream(self._tgt_stream)
+        rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
         losses = {"loss_classifier": loss_cls, "loss_box_reg": loss_box}
         losses.update(rpn_losses)
         sum(losses.values()).backward()

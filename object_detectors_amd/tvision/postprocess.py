@@ -71,7 +71,7 @@ def rpn_filter_proposals(proposals, objectness, image_shapes, num_anchors_per_le
 
 
 def rpn_proposals_fused(deltas, objectness, anchors, image_shapes, num_anchors_per_level, pre_nms_top_n, post_nms_top_n, nms_thresh=0.7,
-                        score_thresh=0.0, min_size=1e-3, xform_clip=math.log(1000.0 / 16)):
+                        score_thresh=0.0, min_size=1e-3, xform_clip=math.log(1000.0 / 16), counts_out=None):
     """rpn.py:336-351 + filter_proposals (:215-280) from the RAW deltas [N, A, 4] and logits [N, A] in one host call
     (`mi355det_rpn_proposals`: only the selected anchors are decoded) and one device-to-host read; same results as
     `ops.box_decode` + `rpn_filter_proposals`, bit for bit (tests/test_gpu_proposals.py).  -> (list of boxes [<=post,4], list of scores)."""
@@ -79,7 +79,9 @@ def rpn_proposals_fused(deltas, objectness, anchors, image_shapes, num_anchors_p
     lim = _clip_limits(image_shapes, objectness.device, torch.float32).reshape(n, 4)
     boxes, scores, counts = ops.rpn_proposals(objectness.detach().reshape(n, -1), deltas.detach().reshape(n, -1, 4), anchors, lim,
                                               list(num_anchors_per_level), pre_nms_top_n, post_nms_top_n, nms_thresh, score_thresh, min_size,
-                                              xform_clip)
+                                              xform_clip, counts_out=counts_out)
+    if counts_out is not None:              # padded form: (boxes [N, post, 4], scores [N, post]); the caller reads counts_out when it needs to
+        return boxes, scores
     counts = counts.tolist()                                                  # the one synchronisation of the proposal filter
     return [boxes[i, :c] for i, c in enumerate(counts)], [scores[i, :c] for i, c in enumerate(counts)]
 

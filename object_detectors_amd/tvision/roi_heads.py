@@ -87,6 +87,45 @@ class RoIHeadTargets:
     def add_gt_proposals(proposals, gt_boxes):
         return [torch.cat((p, g)) for p, g in zip(proposals, gt_boxes)]
 
+    # limits of mi355det_roi_match / mi355det_roi_sample (include/mi355det.h); beyond them the composed route below is used
+    FUSED_MAX_IMAGES, FUSED_MAX_GT, FUSED_MAX_CANDIDATES, FUSED_MAX_SAMPLES = 64, 1024, 8192, 1024
+
+    def fused_ok(self, n_images, max_proposals, targets):
+        g = [int(t["boxes"].shape[0]) for t in targets]
+        return (n_images <= self.FUSED_MAX_IMAGES and min(g) >= 1 and max(g) <= self.FUSED_MAX_GT
+                and max_proposals + max(g) <= self.FUSED_MAX_CANDIDATES and self.fg_bg_sampler.batch_size_per_image <= self.FUSED_MAX_SAMPLES)
+
+    def select_training_samples_fused(self, proposals_pad, meta, targets):
+        """select_training_samples (roi_heads.py:664-713) on the padded proposals [N, P, 4] of `ops.rpn_proposals`, whose counts sit in
+        meta[:N] (int32 [3N] on the device; meta[N:] receives the positive / negative counts): two launches around ONE host read - which
+        is also the read of the proposal counts.  `torch.randperm` is called with the reference's sizes in the reference's order
+        (_utils.py:38-73), so the samples are those of the composed route under the same generator state (tests/test_gpu_proposals.py).
+        -> (rois [S,5], matched_idxs [S], labels [S], regression_targets [S,4], samples per image)."""
+        n = proposals_pad.shape[0]
+        dev = proposals_pad.device
+        gt_boxes = [t["boxes"].to(torch.float32) for t in targets]
+        offs = [0]
+        for g in gt_boxes:
+            offs.append(offs[-1] + int(g.shape[0]))
+        gt_all = torch.cat(gt_boxes)
+        gl_all = torch.cat([t["labels"] for t in targets])
+        m = self.proposal_matcher
+        matched, labels, _ = ops.roi_match(proposals_pad, meta[:n], gt_all, gl_all, offs, m.high_threshold, m.low_threshold,
+                                           counts_out=meta[n:].view(n, 2))
+        host = meta.tolist()                                  # the one synchronisation of proposals + sampling
+        bs, frac = self.fg_bg_sampler.batch_size_per_image, self.fg_bg_sampler.positive_fraction
+        perm_pos, perm_neg, num_pos, num_neg = [], [], [], []
+        for i in range(n):
+            cp, cn = host[n + 2 * i], host[n + 2 * i + 1]
+            npos = min(cp, int(bs * frac))
+            num_pos.append(npos)
+            num_neg.append(min(cn, bs - npos))
+            perm_pos.append(torch.randperm(cp, device=dev))
+            perm_neg.append(torch.randperm(cn, device=dev))
+        rois, out_l, out_m, reg = ops.roi_sample(proposals_pad, meta[:n], gt_all, offs, matched, labels, perm_pos, perm_neg, num_pos, num_neg,
+                                                 self.box_coder.weights)
+        return rois, out_m, out_l, reg, [a + b for a, b in zip(num_pos, num_neg)]
+
     def select_training_samples(self, proposals, targets):
         assert targets is not None and all("boxes" in t and "labels" in t for t in targets)
         dtype = proposals[0].dtype

@@ -105,3 +105,43 @@ def test_topk_segments_degenerate_rows_and_threshold():
             c = int(cnt[r])
             assert torch.equal(idx[r, :c], ri[r, :c]) and torch.equal(val[r, :c], rv[r, :c])
         off += n
+
+
+@pytest.mark.parametrize("n,post,gts", [(4, 2000, [3, 1, 17, 6]), (2, 300, [40, 2]), (1, 64, [5])])
+def test_select_training_samples_fused_matches_composed_route(n, post, gts):
+    """mi355det_roi_match + mi355det_roi_sample against the per-image torch-composed RoIHeadTargets.select_training_samples
+    (roi_heads.py:664-713) under the same generator state: same samples in the same order, bit-equal targets."""
+    from object_detectors_amd.tvision.roi_heads import RoIHeadTargets
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11 + n)
+    targets, boxes, counts = [], [], []
+    pad = torch.zeros((n, post, 4), device=dev)
+    for i in range(n):
+        c = torch.rand((gts[i], 2), device=dev, generator=g) * 600 + 100
+        wh = torch.rand((gts[i], 2), device=dev, generator=g) * 200 + 20
+        gt = torch.cat([c - wh / 2, c + wh / 2], 1)
+        targets.append({"boxes": gt, "labels": torch.randint(1, 91, (gts[i],), device=dev, generator=g)})
+        cnt = post - 7 * i                                                   # ragged proposal counts
+        # proposals: jittered copies of the ground truth (positives), boxes elsewhere (negatives), a few between the thresholds
+        src = gt[torch.randint(0, gts[i], (cnt,), device=dev, generator=g)]
+        jit = torch.randn((cnt, 4), device=dev, generator=g) * torch.rand((cnt, 1), device=dev, generator=g) * 60
+        p = src + jit
+        p = torch.cat([torch.minimum(p[:, :2], p[:, 2:] - 1), torch.maximum(p[:, 2:], p[:, :2] + 1)], 1).clamp(0, 800)
+        boxes.append(p)
+        pad[i, :cnt] = p
+        counts.append(cnt)
+    tg = RoIHeadTargets()
+    assert tg.fused_ok(n, post, targets)
+    torch.manual_seed(1234)
+    r_props, r_mi, r_lab, r_reg = tg.select_training_samples([b.clone() for b in boxes], targets)
+    meta = torch.zeros(3 * n, device=dev, dtype=torch.int32)
+    meta[:n] = torch.tensor(counts, dtype=torch.int32)
+    torch.manual_seed(1234)
+    rois, mi, lab, reg, per_image = tg.select_training_samples_fused(pad, meta, targets)
+    assert per_image == [int(p.shape[0]) for p in r_props] and sum(per_image) == rois.shape[0]
+    assert (torch.cat(r_lab) >= 1).any() and (torch.cat(r_lab) == 0).any()
+    ids = torch.cat([torch.full((k,), float(i), device=dev) for i, k in enumerate(per_image)])
+    assert torch.equal(rois[:, 0], ids)
+    assert torch.equal(rois[:, 1:], torch.cat(r_props))
+    assert torch.equal(mi, torch.cat(r_mi)) and torch.equal(lab, torch.cat(r_lab))
+    assert torch.equal(reg, torch.cat(r_reg)), (reg - torch.cat(r_reg)).abs().max()
