@@ -208,3 +208,32 @@ def test_topk_long_rows_multi_workgroup():
             assert cnt[r] == want.size, (x.shape, k, r, cnt[r], want.size)
             assert np.array_equal(idx[r, :cnt[r]], want), (x.shape, k, r)
             assert np.array_equal(val[r, :cnt[r]], x[r][want])
+
+
+@pytest.mark.parametrize("sampling,aligned", [(2, False), (2, True), (0, False), (3, True)])
+def test_roi_align_separable_edge_cases(sampling, aligned):
+    """The separable 7x7 form of mi355det_roi_align_nhwc (footprint weights per axis) against the per-sample NCHW kernel (pinned by the
+    oracle above) on boxes that leave the map, degenerate boxes, whole-image and very elongated boxes; forward and backward; 300 channels
+    (more than one pass of the channel loop)."""
+    from object_detectors_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(4 + sampling)
+    n, c = 2, 300
+    sizes, scales = [(50, 68), (25, 34), (13, 17), (7, 9)], [0.25, 0.125, 0.0625, 0.03125]
+    feats = [torch.randn((n, c, h, w), device=dev, generator=g).bfloat16().float() for h, w in sizes]
+    feats_cl = [f.permute(0, 2, 3, 1).contiguous().bfloat16() for f in feats]
+    special = torch.tensor([[-40.0, -30.0, 20.0, 25.0], [250.0, 180.0, 330.0, 260.0], [100.0, 100.0, 100.0, 100.0], [0.0, 0.0, 272.0, 200.0],
+                            [5.0, 90.0, 270.0, 96.0], [130.0, 2.0, 134.0, 198.0], [300.0, 300.0, 400.0, 400.0], [-500.0, -500.0, -400.0, -450.0],
+                            [10.0, 10.0, 11.5, 12.0], [60.0, 40.0, 200.0, 190.0]], device=dev)
+    tl = torch.rand((50, 2), device=dev, generator=g) * torch.tensor([220.0, 160.0], device=dev)
+    wh = torch.rand((50, 2), device=dev, generator=g) ** 2 * 200 + 1
+    boxes = torch.cat([special, torch.cat([tl, tl + wh], 1)])
+    rois = torch.cat([(torch.arange(boxes.shape[0], device=dev) % n).float()[:, None], boxes], 1)
+    ya = ops.roi_align_multi(feats, rois, 7, scales, sampling, aligned, 2, 5)
+    yb = ops.roi_align_nhwc(feats_cl, rois, 7, scales, sampling, aligned, 2, 5)
+    torch.testing.assert_close(yb, ya, rtol=1e-5, atol=2e-5)
+    go = torch.randn(ya.shape, device=dev, generator=g)
+    da = ops.roi_align_multi(feats, rois, 7, scales, sampling, aligned, 2, 5, grad_out=go)
+    db = ops.roi_align_nhwc(feats_cl, rois, 7, scales, sampling, aligned, 2, 5, grad_out=go)
+    for a, b_ in zip(da, db):
+        torch.testing.assert_close(b_, a.permute(0, 2, 3, 1), rtol=1e-4, atol=1e-4)
