@@ -353,10 +353,20 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(LevelsCL L, int num_
         } else {
 #pragma unroll
           for (int j = 0; j < RSEP_BINS; ++j) t[j] = 0.f;
-          for (int x = 0; x < FW; ++x) {
-            if (!touched[1][x]) continue;
+          // untouched columns carry zero weights: no test, so that the loads of four columns are in flight together
+          const bf16_t* fr = f + row * ld + c;
+          int x = 0;
+          for (; x + 3 < FW; x += 4) {
+            const float v0 = bf2f(fr[(size_t)x * ld]), v1 = bf2f(fr[(size_t)(x + 1) * ld]), v2 = bf2f(fr[(size_t)(x + 2) * ld]),
+                        v3 = bf2f(fr[(size_t)(x + 3) * ld]);
             const float* ax = &A[1][x * RSEP_BINS];
-            const float v = bf2f(f[(row + x) * ld + c]);
+#pragma unroll
+            for (int j = 0; j < RSEP_BINS; ++j)
+              t[j] += ax[j] * v0 + ax[RSEP_BINS + j] * v1 + ax[2 * RSEP_BINS + j] * v2 + ax[3 * RSEP_BINS + j] * v3;
+          }
+          for (; x < FW; ++x) {
+            const float* ax = &A[1][x * RSEP_BINS];
+            const float v = bf2f(fr[(size_t)x * ld]);
 #pragma unroll
             for (int j = 0; j < RSEP_BINS; ++j) t[j] += ax[j] * v;
           }

@@ -46,21 +46,24 @@ for _ in range(R):
     self.engine.normalize = True
     out = sec("1 engine forward (body+FPN+RPN head)", lambda: self.engine.forward(imgs, training=True))
     plan = self.engine._last_plan
-    boxes, _s = sec("2 proposals (decode, top-k, NMS)", lambda: self._proposals(out, plan, image_shapes))
+    rpn_side = sec("2 RPN targets (match, sampler, encode; model: side stream under 1)", lambda: self.rpn_targets.prepare([plan.anchors] * n, targets))
+    meta = torch.empty(3 * n, device=dev, dtype=torch.int32)
+    boxes, _s = sec("3 proposals (top-k, decode, NMS; no host read)", lambda: self._proposals(out, plan, image_shapes, counts_out=meta[:n]))
     feats = self.engine.feature_maps_nhwc(4)
+    proposals, _mi, labels, reg_targets, _pi = sec("4 RoI sampling (roi_match, ONE host read, randperm, roi_sample)",
+                                                   lambda: self.roi_targets.select_training_samples_fused(boxes, meta, targets))
+    x = sec("5 RoIAlign forward", lambda: self.box_roi_pool.forward_nhwc(feats, proposals, image_shapes))
+    cls, reg = sec("6 box head forward (2 FC + predictor)", lambda: self.box_predictor(self.box_head(x)))
+    lc, lb = sec("7 fastrcnn_loss", lambda: fastrcnn_loss(cls, reg, [labels], [reg_targets], weights=self.classification_weights, loss_type=self.loss_function_name, class_scale=self.tfidf))
     def rpnl():
         obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
         dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
-        return obj, dl, self.rpn_targets.losses(obj, dl, [plan.anchors] * n, targets)
-    obj, dl, rpn_losses = sec("3 RPN targets + losses", rpnl)
-    proposals, _mi, labels, reg_targets = sec("4 RoI sampling (match, sampler, encode)", lambda: self.roi_targets.select_training_samples([b.detach() for b in boxes], targets))
-    x = sec("5 RoIAlign forward", lambda: self.box_roi_pool.forward_nhwc(feats, proposals, image_shapes))
-    cls, reg = sec("6 box head forward (2 FC + predictor)", lambda: self.box_predictor(self.box_head(x)))
-    lc, lb = sec("7 fastrcnn_loss", lambda: fastrcnn_loss(cls, reg, labels, reg_targets, weights=self.classification_weights, loss_type=self.loss_function_name, class_scale=self.tfidf))
+        return obj, dl, self.rpn_targets.losses_prepared(obj, dl, rpn_side)
+    obj, dl, rpn_losses = sec("8 RPN losses", rpnl)
     losses = {"loss_classifier": lc, "loss_box_reg": lb}; losses.update(rpn_losses)
-    sec("8 torch backward (losses, head, RoIAlign)", lambda: sum(losses.values()).backward())
-    sec("9 engine backward", lambda: self.engine.backward(obj.grad, dl.grad, [f.grad for f in feats]))
-    sec("10 optimizers", lambda: (opt.step(), opt_head.step()))
+    sec("9 torch backward (losses, head, RoIAlign)", lambda: sum(losses.values()).backward())
+    sec("10 engine backward", lambda: self.engine.backward(obj.grad, dl.grad, [f.grad for f in feats]))
+    sec("11 optimizers", lambda: (opt.step(), opt_head.step()))
 tot_h = sum(a[0] for a in acc.values()); tot_s = sum(a[1] for a in acc.values())
 print(f"Faster R-CNN R50-FPN training step, bs {bs}, 800 px: per-section time over {R} steps (each section followed by a synchronise)\n")
 print("| section | host issue ms | host+device ms |\n|---|---|---|")
