@@ -36,6 +36,7 @@ from .transform import GeneralizedRCNNTransform
 
 _RPN_FUSED = os.environ.get("MI355DET_RPN_FUSED", "1") != "0"      # 0: box_decode of every anchor + the torch-composed filter (A/B, tests)
 _ROI_FUSED = os.environ.get("MI355DET_ROI_FUSED", "1") != "0"      # 0: the per-image torch-composed select_training_samples
+_RPN_LOSS_SIDE = os.environ.get("MI355DET_RPN_LOSS_SIDE", "0") != "0"      # 1: RPN losses on the target stream beside the proposal kernels (A/B: no gain)
 
 
 class TwoMLPHead(nn.Module):
@@ -181,10 +182,20 @@ class FasterRCNN(nn.Module):
             self._tgt_stream.wait_stream(cur)
         out = self.engine.forward(images, training=self.training)
         plan = self.engine._last_plan
+        rpn_losses = None
         if self.training:
             assert plan is plan0
+            fwd_done = torch.cuda.Event()
+            fwd_done.record(cur)
             with torch.cuda.stream(self._tgt_stream):
                 rpn_side = self.rpn_targets.prepare([plan.anchors] * n, targets)
+                if _RPN_LOSS_SIDE:
+                    # the RPN losses too (leaf copies of the engine's outputs: their .grad is the engine's head gradient): ~10 small
+                    # launches that need the forward's outputs but not the RoI branch - beside the proposal kernels instead of behind them
+                    self._tgt_stream.wait_event(fwd_done)
+                    obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
+                    dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
+                    rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
         fused = self.training and _RPN_FUSED and _ROI_FUSED and self.roi_targets.fused_ok(n, self.rpn_post["training"], targets)
         if fused:     # proposals stay padded on the device; their counts are read together with the sampler's counts (one host read in all)
             meta = torch.empty(3 * n, device=images.device, dtype=torch.int32)
@@ -215,10 +226,11 @@ class FasterRCNN(nn.Module):
                                            class_scale=self.tfidf)
         # ---- RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient).  Issued AFTER the RoI branch:
         # they do not feed it, and their host time then hides behind the RoI kernels instead of sitting in front of them with the device idle
-        obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
-        dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
         torch.cuda.current_stream(images.device).wait_stream(self._tgt_stream)
-        rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
+        if rpn_losses is None:
+            obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
+            dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
+            rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
         losses = {"loss_classifier": loss_cls, "loss_box_reg": loss_box}
         losses.update(rpn_losses)
         sum(losses.values()).backward()
