@@ -166,6 +166,20 @@ int mi355det_rpn_proposals(const float* objectness, const float* deltas, const f
                            float score_thresh, float min_size, float xform_clip, float* out_boxes, float* out_scores, int32_t* out_counts,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* RetinaNet.postprocess_detections for the whole batch in one call (tvision/retinanet.py:414-472): per level the scores above the threshold
+ * (logit_thresh = logit of score_thresh: sigmoid is monotone), of those the topk_candidates best of the flattened [HWA_l x K] scores of
+ * every image, decode of their anchors (BoxCoder weights 1), clip to clip_limits[img] = (w, h, w, h), per-class NMS, the first
+ * detections_per_img survivors.  HOST tables per level: cls_logits[l] [N, HWA_l, K] fp32 (already scaled by the tf-idf row if any),
+ * bbox_regression[l] [N, HWA_l, 4], anchors[l] [HWA_l, 4], level_anchors[l] = HWA_l.  Outputs: out_boxes [N, det, 4], out_scores [N, det],
+ * out_labels [N, det] int64, out_counts [N] int32 on the device; rows beyond out_counts[img] are zero.  The same results as
+ * mi355det_topk_ws + mi355det_box_decode + clip + mi355det_nms_batch.  Workspace: mi355det_retina_detections_workspace (0 = bad arguments). */
+size_t mi355det_retina_detections_workspace(int32_t n_images, const int64_t* level_anchors, int32_t nlev, int32_t num_classes, int32_t topk_candidates);
+int mi355det_retina_detections(const float* const* cls_logits, const float* const* bbox_regression, const float* const* anchors,
+                               const int64_t* level_anchors, int32_t nlev, int32_t n_images, int32_t num_classes, const float* clip_limits,
+                               float logit_thresh, int32_t topk_candidates, float nms_thresh, int32_t detections_per_img, float xform_clip,
+                               float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_counts, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* RoIHeads.select_training_samples for the whole batch (tvision/roi_heads.py:627-713), the two launches around the one host read its
  * sampler needs.  Candidates of image i are its proposals (proposals [N, max_proposals, 4] padded, proposal_counts [N] on the device, as
  * mi355det_rpn_proposals leaves them) followed by its ground truth (add_gt_proposals): gt_boxes [G,4] / gt_labels [G] of all images

@@ -294,6 +294,138 @@ int proposal_layout(int n_images, const int64_t* level_counts, int nlev, int pre
   return 0;
 }
 
+// ---- RetinaNet.postprocess_detections for the whole batch (tvision/retinanet.py:414-472) ------------------------------------------------
+// per level: thresholded top-k over the flattened [HWA x K] scores of every image (mi355det_topk_ws), then ONE kernel for all levels:
+// anchor / class from the flat index, decode + clip of the selected anchors, sigmoid; per-class NMS of all images side by side; the first
+// detections_per_img survivors gathered.  Candidates a level could not fill (fewer than k scores above the threshold) are masked entries.
+struct RetinaLevels {
+  int nlev, num_classes;
+  int k[MAX_LEVELS], koff[MAX_LEVELS + 1];
+  long long hwa[MAX_LEVELS];
+  long long idx_off[MAX_LEVELS], val_off[MAX_LEVELS], cnt_off[MAX_LEVELS];
+  const float* reg[MAX_LEVELS];        // [N, HWA_l, 4]
+  const float* anchors[MAX_LEVELS];    // [HWA_l, 4]
+};
+
+__global__ __launch_bounds__(256) void retina_select_kernel(const char* __restrict__ ws, RetinaLevels L, const float* __restrict__ lim, int n_images,
+                                                            float xform_clip, float* __restrict__ boxes, float* __restrict__ masked,
+                                                            float* __restrict__ scores, long long* __restrict__ labels) {
+  const int K = L.koff[L.nlev];
+  const long long total = (long long)n_images * K;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int img = (int)(t / K), j = (int)(t - (long long)img * K);
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_LEVELS; ++q)
+      if (q < L.nlev && j >= L.koff[q]) l = q;
+    const int jj = j - L.koff[l], kl = L.k[l];
+    if (jj >= ((const int*)(ws + L.cnt_off[l]))[img]) {
+      *(float4*)(boxes + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+      scores[t] = 0.f;
+      masked[t] = -INFINITY;
+      labels[t] = 0;
+      continue;
+    }
+    const long long flat = ((const long long*)(ws + L.idx_off[l]))[(long long)img * kl + jj];
+    const float logit = ((const float*)(ws + L.val_off[l]))[(long long)img * kl + jj];
+    const long long a = flat / L.num_classes;
+    const int cls = (int)(flat - a * L.num_classes);
+    const float4 b = *(const float4*)(L.anchors[l] + 4 * a), c = *(const float4*)(L.reg[l] + 4 * ((long long)img * L.hwa[l] + a));
+    const float w = b.z - b.x, h = b.w - b.y, cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+    const float dw = fminf(c.z, xform_clip), dh = fminf(c.w, xform_clip);
+    const float pcx = c.x * w + cx, pcy = c.y * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+    float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+    const float4 m = *(const float4*)(lim + 4 * img);
+    o.x = fminf(fmaxf(o.x, 0.f), m.x);
+    o.y = fminf(fmaxf(o.y, 0.f), m.y);
+    o.z = fminf(fmaxf(o.z, 0.f), m.z);
+    o.w = fminf(fmaxf(o.w, 0.f), m.w);
+    const float sc = 1.0f / (1.0f + expf(-logit));
+    *(float4*)(boxes + 4 * t) = o;
+    scores[t] = sc;
+    masked[t] = sc;
+    labels[t] = cls;
+  }
+}
+
+__global__ __launch_bounds__(256) void retina_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ masked,
+                                                            const float* __restrict__ scores, const long long* __restrict__ labels,
+                                                            const long long* __restrict__ keep, const int* __restrict__ keep_cnt, int K, int post,
+                                                            float* __restrict__ out_boxes, float* __restrict__ out_scores,
+                                                            long long* __restrict__ out_labels, int* __restrict__ out_counts) {
+  __shared__ int s_cnt;
+  const int img = blockIdx.x;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int kc = min(keep_cnt[img], K);
+  const long long* kp = keep + (long long)img * K;
+  int mine = 0;
+  for (int j = threadIdx.x; j < kc; j += blockDim.x) mine += masked[(long long)img * K + kp[j]] > -INFINITY ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, WAVE);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && mine) atomicAdd(&s_cnt, mine);
+  __syncthreads();
+  const int cnt = min(s_cnt, post);
+  if (threadIdx.x == 0) out_counts[img] = cnt;
+  for (int j = threadIdx.x; j < post; j += blockDim.x) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc = 0.f;
+    long long lb = 0;
+    if (j < cnt) {
+      const long long src = (long long)img * K + kp[j];
+      b = *(const float4*)(boxes + 4 * src);
+      sc = scores[src];
+      lb = labels[src];
+    }
+    *(float4*)(out_boxes + 4 * ((long long)img * post + j)) = b;
+    out_scores[(long long)img * post + j] = sc;
+    out_labels[(long long)img * post + j] = lb;
+  }
+}
+
+struct RetinaWs {
+  RetinaLevels L;
+  int K;
+  size_t topk_ws, boxes, masked, scores, labels, keep, keep_cnt, nms_ws, total;
+};
+
+int retina_layout(int n_images, const int64_t* level_anchors, int nlev, int num_classes, int topk, RetinaWs& W) {
+  if (n_images <= 0 || nlev <= 0 || nlev > MAX_LEVELS || num_classes <= 0 || topk <= 0 || topk > 16384 || !level_anchors) return 1;
+  size_t off = 0;
+  W.L.nlev = nlev;
+  W.L.num_classes = num_classes;
+  W.L.koff[0] = 0;
+  for (int l = 0; l < nlev; ++l) {
+    const long long n = level_anchors[l] * (long long)num_classes;
+    if (level_anchors[l] <= 0 || n >= (1ll << 32)) return 1;
+    const int k = (int)(n < topk ? n : topk);
+    W.L.k[l] = k;
+    W.L.hwa[l] = level_anchors[l];
+    W.L.koff[l + 1] = W.L.koff[l] + k;
+    W.L.idx_off[l] = (long long)off;
+    off = align256(off + (size_t)n_images * k * sizeof(int64_t));
+    W.L.val_off[l] = (long long)off;
+    off = align256(off + (size_t)n_images * k * sizeof(float));
+    W.L.cnt_off[l] = (long long)off;
+    off = align256(off + (size_t)n_images * sizeof(int32_t));
+  }
+  for (int l = nlev; l < MAX_LEVELS; ++l) {
+    W.L.k[l] = 0, W.L.hwa[l] = 0, W.L.koff[l + 1] = W.L.koff[nlev], W.L.idx_off[l] = W.L.val_off[l] = W.L.cnt_off[l] = 0;
+    W.L.reg[l] = W.L.anchors[l] = nullptr;
+  }
+  W.K = W.L.koff[nlev];
+  const size_t NK = (size_t)n_images * W.K;
+  W.topk_ws = off, off = align256(off + mi355det_topk_workspace(n_images));
+  W.boxes = off, off = align256(off + NK * 4 * sizeof(float));
+  W.masked = off, off = align256(off + NK * sizeof(float));
+  W.scores = off, off = align256(off + NK * sizeof(float));
+  W.labels = off, off = align256(off + NK * sizeof(int64_t));
+  W.keep = off, off = align256(off + NK * sizeof(int64_t));
+  W.keep_cnt = off, off = align256(off + sizeof(int32_t) * (size_t)n_images);
+  W.nms_ws = off, off = align256(off + mi355det_nms_workspace(n_images, W.K));
+  W.total = off;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -404,6 +536,46 @@ int mi355det_roi_sample(const float* proposals, const int32_t* proposal_counts, 
   hipLaunchKernelGGL(roi_sample_kernel, dim3(n_images), dim3(1024), 0, S(stream), proposals, proposal_counts, max_proposals, gt_boxes, A, row_stride,
                      matched, labels, wx, wy, ww, wh, rois, (long long*)out_labels, (long long*)out_matched, out_regression_targets);
   return check_launch("roi_sample");
+}
+
+size_t mi355det_retina_detections_workspace(int32_t n_images, const int64_t* level_anchors, int32_t nlev, int32_t num_classes, int32_t topk_candidates) {
+  RetinaWs W;
+  if (retina_layout(n_images, level_anchors, nlev, num_classes, topk_candidates, W)) return 0;
+  return W.total;
+}
+
+int mi355det_retina_detections(const float* const* cls_logits, const float* const* bbox_regression, const float* const* anchors,
+                               const int64_t* level_anchors, int32_t nlev, int32_t n_images, int32_t num_classes, const float* clip_limits,
+                               float logit_thresh, int32_t topk_candidates, float nms_thresh, int32_t detections_per_img, float xform_clip,
+                               float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_counts, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  RetinaWs W;
+  if (retina_layout(n_images, level_anchors, nlev, num_classes, topk_candidates, W))
+    return fail(MI355DET_EINVAL, "%s: need 1..8 levels with fewer than 2^32 scores per image, 1 <= topk_candidates <= 16384", "retina_detections");
+  if (detections_per_img <= 0 || !cls_logits || !bbox_regression || !anchors || !clip_limits || !out_boxes || !out_scores || !out_labels || !out_counts ||
+      !workspace)
+    return fail(MI355DET_EINVAL, "%s: null argument or detections_per_img <= 0", "retina_detections");
+  if (workspace_bytes < W.total) return fail(MI355DET_EWORKSPACE, "%s: workspace too small", "retina_detections");
+  char* ws = (char*)workspace;
+  for (int l = 0; l < nlev; ++l) {
+    if (!cls_logits[l] || !bbox_regression[l] || !anchors[l]) return fail(MI355DET_EINVAL, "%s: null level pointer", "retina_detections");
+    W.L.reg[l] = bbox_regression[l];
+    W.L.anchors[l] = anchors[l];
+    const long long n = level_anchors[l] * (long long)num_classes;          // retinanet.py:437-445: threshold, then top-k of the flattened scores
+    if (int e = mi355det_topk_ws(cls_logits[l], n_images, n, n, W.L.k[l], logit_thresh, (int64_t*)(ws + W.L.idx_off[l]), (float*)(ws + W.L.val_off[l]),
+                                 (int32_t*)(ws + W.L.cnt_off[l]), ws + W.topk_ws, mi355det_topk_workspace(n_images), stream))
+      return e;
+  }
+  const long long total = (long long)n_images * W.K;
+  hipLaunchKernelGGL(retina_select_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, S(stream), ws, W.L, clip_limits, n_images, xform_clip,
+                     (float*)(ws + W.boxes), (float*)(ws + W.masked), (float*)(ws + W.scores), (long long*)(ws + W.labels));
+  if (int e = mi355det_nms_batch((const float*)(ws + W.boxes), (const float*)(ws + W.masked), (const int64_t*)(ws + W.labels), n_images, W.K, nms_thresh,
+                                 (int64_t*)(ws + W.keep), (int32_t*)(ws + W.keep_cnt), ws + W.nms_ws, mi355det_nms_workspace(n_images, W.K), stream))
+    return e;
+  hipLaunchKernelGGL(retina_gather_kernel, dim3(n_images), dim3(256), 0, S(stream), (const float*)(ws + W.boxes), (const float*)(ws + W.masked),
+                     (const float*)(ws + W.scores), (const long long*)(ws + W.labels), (const long long*)(ws + W.keep), (const int*)(ws + W.keep_cnt), W.K,
+                     detections_per_img, out_boxes, out_scores, (long long*)out_labels, out_counts);
+  return check_launch("retina_detections");
 }
 
 }  // extern "C"

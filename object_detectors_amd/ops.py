@@ -221,6 +221,37 @@ def rpn_proposals(objectness, deltas, anchors, clip_limits, level_counts, pre_nm
     return boxes, scores, counts
 
 
+def retina_detections(cls_logits_per_level, bbox_reg_per_level, anchors_per_level, clip_limits, logit_thresh, topk_candidates, nms_thresh,
+                      detections_per_img, xform_clip=math.log(1000.0 / 16)):
+    """RetinaNet.postprocess_detections (retinanet.py:414-472), whole batch, one host call: per level cls_logits [N,HWA,K] (fp32, tf-idf
+    scaling already applied), bbox regression [N,HWA,4], anchors [HWA,4]; clip_limits [N,4] = (w,h,w,h) ->
+    (boxes [N,det,4], scores [N,det], labels [N,det] i64, counts [N] i32 on the device)."""
+    cl = [_f32c(t) for t in cls_logits_per_level]
+    rg = [_f32c(t) for t in bbox_reg_per_level]
+    an = [_f32c(t) for t in anchors_per_level]
+    clip_limits = _f32c(clip_limits)
+    nl, n, k = len(cl), cl[0].shape[0], cl[0].shape[-1]
+    hwa = [int(t.shape[1]) for t in cl]
+    if not 1 <= nl <= 8 or any(r.shape[:2] != c.shape[:2] or a.shape[0] != c.shape[1] for c, r, a in zip(cl, rg, an)) or clip_limits.numel() != 4 * n:
+        raise ValueError("retina_detections: 1..8 levels of cls_logits [N,HWA,K], bbox_regression [N,HWA,4], anchors [HWA,4]; clip_limits [N,4]")
+    i64a, vpa = C.c_int64 * nl, C.c_void_p * nl
+    la = i64a(*hwa)
+    wsb = lib().mi355det_retina_detections_workspace(n, la, nl, k, int(topk_candidates))
+    if wsb == 0:
+        raise ValueError("retina_detections: need fewer than 2^32 scores per image and level and 1 <= topk_candidates <= 16384")
+    dev = cl[0].device
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    det = int(detections_per_img)
+    boxes = torch.empty((n, det, 4), device=dev, dtype=torch.float32)
+    scores = torch.empty((n, det), device=dev, dtype=torch.float32)
+    labels = torch.empty((n, det), device=dev, dtype=torch.int64)
+    counts = torch.empty(n, device=dev, dtype=torch.int32)
+    check(lib().mi355det_retina_detections(vpa(*[ptr(t) for t in cl]), vpa(*[ptr(t) for t in rg]), vpa(*[ptr(t) for t in an]), la, nl, n, k,
+                                           ptr(clip_limits), float(logit_thresh), int(topk_candidates), float(nms_thresh), det, float(xform_clip),
+                                           ptr(boxes), ptr(scores), ptr(labels), ptr(counts), ptr(ws), wsb, stream_ptr()), "retina_detections")
+    return boxes, scores, labels, counts
+
+
 def roi_match(proposals, proposal_counts, gt_boxes, gt_labels, gt_offsets, fg_iou_thresh, bg_iou_thresh, counts_out=None):
     """RoIHeads.assign_targets_to_proposals over add_gt_proposals (roi_heads.py:627-652,664-668) for the whole batch, one launch: proposals
     [N,P,4] padded + proposal_counts [N] i32 on the device, gt_boxes [G,4] / gt_labels [G] concatenated, gt_offsets host list [N+1] ->

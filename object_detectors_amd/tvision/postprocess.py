@@ -4,6 +4,7 @@
   RoIHeads.postprocess_detections                           tvision/roi_heads.py:715-781
 Only index bookkeeping (gather by the selected indices, concatenation, ragged python lists) stays in torch."""
 import math
+import os
 
 import torch
 
@@ -13,6 +14,7 @@ from ._utils import BoxCoder
 
 
 _CLIP_LIMITS = {}
+_RETINA_FUSED = os.environ.get("MI355DET_RETINA_POST_FUSED", "1") != "0"      # 0: the torch-composed chain (A/B, tests)
 
 
 def _clip_limits(image_shapes, device, dtype):
@@ -98,6 +100,15 @@ def retinanet_postprocess_detections(cls_logits_per_level, bbox_reg_per_level, a
     dev = cls_logits_per_level[0].device
     # sigmoid is monotone: select on the (tf-idf scaled) logits with the threshold mapped to logit space
     thr_logit = math.log(score_thresh / (1.0 - score_thresh)) if 0.0 < score_thresh < 1.0 else float("-inf")
+    if _RETINA_FUSED and len(cls_logits_per_level) <= 8 and topk_candidates <= 16384:
+        # the whole chain below as ONE host call (`mi355det_retina_detections`: same kernels for top-k and NMS, one kernel for the index
+        # arithmetic / decode / clip of all levels, one for the final gather) and one read
+        lg = cls_logits_per_level if tfidf_post is None else [l * tfidf_post for l in cls_logits_per_level]
+        lim = _clip_limits(image_shapes, dev, torch.float32).reshape(num_images, 4)
+        b, sc, l, counts = ops.retina_detections(lg, bbox_reg_per_level, anchors_per_level, lim, thr_logit, topk_candidates, nms_thresh,
+                                                 detections_per_img, coder.bbox_xform_clip)
+        counts = counts.tolist()                                                              # the one synchronisation
+        return [{"boxes": b[i, :c], "scores": sc[i, :c], "labels": l[i, :c]} for i, c in enumerate(counts)]
     batch = torch.arange(num_images, device=dev)[:, None]
     lb, ls, ll, lv = [], [], [], []
     for logits, reg, anchors in zip(cls_logits_per_level, bbox_reg_per_level, anchors_per_level):

@@ -145,3 +145,33 @@ def test_select_training_samples_fused_matches_composed_route(n, post, gts):
     assert torch.equal(rois[:, 1:], torch.cat(r_props))
     assert torch.equal(mi, torch.cat(r_mi)) and torch.equal(lab, torch.cat(r_lab))
     assert torch.equal(reg, torch.cat(r_reg)), (reg - torch.cat(r_reg)).abs().max()
+
+
+@pytest.mark.parametrize("n,k_cls,prior,tfidf", [(3, 91, 0.05, False), (2, 20, 0.01, True), (2, 1204, 0.05, False)])
+def test_retina_detections_matches_composed_route(n, k_cls, prior, tfidf, monkeypatch):
+    """mi355det_retina_detections (RetinaNet.postprocess_detections, retinanet.py:414-472, one host call) against the torch-composed chain of
+    postprocess.retinanet_postprocess_detections (pinned by the oracle in tests/test_gpu_roi.py): identical detections."""
+    from object_detectors_amd.tvision import postprocess as pp
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(21 + k_cls)
+    sides = [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)]
+    logits, regs, anchors = [], [], []
+    bias = math.log(prior / (1 - prior))
+    for li, (h, w) in enumerate(sides):
+        hwa = h * w * 9
+        logits.append(torch.randn((n, hwa, k_cls), device=dev, generator=g) + bias)
+        regs.append(torch.randn((n, hwa, 4), device=dev, generator=g) * 0.3)
+        c = torch.rand((hwa, 2), device=dev, generator=g) * 320
+        wh = torch.rand((hwa, 2), device=dev, generator=g) * (20 * 2 ** li) + 4
+        anchors.append(torch.cat([c - wh / 2, c + wh / 2], 1))
+    logits[4][1] = -20.0                                    # a level / image without a single score above the threshold
+    shapes = [(320, 320), (300, 256), (256, 320)][:n]
+    tf = (torch.rand((1, k_cls), device=dev, generator=g) + 0.5) if tfidf else None
+    monkeypatch.setattr(pp, "_RETINA_FUSED", False)
+    ref = pp.retinanet_postprocess_detections(logits, regs, anchors, shapes, tf, 0.05, 1000, 0.5, 300)
+    monkeypatch.setattr(pp, "_RETINA_FUSED", True)
+    got = pp.retinanet_postprocess_detections(logits, regs, anchors, shapes, tf, 0.05, 1000, 0.5, 300)
+    assert sum(int(d["boxes"].shape[0]) for d in ref) > 0
+    for r, d in zip(ref, got):
+        assert d["boxes"].shape == r["boxes"].shape
+        assert torch.equal(d["boxes"], r["boxes"]) and torch.equal(d["scores"], r["scores"]) and torch.equal(d["labels"], r["labels"])
