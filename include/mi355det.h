@@ -180,6 +180,15 @@ int mi355det_retina_detections(const float* const* cls_logits, const float* cons
                                float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_counts, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* RegionProposalNetwork.compute_loss (tvision/rpn.py:282-318) on prepared indices, forward and gradient in one launch: objectness [T] logits,
+ * pred_bbox_deltas / regression_targets [T,4], labels [T] (1 / 0 for the sampled anchors), pos_idx [num_pos] and sampled_idx [num_sampled]
+ * (positives followed by negatives, unique).  losses[0] = binary_cross_entropy_with_logits(objectness[sampled], labels[sampled]) (mean),
+ * losses[1] = smooth_l1(deltas[pos], targets[pos], beta 1/9, sum) / num_sampled; grad_objectness [T] and grad_deltas [T,4] are their
+ * gradients (zero outside the sampled / positive anchors), written completely. */
+int mi355det_rpn_loss(const float* objectness, const float* pred_bbox_deltas, const float* labels, const float* regression_targets, int64_t total,
+                      const int64_t* pos_idx, int32_t num_pos, const int64_t* sampled_idx, int32_t num_sampled, float* losses, float* grad_objectness,
+                      float* grad_deltas, void* stream);
+
 /* RoIHeads.select_training_samples for the whole batch (tvision/roi_heads.py:627-713), the two launches around the one host read its
  * sampler needs.  Candidates of image i are its proposals (proposals [N, max_proposals, 4] padded, proposal_counts [N] on the device, as
  * mi355det_rpn_proposals leaves them) followed by its ground truth (add_gt_proposals): gt_boxes [G,4] / gt_labels [G] of all images

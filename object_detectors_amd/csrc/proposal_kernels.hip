@@ -426,6 +426,44 @@ int retina_layout(int n_images, const int64_t* level_anchors, int nlev, int num_
   return 0;
 }
 
+// ---- RegionProposalNetwork.compute_loss (tvision/rpn.py:282-318), forward and gradient in one launch ------------------------------------
+// objectness_loss = mean over the sampled anchors of BCE-with-logits, box_loss = sum over the positive anchors of smooth-L1 (beta 1/9) /
+// number of sampled anchors.  The gradients go straight into the dense [T] / [T,4] buffers the network backward reads (zero elsewhere): the
+// autograd form needs ~25 launches, among them two sort-based `index_put(accumulate)` for the gathers' backward.  One workgroup, fixed
+// summation order (at most a few thousand sampled anchors).
+__global__ __launch_bounds__(1024) void rpn_loss_kernel(const float* __restrict__ obj, const float* __restrict__ deltas,
+                                                        const float* __restrict__ labels, const float* __restrict__ targets,
+                                                        const long long* __restrict__ pos, int P, const long long* __restrict__ sampled, int S,
+                                                        float* __restrict__ losses, float* __restrict__ grad_obj, float* __restrict__ grad_deltas) {
+  __shared__ float red[2][1024 / WAVE];
+  const float inv = 1.0f / (float)S, beta = 1.0f / 9;
+  float lo = 0.f, lb = 0.f;
+  for (int i = threadIdx.x; i < S; i += 1024) {
+    const long long a = sampled[i];
+    const float x = obj[a], y = labels[a];
+    lo += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    grad_obj[a] = (1.0f / (1.0f + expf(-x)) - y) * inv;
+  }
+  for (int i = threadIdx.x; i < 4 * P; i += 1024) {
+    const long long a = pos[i >> 2] * 4 + (i & 3);
+    const float d = deltas[a] - targets[a], n = fabsf(d);
+    lb += n < beta ? 0.5f * n * n / beta : n - 0.5f * beta;
+    grad_deltas[a] = (n < beta ? d / beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f))) * inv;
+  }
+  lo = wave_sum(lo);
+  lb = wave_sum(lb);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    red[0][threadIdx.x / WAVE] = lo;
+    red[1][threadIdx.x / WAVE] = lb;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    float t = 0.f;
+    for (int w = 0; w < 1024 / WAVE; ++w) t += red[threadIdx.x][w];
+    losses[threadIdx.x] = t * inv;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -576,6 +614,21 @@ int mi355det_retina_detections(const float* const* cls_logits, const float* cons
                      (const float*)(ws + W.scores), (const long long*)(ws + W.labels), (const long long*)(ws + W.keep), (const int*)(ws + W.keep_cnt), W.K,
                      detections_per_img, out_boxes, out_scores, (long long*)out_labels, out_counts);
   return check_launch("retina_detections");
+}
+
+int mi355det_rpn_loss(const float* objectness, const float* pred_bbox_deltas, const float* labels, const float* regression_targets, int64_t total,
+                      const int64_t* pos_idx, int32_t num_pos, const int64_t* sampled_idx, int32_t num_sampled, float* losses, float* grad_objectness,
+                      float* grad_deltas, void* stream) {
+  if (total <= 0 || num_pos < 0 || num_sampled <= 0 || num_pos > num_sampled)
+    return fail(MI355DET_EINVAL, "%s: need total > 0 and 0 <= num_pos <= num_sampled, num_sampled > 0", "rpn_loss");
+  if (!objectness || !pred_bbox_deltas || !labels || !regression_targets || !sampled_idx || (num_pos && !pos_idx) || !losses || !grad_objectness || !grad_deltas)
+    return fail(MI355DET_EINVAL, "%s: null argument", "rpn_loss");
+  if (hipMemsetAsync(grad_objectness, 0, sizeof(float) * (size_t)total, S(stream)) != hipSuccess ||
+      hipMemsetAsync(grad_deltas, 0, sizeof(float) * 4 * (size_t)total, S(stream)) != hipSuccess)
+    return fail(MI355DET_ELAUNCH, "%s: memset failed", "rpn_loss");
+  hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, S(stream), objectness, pred_bbox_deltas, labels, regression_targets,
+                     (const long long*)pos_idx, num_pos, (const long long*)sampled_idx, num_sampled, losses, grad_objectness, grad_deltas);
+  return check_launch("rpn_loss");
 }
 
 }  // extern "C"

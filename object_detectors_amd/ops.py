@@ -252,6 +252,21 @@ def retina_detections(cls_logits_per_level, bbox_reg_per_level, anchors_per_leve
     return boxes, scores, labels, counts
 
 
+def rpn_loss(objectness, pred_bbox_deltas, labels, regression_targets, pos_idx, sampled_idx):
+    """RegionProposalNetwork.compute_loss (rpn.py:282-318) with its gradients, one launch: objectness [T(,1)], deltas / targets [T,4],
+    labels [T] float, pos_idx / sampled_idx int64 -> (losses [2] = (objectness, box), grad_objectness like objectness, grad_deltas [T,4])."""
+    obj, dl, lab, tg = _f32c(objectness), _f32c(pred_bbox_deltas), _f32c(labels), _f32c(regression_targets)
+    t = obj.numel()
+    if dl.numel() != 4 * t or lab.numel() != t or tg.numel() != 4 * t or sampled_idx.numel() == 0:
+        raise ValueError("rpn_loss: objectness [T], deltas / targets [T,4], labels [T], at least one sampled anchor")
+    pos_idx, sampled_idx = pos_idx.to(torch.int64).contiguous(), sampled_idx.to(torch.int64).contiguous()
+    losses = torch.empty(2, device=obj.device, dtype=torch.float32)
+    g_obj, g_dl = torch.empty_like(obj), torch.empty_like(dl)
+    check(lib().mi355det_rpn_loss(ptr(obj), ptr(dl), ptr(lab), ptr(tg), t, ptr(pos_idx) if pos_idx.numel() else None, pos_idx.numel(),
+                                  ptr(sampled_idx), sampled_idx.numel(), ptr(losses), ptr(g_obj), ptr(g_dl), stream_ptr()), "rpn_loss")
+    return losses, g_obj, g_dl
+
+
 def roi_match(proposals, proposal_counts, gt_boxes, gt_labels, gt_offsets, fg_iou_thresh, bg_iou_thresh, counts_out=None):
     """RoIHeads.assign_targets_to_proposals over add_gt_proposals (roi_heads.py:627-652,664-668) for the whole batch, one launch: proposals
     [N,P,4] padded + proposal_counts [N] i32 on the device, gt_boxes [G,4] / gt_labels [G] concatenated, gt_offsets host list [N+1] ->

@@ -36,6 +36,7 @@ from .transform import GeneralizedRCNNTransform
 
 _RPN_FUSED = os.environ.get("MI355DET_RPN_FUSED", "1") != "0"      # 0: box_decode of every anchor + the torch-composed filter (A/B, tests)
 _ROI_FUSED = os.environ.get("MI355DET_ROI_FUSED", "1") != "0"      # 0: the per-image torch-composed select_training_samples
+_RPN_LOSS_FUSED = os.environ.get("MI355DET_RPN_LOSS_FUSED", "1") != "0"      # 0: the autograd-composed RPN losses
 _RPN_LOSS_SIDE = os.environ.get("MI355DET_RPN_LOSS_SIDE", "0") != "0"      # 1: RPN losses on the target stream beside the proposal kernels (A/B: no gain)
 
 
@@ -227,16 +228,26 @@ class FasterRCNN(nn.Module):
         # ---- RPN losses on leaf copies of the engine's outputs (their .grad is the engine's head gradient).  Issued AFTER the RoI branch:
         # they do not feed it, and their host time then hides behind the RoI kernels instead of sitting in front of them with the device idle
         torch.cuda.current_stream(images.device).wait_stream(self._tgt_stream)
-        if rpn_losses is None:
+        obj_grad = dl_grad = None
+        if rpn_losses is None and _RPN_LOSS_FUSED and rpn_side["sampled"].numel():
+            # compute_loss and its gradients in ONE launch, outside autograd (the autograd form: ~25 launches, two of them sort-based
+            # index_put(accumulate) for the backward of the gathers); the loss weights are 1, as in the sum below
+            rpn_losses, obj_grad, dl_grad = self.rpn_targets.losses_prepared_fused(out["cls_logits"].reshape(-1, 1), out["bbox_regression"].reshape(-1, 4),
+                                                                                   rpn_side)
+        elif rpn_losses is None:
             obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
             dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
             rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
         losses = {"loss_classifier": loss_cls, "loss_box_reg": loss_box}
         losses.update(rpn_losses)
-        sum(losses.values()).backward()
+        if obj_grad is not None:
+            (loss_cls + loss_box).backward()
+        else:
+            sum(losses.values()).backward()
+            obj_grad, dl_grad = obj.grad, dl.grad
         if getattr(self, "head_grad_sync", None) is not None:     # data parallel: parallel.ParamGradSync over head_parameters(), overlapped with
             self.head_grad_sync.reduce()                          # the whole backbone backward below
-        self.engine.backward(obj.grad, dl.grad, [f.grad for f in feats])
+        self.engine.backward(obj_grad, dl_grad, [f.grad for f in feats])
         return {k: v.detach() for k, v in losses.items()}
 
 

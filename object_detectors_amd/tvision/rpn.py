@@ -67,6 +67,13 @@ class RPNTargets:
         objectness_loss = F.binary_cross_entropy_with_logits(objectness.flatten()[sampled], prep["labels"][sampled])
         return {"loss_objectness": objectness_loss, "loss_rpn_box_reg": box_loss}
 
+    def losses_prepared_fused(self, objectness, pred_bbox_deltas, prep):
+        """losses_prepared + its gradients in one launch (`mi355det_rpn_loss`), outside autograd:
+        -> ({'loss_objectness', 'loss_rpn_box_reg'}, d loss / d objectness, d loss / d pred_bbox_deltas) for a unit weight on both losses."""
+        from .. import ops
+        losses, g_obj, g_dl = ops.rpn_loss(objectness.detach(), pred_bbox_deltas.detach(), prep["labels"], prep["reg"], prep["pos"], prep["sampled"])
+        return {"loss_objectness": losses[0], "loss_rpn_box_reg": losses[1]}, g_obj, g_dl
+
     def losses(self, objectness, pred_bbox_deltas, anchors, targets):
         """rpn.py:353-361: -> {'loss_objectness', 'loss_rpn_box_reg'}."""
         labels, matched = self.assign_targets_to_anchors(anchors, targets)

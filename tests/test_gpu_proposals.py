@@ -175,3 +175,32 @@ def test_retina_detections_matches_composed_route(n, k_cls, prior, tfidf, monkey
     for r, d in zip(ref, got):
         assert d["boxes"].shape == r["boxes"].shape
         assert torch.equal(d["boxes"], r["boxes"]) and torch.equal(d["scores"], r["scores"]) and torch.equal(d["labels"], r["labels"])
+
+
+def test_rpn_loss_kernel_matches_autograd():
+    """mi355det_rpn_loss against RPNTargets.losses_prepared under autograd (rpn.py:282-318): losses and both gradients."""
+    from object_detectors_amd.tvision.rpn import RPNTargets
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    t = 4 * 159882
+    obj = torch.randn((t, 1), device=dev, generator=g) * 3
+    dl = torch.randn((t, 4), device=dev, generator=g) * 0.3
+    perm = torch.randperm(t, device=dev, generator=g)
+    pos, neg = perm[:317].sort().values, perm[317:1024].sort().values
+    labels = torch.zeros(t, device=dev)
+    labels[pos] = 1.0
+    reg = torch.zeros((t, 4), device=dev)
+    reg[pos] = dl[pos] + torch.randn((317, 4), device=dev, generator=g) * 0.2      # both smooth-L1 branches (beta = 1/9)
+    reg[pos[:5]] = dl[pos[:5]]                                                      # zero difference
+    prep = dict(pos=pos, sampled=torch.cat([pos, neg]), labels=labels, reg=reg)
+    tg = RPNTargets()
+    o, d = obj.clone().requires_grad_(True), dl.clone().requires_grad_(True)
+    ref = tg.losses_prepared(o, d, prep)
+    (ref["loss_objectness"] + ref["loss_rpn_box_reg"]).backward()
+    got, g_obj, g_dl = tg.losses_prepared_fused(obj, dl, prep)
+    torch.testing.assert_close(got["loss_objectness"], ref["loss_objectness"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got["loss_rpn_box_reg"], ref["loss_rpn_box_reg"], rtol=1e-5, atol=1e-6)
+    assert g_obj.shape == o.grad.shape and g_dl.shape == d.grad.shape
+    torch.testing.assert_close(g_obj, o.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(g_dl, d.grad, rtol=1e-5, atol=1e-9)
+    assert int((g_obj != 0).sum()) <= 1024 and int((g_dl != 0).sum()) <= 4 * 317
