@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--px", type=int, default=800)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reuse-rpn-targets", action="store_true", help="MEASUREMENT ONLY: prepare the RPN targets once and reuse them (the "
+                    "targets are constant in this bench) - the step time that kernels for RPNTargets.prepare could reach at most; not a valid step")
     args = ap.parse_args()
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.tvision.frcnn import fasterrcnn_resnet50_fpn
@@ -41,6 +43,9 @@ def main():
         wh = torch.rand((7, 2), generator=g) * args.px * 0.3 + 16
         targets.append({"boxes": torch.cat([tl, tl + wh], 1).to(dev), "labels": torch.randint(1, 91, (7,), generator=g).to(dev)})
     model.train()
+    if args.reuse_rpn_targets:
+        real, cache = model.rpn_targets.prepare, {}
+        model.rpn_targets.prepare = lambda anchors, tg: cache.setdefault("p", real(anchors, tg)) if "p" not in cache else cache["p"]
 
     def step():
         opt_head.zero_grad(set_to_none=True)
@@ -65,7 +70,7 @@ def main():
             det = model(imgs)
         torch.cuda.synchronize()
     de = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"bench": "fasterrcnn_resnet50_fpn", "batch": args.batch, "px": args.px, "train_images_per_s": round(args.batch / dt, 2),
+    print(json.dumps({"bench": "fasterrcnn_resnet50_fpn" + ("_REUSED_RPN_TARGETS_not_a_valid_step" if args.reuse_rpn_targets else ""), "batch": args.batch, "px": args.px, "train_images_per_s": round(args.batch / dt, 2),
                       "train_ms_per_step": round(dt * 1e3, 2), "eval_images_per_s": round(args.batch / de, 2), "eval_ms_per_batch": round(de * 1e3, 2),
                       "losses_first": {k: round(float(v), 4) for k, v in l0.items()}, "losses_last": {k: round(float(v), 4) for k, v in l1.items()},
                       "detections_img0": int(det[0]["boxes"].shape[0])}))
