@@ -180,6 +180,19 @@ int mi355det_retina_detections(const float* const* cls_logits, const float* cons
                                float* out_boxes, float* out_scores, int64_t* out_labels, int32_t* out_counts, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* RoIHeads.postprocess_detections for the whole batch in one call (tvision/roi_heads.py:715-781): scores [N, P, C] (the reference's score
+ * function already applied; the caller pushes class 0 and padded proposals below score_thresh), box_regression [N, P, C, 4], proposals
+ * [N, P, 4], clip_limits [N, 4] = (w, h, w, h).  Candidates = the scores above score_thresh, at most max_candidates per image in descending
+ * order (candidate_counts[img] == max_candidates means the list may be truncated: the caller then takes the unbounded route); decode with
+ * BoxCoder(wx, wy, ww, wh), clip, boxes smaller than min_size masked, per-class NMS, the first detections_per_img survivors ->
+ * out_boxes [N, det, 4], out_scores [N, det], out_labels [N, det] int64, out_counts [N], candidate_counts [N] (int32, device). */
+size_t mi355det_roi_detections_workspace(int32_t n_images, int32_t max_proposals, int32_t num_classes, int32_t max_candidates);
+int mi355det_roi_detections(const float* scores, const float* box_regression, const float* proposals, const float* clip_limits, int32_t n_images,
+                            int32_t max_proposals, int32_t num_classes, float score_thresh, int32_t max_candidates, float wx, float wy, float ww,
+                            float wh, float xform_clip, float min_size, float nms_thresh, int32_t detections_per_img, float* out_boxes,
+                            float* out_scores, int64_t* out_labels, int32_t* out_counts, int32_t* candidate_counts, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* RegionProposalNetwork.compute_loss (tvision/rpn.py:282-318) on prepared indices, forward and gradient in one launch: objectness [T] logits,
  * pred_bbox_deltas / regression_targets [T,4], labels [T] (1 / 0 for the sampled anchors), pos_idx [num_pos] and sampled_idx [num_sampled]
  * (positives followed by negatives, unique).  losses[0] = binary_cross_entropy_with_logits(objectness[sampled], labels[sampled]) (mean),

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "mi355det_rpn_proposals": (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, f32, f32, f32, f32, vp, vp, vp, vp, sz, vp]),
     "mi355det_retina_detections_workspace": (sz, [i32, vp, i32, i32, i32]),
     "mi355det_retina_detections": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, f32, i32, f32, i32, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "mi355det_roi_detections_workspace": (sz, [i32, i32, i32, i32]),
+    "mi355det_roi_detections": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "mi355det_rpn_loss": (C.c_int, [vp, vp, vp, vp, i64, vp, i32, vp, i32, vp, vp, vp, vp]),
     "mi355det_roi_match": (C.c_int, [vp, vp, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp]),
     "mi355det_roi_sample": (C.c_int, [vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, vp, vp, vp, vp]),

@@ -464,6 +464,71 @@ __global__ __launch_bounds__(1024) void rpn_loss_kernel(const float* __restrict_
   }
 }
 
+// ---- RoIHeads.postprocess_detections for the whole batch (tvision/roi_heads.py:715-781) ------------------------------------------------
+// scores [N, P, C] (softmax / sigmoid / gombit already applied, class 0 and padded proposals pushed below the threshold by the caller),
+// box_regression [N, P, C, 4], proposals [N, P, 4]: thresholded top-k over the flattened P x C scores of every image, decode of the
+// selected (proposal, class) pairs with the head's BoxCoder weights, clip, small boxes masked, per-class NMS, the first detections_per_img.
+__global__ __launch_bounds__(256) void roi_det_select_kernel(const long long* __restrict__ idx, const float* __restrict__ val,
+                                                             const int* __restrict__ cnt, int k, int P, int C, const float* __restrict__ reg,
+                                                             const float* __restrict__ props, const float* __restrict__ lim, int n_images, float wx,
+                                                             float wy, float ww, float wh, float xform_clip, float min_size,
+                                                             float* __restrict__ boxes, float* __restrict__ masked, float* __restrict__ scores,
+                                                             long long* __restrict__ labels) {
+  const long long total = (long long)n_images * k;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int img = (int)(t / k), j = (int)(t - (long long)img * k);
+    if (j >= cnt[img]) {
+      *(float4*)(boxes + 4 * t) = make_float4(0.f, 0.f, 0.f, 0.f);
+      scores[t] = 0.f;
+      masked[t] = -INFINITY;
+      labels[t] = 0;
+      continue;
+    }
+    const long long flat = idx[t];
+    const int p = (int)(flat / C), cls = (int)(flat - (long long)p * C);
+    const float4 b = *(const float4*)(props + 4 * ((long long)img * P + p));
+    const float4 c = *(const float4*)(reg + 4 * (((long long)img * P + p) * C + cls));
+    const float w = b.z - b.x, h = b.w - b.y, cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+    const float dx = c.x / wx, dy = c.y / wy, dw = fminf(c.z / ww, xform_clip), dh = fminf(c.w / wh, xform_clip);      // box_decode_kernel's order
+    const float pcx = dx * w + cx, pcy = dy * h + cy, pw = expf(dw) * w, ph = expf(dh) * h;
+    float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+    const float4 m = *(const float4*)(lim + 4 * img);
+    o.x = fminf(fmaxf(o.x, 0.f), m.x);
+    o.y = fminf(fmaxf(o.y, 0.f), m.y);
+    o.z = fminf(fmaxf(o.z, 0.f), m.z);
+    o.w = fminf(fmaxf(o.w, 0.f), m.w);
+    const float sc = val[t];
+    const bool valid = (o.z - o.x >= min_size) && (o.w - o.y >= min_size);
+    *(float4*)(boxes + 4 * t) = o;
+    scores[t] = sc;
+    masked[t] = valid ? sc : -INFINITY;
+    labels[t] = cls;
+  }
+}
+
+struct RoiDetWs {
+  size_t idx, val, cnt, topk_ws, boxes, masked, scores, labels, keep, keep_cnt, nms_ws, total;
+};
+
+int roi_det_layout(int n_images, long long row, int k, RoiDetWs& W) {
+  if (n_images <= 0 || row <= 0 || row >= (1ll << 32) || k <= 0 || k > 16384 || k > row) return 1;
+  const size_t NK = (size_t)n_images * k;
+  size_t off = 0;
+  W.idx = off, off = align256(off + NK * sizeof(int64_t));
+  W.val = off, off = align256(off + NK * sizeof(float));
+  W.cnt = off, off = align256(off + sizeof(int32_t) * (size_t)n_images);
+  W.topk_ws = off, off = align256(off + mi355det_topk_workspace(n_images));
+  W.boxes = off, off = align256(off + NK * 4 * sizeof(float));
+  W.masked = off, off = align256(off + NK * sizeof(float));
+  W.scores = off, off = align256(off + NK * sizeof(float));
+  W.labels = off, off = align256(off + NK * sizeof(int64_t));
+  W.keep = off, off = align256(off + NK * sizeof(int64_t));
+  W.keep_cnt = off, off = align256(off + sizeof(int32_t) * (size_t)n_images);
+  W.nms_ws = off, off = align256(off + mi355det_nms_workspace(n_images, k));
+  W.total = off;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -629,6 +694,44 @@ int mi355det_rpn_loss(const float* objectness, const float* pred_bbox_deltas, co
   hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, S(stream), objectness, pred_bbox_deltas, labels, regression_targets,
                      (const long long*)pos_idx, num_pos, (const long long*)sampled_idx, num_sampled, losses, grad_objectness, grad_deltas);
   return check_launch("rpn_loss");
+}
+
+size_t mi355det_roi_detections_workspace(int32_t n_images, int32_t max_proposals, int32_t num_classes, int32_t max_candidates) {
+  RoiDetWs W;
+  if (max_proposals <= 0 || num_classes <= 0 || roi_det_layout(n_images, (long long)max_proposals * num_classes, max_candidates, W)) return 0;
+  return W.total;
+}
+
+int mi355det_roi_detections(const float* scores, const float* box_regression, const float* proposals, const float* clip_limits, int32_t n_images,
+                            int32_t max_proposals, int32_t num_classes, float score_thresh, int32_t max_candidates, float wx, float wy, float ww,
+                            float wh, float xform_clip, float min_size, float nms_thresh, int32_t detections_per_img, float* out_boxes,
+                            float* out_scores, int64_t* out_labels, int32_t* out_counts, int32_t* candidate_counts, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  RoiDetWs W;
+  if (max_proposals <= 0 || num_classes <= 0 || roi_det_layout(n_images, (long long)max_proposals * num_classes, max_candidates, W))
+    return fail(MI355DET_EINVAL, "%s: need a positive batch, 1 <= max_candidates <= min(16384, proposals x classes)", "roi_detections");
+  if (detections_per_img <= 0 || !scores || !box_regression || !proposals || !clip_limits || !out_boxes || !out_scores || !out_labels || !out_counts ||
+      !candidate_counts || !workspace)
+    return fail(MI355DET_EINVAL, "%s: null argument or detections_per_img <= 0", "roi_detections");
+  if (workspace_bytes < W.total) return fail(MI355DET_EWORKSPACE, "%s: workspace too small", "roi_detections");
+  char* ws = (char*)workspace;
+  const long long row = (long long)max_proposals * num_classes;
+  if (int e = mi355det_topk_ws(scores, n_images, row, row, max_candidates, score_thresh, (int64_t*)(ws + W.idx), (float*)(ws + W.val), candidate_counts,
+                               ws + W.topk_ws, mi355det_topk_workspace(n_images), stream))
+    return e;
+  const long long total = (long long)n_images * max_candidates;
+  hipLaunchKernelGGL(roi_det_select_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, S(stream), (const long long*)(ws + W.idx),
+                     (const float*)(ws + W.val), (const int*)candidate_counts, max_candidates, max_proposals, num_classes, box_regression, proposals,
+                     clip_limits, n_images, wx, wy, ww, wh, xform_clip, min_size, (float*)(ws + W.boxes), (float*)(ws + W.masked),
+                     (float*)(ws + W.scores), (long long*)(ws + W.labels));
+  if (int e = mi355det_nms_batch((const float*)(ws + W.boxes), (const float*)(ws + W.masked), (const int64_t*)(ws + W.labels), n_images, max_candidates,
+                                 nms_thresh, (int64_t*)(ws + W.keep), (int32_t*)(ws + W.keep_cnt), ws + W.nms_ws,
+                                 mi355det_nms_workspace(n_images, max_candidates), stream))
+    return e;
+  hipLaunchKernelGGL(retina_gather_kernel, dim3(n_images), dim3(256), 0, S(stream), (const float*)(ws + W.boxes), (const float*)(ws + W.masked),
+                     (const float*)(ws + W.scores), (const long long*)(ws + W.labels), (const long long*)(ws + W.keep), (const int*)(ws + W.keep_cnt),
+                     max_candidates, detections_per_img, out_boxes, out_scores, (long long*)out_labels, out_counts);
+  return check_launch("roi_detections");
 }
 
 }  // extern "C"

@@ -252,6 +252,32 @@ def retina_detections(cls_logits_per_level, bbox_reg_per_level, anchors_per_leve
     return boxes, scores, labels, counts
 
 
+def roi_detections(scores, box_regression, proposals, clip_limits, score_thresh, max_candidates, weights, nms_thresh, detections_per_img,
+                   min_size=1e-2, xform_clip=math.log(1000.0 / 16), meta_out=None):
+    """RoIHeads.postprocess_detections (roi_heads.py:715-781), whole batch, one host call: scores [N,P,C] (class 0 / padded proposals already
+    below the threshold), box_regression [N,P,C*4], proposals [N,P,4], clip_limits [N,4] -> (boxes [N,det,4], scores [N,det], labels [N,det],
+    meta [2N] i32 = detections per image, then candidates per image (== max_candidates: possibly truncated))."""
+    scores, box_regression, proposals, clip_limits = _f32c(scores), _f32c(box_regression), _f32c(proposals), _f32c(clip_limits)
+    n, p, c = scores.shape
+    k = int(min(max_candidates, p * c))
+    if box_regression.numel() != n * p * c * 4 or proposals.numel() != n * p * 4 or clip_limits.numel() != n * 4:
+        raise ValueError("roi_detections: scores [N,P,C], box_regression [N,P,C*4], proposals [N,P,4], clip_limits [N,4]")
+    wsb = lib().mi355det_roi_detections_workspace(n, p, c, k)
+    if wsb == 0:
+        raise ValueError("roi_detections: need 1 <= max_candidates <= 16384 and fewer than 2^32 scores per image")
+    dev = scores.device
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    det = int(detections_per_img)
+    boxes = torch.empty((n, det, 4), device=dev, dtype=torch.float32)
+    out_s = torch.empty((n, det), device=dev, dtype=torch.float32)
+    labels = torch.empty((n, det), device=dev, dtype=torch.int64)
+    meta = meta_out if meta_out is not None else torch.empty(2 * n, device=dev, dtype=torch.int32)
+    check(lib().mi355det_roi_detections(ptr(scores), ptr(box_regression), ptr(proposals), ptr(clip_limits), n, p, c, float(score_thresh), k,
+                                        *[float(w) for w in weights], float(xform_clip), float(min_size), float(nms_thresh), det, ptr(boxes),
+                                        ptr(out_s), ptr(labels), ptr(meta[:n]), ptr(meta[n:]), ptr(ws), wsb, stream_ptr()), "roi_detections")
+    return boxes, out_s, labels, meta, k
+
+
 def rpn_loss(objectness, pred_bbox_deltas, labels, regression_targets, pos_idx, sampled_idx):
     """RegionProposalNetwork.compute_loss (rpn.py:282-318) with its gradients, one launch: objectness [T(,1)], deltas / targets [T,4],
     labels [T] float, pos_idx / sampled_idx int64 -> (losses [2] = (objectness, box), grad_objectness like objectness, grad_deltas [T,4])."""

@@ -27,7 +27,8 @@ from .. import ops
 from ._utils import BoxCoder
 from .linear import MfmaLinear
 from .engine import IMAGE_MEAN, IMAGE_STD, FasterRCNNEngine
-from .postprocess import roi_heads_postprocess_detections, rpn_filter_proposals, rpn_proposals_fused
+from .postprocess import (roi_heads_postprocess_detections, roi_heads_postprocess_detections_batch, rpn_filter_proposals,
+                          rpn_proposals_fused)
 from .roi_align import MultiScaleRoIAlign
 from .roi_heads import RoIHeadTargets, fastrcnn_loss, minibatch_tfidf
 from .rpn import RPNTargets
@@ -36,6 +37,7 @@ from .transform import GeneralizedRCNNTransform
 
 _RPN_FUSED = os.environ.get("MI355DET_RPN_FUSED", "1") != "0"      # 0: box_decode of every anchor + the torch-composed filter (A/B, tests)
 _ROI_FUSED = os.environ.get("MI355DET_ROI_FUSED", "1") != "0"      # 0: the per-image torch-composed select_training_samples
+_ROI_DET_FUSED = os.environ.get("MI355DET_ROI_DET_FUSED", "1") != "0"      # 0: inference through proposal lists and the per-image post-processing
 _RPN_LOSS_FUSED = os.environ.get("MI355DET_RPN_LOSS_FUSED", "1") != "0"      # 0: the autograd-composed RPN losses
 _RPN_LOSS_SIDE = os.environ.get("MI355DET_RPN_LOSS_SIDE", "0") != "0"      # 1: RPN losses on the target stream beside the proposal kernels (A/B: no gain)
 
@@ -149,6 +151,29 @@ class FasterRCNN(nn.Module):
         return rpn_filter_proposals(proposals, out["cls_logits"].detach().reshape(n, -1), image_shapes, plan.level_rows, self.rpn_pre[mode],
                                     self.rpn_post[mode], self.rpn_nms_thresh, self.rpn_score_thresh)
 
+    def _detect_padded(self, out, plan, image_shapes):
+        """Inference with the proposals kept padded on the device from the RPN to the detections: proposal filter, RoIAlign, box head and
+        `postprocess_detections` without a host read in between - ONE read at the end (the list route reads the proposal counts, then three
+        counts per image in the post-processing).  None when an image has too many candidates for the one-call post-processing."""
+        n = out["cls_logits"].shape[0]
+        dev = out["cls_logits"].device
+        counts = torch.empty(n, device=dev, dtype=torch.int32)
+        with torch.no_grad():
+            boxes, _scores = self._proposals(out, plan, image_shapes, counts_out=counts)
+            p = boxes.shape[1]
+            key = (n, p, str(dev))
+            if getattr(self, "_roi_ids_key", None) != key:
+                self._roi_ids = torch.arange(n, device=dev, dtype=torch.float32).repeat_interleave(p)[:, None]
+                self._roi_ids_key = key
+            rois = torch.cat([self._roi_ids, boxes.reshape(-1, 4)], 1)
+            x = self.box_roi_pool.forward_nhwc(self.engine.feature_maps_nhwc(4), rois, image_shapes)
+            cls, reg = self.box_predictor(self.box_head(x))
+            res = roi_heads_postprocess_detections_batch(cls, reg, boxes, counts, image_shapes, self.tfidf_post, self.box_score_thresh,
+                                                         self.box_nms_thresh, self.box_detections_per_img, self.bbox_reg_weights, self.loss_type)
+        if res is None:
+            return None
+        return [{"boxes": bb, "labels": ll, "scores": ss} for bb, ll, ss in zip(*(res[0], res[2], res[1]))]
+
     def forward(self, images, targets=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")          # generalized_rcnn.py:60-61
@@ -197,6 +222,12 @@ class FasterRCNN(nn.Module):
                     obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
                     dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
                     rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
+        if not self.training and _RPN_FUSED and _ROI_DET_FUSED:
+            det = self._detect_padded(out, plan, image_shapes)
+            if det is not None:
+                if original_image_sizes is not None:
+                    det = self.transform.postprocess(det, image_shapes, original_image_sizes)      # generalized_rcnn.py:110
+                return det
         fused = self.training and _RPN_FUSED and _ROI_FUSED and self.roi_targets.fused_ok(n, self.rpn_post["training"], targets)
         if fused:     # proposals stay padded on the device; their counts are read together with the sampler's counts (one host read in all)
             meta = torch.empty(3 * n, device=images.device, dtype=torch.int32)

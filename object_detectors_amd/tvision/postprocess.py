@@ -170,6 +170,37 @@ def roi_heads_postprocess_detections(class_logits, box_regression, proposals, im
     return out_b, out_s, out_l
 
 
+ROI_DET_MAX_CANDIDATES = 4096      # (proposal, class) pairs above the score threshold per image the one-call route handles
+
+
+def roi_heads_postprocess_detections_batch(class_logits, box_regression, proposals_pad, proposal_counts, image_shapes, tfidf_post=1.0,
+                                           score_thresh=0.05, nms_thresh=0.5, detections_per_img=100, weights=(10.0, 10.0, 5.0, 5.0),
+                                           loss_type="ce", max_candidates=ROI_DET_MAX_CANDIDATES):
+    """RoIHeads.postprocess_detections (roi_heads.py:715-781) on PADDED proposals [N, P, 4] (+ their counts [N] int32 on the device) with one
+    host call (`mi355det_roi_detections`) and ONE host read: class_logits [N*P, C], box_regression [N*P, C*4] in proposal order.
+    -> (boxes, scores, labels) lists like roi_heads_postprocess_detections, or None when an image has max_candidates or more scores above
+    the threshold (the caller then takes the unbounded per-image route)."""
+    n, p = proposals_pad.shape[0], proposals_pad.shape[1]
+    c = class_logits.shape[-1]
+    if loss_type == "ce":
+        scores = torch.softmax(tfidf_post * class_logits, -1)
+    elif loss_type.startswith("gombit"):
+        scores = 1 / (torch.exp(torch.exp(-tfidf_post * (class_logits - 1.96))))
+    else:
+        scores = torch.sigmoid(tfidf_post * class_logits)
+    scores = scores.reshape(n, p, c)
+    scores[:, :, 0] = float("-inf")                                     # the background column is dropped (roi_heads.py:744-747)
+    pad = torch.arange(p, device=scores.device)[None, :] >= proposal_counts[:, None]
+    scores.masked_fill_(pad[:, :, None], float("-inf"))                 # rows of the padding
+    lim = _clip_limits(image_shapes, scores.device, torch.float32).reshape(n, 4)
+    boxes, out_s, labels, meta, k = ops.roi_detections(scores, box_regression, proposals_pad, lim, score_thresh, max_candidates, weights, nms_thresh,
+                                                       detections_per_img)
+    host = meta.tolist()                                                # the one synchronisation of the inference step
+    if any(host[n + i] >= k for i in range(n)):
+        return None
+    return ([boxes[i, :host[i]] for i in range(n)], [out_s[i, :host[i]] for i in range(n)], [labels[i, :host[i]] for i in range(n)])
+
+
 NMS_CAPACITY = 16384     # boxes per launch of the NMS kernels (include/mi355det.h)
 
 

@@ -204,3 +204,36 @@ def test_rpn_loss_kernel_matches_autograd():
     torch.testing.assert_close(g_obj, o.grad, rtol=1e-5, atol=1e-9)
     torch.testing.assert_close(g_dl, d.grad, rtol=1e-5, atol=1e-9)
     assert int((g_obj != 0).sum()) <= 1024 and int((g_dl != 0).sum()) <= 4 * 317
+
+
+@pytest.mark.parametrize("loss_type,c", [("ce", 91), ("bce", 21), ("gombit", 91)])
+def test_roi_detections_batch_matches_per_image_route(loss_type, c):
+    """mi355det_roi_detections (RoIHeads.postprocess_detections, roi_heads.py:715-781, padded proposals, one host call) against the per-image
+    composed route (pinned by the oracle in tests/test_gpu_roi.py): identical detections; saturation reported as None."""
+    from object_detectors_amd.tvision.postprocess import roi_heads_postprocess_detections, roi_heads_postprocess_detections_batch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(31 + c)
+    n, p = 3, 300
+    counts = [300, 257, 12]
+    shapes = [(400, 500), (384, 512), (400, 400)]
+    ctr = torch.rand((n, p, 2), device=dev, generator=g) * 380 + 10
+    wh = torch.rand((n, p, 2), device=dev, generator=g) * 150 + 2
+    pad = torch.cat([ctr - wh / 2, ctr + wh / 2], -1).clamp(0, 512)
+    for i, k in enumerate(counts):
+        pad[i, k:] = 0
+    scale = 3.0 if loss_type == "ce" else 1.5
+    logits = torch.randn((n * p, c), device=dev, generator=g) * scale - (0.0 if loss_type == "ce" else 2.5)
+    reg = torch.randn((n * p, c * 4), device=dev, generator=g) * 0.5
+    reg[::7, 2::4] = -60.0                                        # collapsed boxes: dropped by remove_small_boxes
+    tf = torch.rand((1, c), device=dev, generator=g) + 0.5
+    cnt_dev = torch.tensor(counts, device=dev, dtype=torch.int32)
+    rows = torch.cat([torch.arange(k, device=dev) + i * p for i, k in enumerate(counts)])
+    ref = roi_heads_postprocess_detections(logits[rows], reg[rows], [pad[i, :k] for i, k in enumerate(counts)], shapes, tf, 0.05, 0.5, 100,
+                                           (10.0, 10.0, 5.0, 5.0), loss_type)
+    got = roi_heads_postprocess_detections_batch(logits, reg, pad, cnt_dev, shapes, tf, 0.05, 0.5, 100, (10.0, 10.0, 5.0, 5.0), loss_type)
+    assert got is not None and sum(int(b.shape[0]) for b in ref[0]) > 20
+    for q in range(3):
+        for a, b in zip(ref[q], got[q]):
+            assert a.shape == b.shape and torch.equal(a, b), (q, a.shape, b.shape)
+    assert roi_heads_postprocess_detections_batch(logits, reg, pad, cnt_dev, shapes, tf, 0.05, 0.5, 100, (10.0, 10.0, 5.0, 5.0), loss_type,
+                                                  max_candidates=16) is None
