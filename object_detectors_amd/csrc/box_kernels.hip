@@ -789,8 +789,53 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
   const long long nvec = vec ? total / 4 : total;
   for (long long q = blockIdx.x * (long long)NT + threadIdx.x; q < nvec; q += (long long)gridDim.x * NT) {
     const long long i0 = vec ? q * 4 : q;
-    if (TGT_MODE == 1 && lv.nlev > 0 && lv.fast && vec && !grad &&
-        (lv.fast == 1 || (unsigned)i0 - fdivu((unsigned)i0, lv.dk) * (unsigned)k + 3u < (unsigned)k)) {      // fast == 2: only groups inside one row
+    const bool level_out = TGT_MODE == 1 && lv.nlev > 0 && lv.fast && vec && !grad;      // (wave-uniform) bf16 level output, 32-bit index arithmetic
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+    bf16_t* da[4] = {nullptr, nullptr, nullptr, nullptr};                                  // destination of each of the four gradients
+    const bool straddles = level_out && lv.fast == 2 && (unsigned)i0 - fdivu((unsigned)i0, lv.dk) * (unsigned)k + 3u >= (unsigned)k;
+    if (straddles) {
+      // ---- k % 4 != 0 (the 91-class head): a group that straddles two rows.  13 % of the groups at k = 91 - through the general path below
+      //      (64-bit divisions, per-element bookkeeping) they cost more than all the others together (1.19 ms for 175 M logits against
+      //      2.2 ms for the 1.16 G of the 1204-class head).  Same 32-bit index arithmetic as the one-row path, per element; sfl() as there.
+      const unsigned iu = (unsigned)i0;
+      const unsigned r0 = fdivu(iu, lv.dk), c0 = iu - r0 * (unsigned)k;
+      const float4 v = *(const float4*)(x + i0);
+      const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned ru = r0 + half;
+        const unsigned bu = fdivu(ru, lv.drpi), rl = ru - bu * lv.drpi.d;
+        unsigned st0 = 0, px = (unsigned)lv.pixels[0];
+        bf16_t* base = lv.dst[0];
+        int ldq = lv.ld[0];
+#pragma unroll
+        for (int l = 1; l < 8; ++l)
+          if (l < lv.nlev && rl >= (unsigned)lv.start[l]) {
+            st0 = (unsigned)lv.start[l]; px = (unsigned)lv.pixels[l]; base = lv.dst[l]; ldq = lv.ld[l];
+          }
+        const unsigned local = rl - st0, pix = fdivu(local, lv.da);
+        bf16_t* drow = base + ((size_t)bu * px + pix) * (size_t)ldq + (size_t)(local - pix * lv.da.d) * k;
+        const long long mi = matched[ru];
+        const float wimg = nfg ? inv_images / fmaxf(1.f, nfg[bu]) : 1.f;
+        const long long lab = mi >= 0 ? gt_labels[mi + (gt_off ? gt_off[bu] : 0)] : -1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool first = c0 + e < (unsigned)k;
+          if (first != (half == 0)) continue;
+          const unsigned cu = first ? c0 + e : c0 + e - (unsigned)k;
+          float g = 0.f;
+          if (mi != -2) {
+            const float sc = scale ? scale[cu] : 1.0f;
+            float l;
+            sfl(sc * xs[e], lab == (long long)cu ? 1.0f : 0.0f, alpha, gamma, l, g);
+            acc += l * wimg;
+            g *= sc * gscale * wimg;
+          }
+          g4[e] = g;
+          da[e] = drow + cu;
+        }
+      }
+    } else if (level_out) {
       // ---- training fast path (mi355det_retina_loss_lv): one row per group, 32-bit index arithmetic with multiply-shift divisions,
       //      the t = 0 form of the loss for groups that do not contain the row's label (all but one group in 301 at K = 1204).
       //      The general path below spends ~100 instructions per element on 64-bit divisions and per-element bookkeeping.
@@ -810,7 +855,6 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
       const float4 v = *(const float4*)(x + i0);
       const float xs[4] = {v.x, v.y, v.z, v.w};
       const long long mi = matched[ru];
-      float g4[4] = {0.f, 0.f, 0.f, 0.f};
       if (mi != -2) {                                    // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135)
         const float wimg = nfg ? inv_images / fmaxf(1.f, nfg[bu]) : 1.f;
         const long long lab = mi >= 0 ? gt_labels[mi + (gt_off ? gt_off[bu] : 0)] : -1;
@@ -841,14 +885,45 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
           g4[e] = g * (sc * gscale * wimg);
         }
       }
-      if (lv.fast == 1 || (((unsigned long long)dst) & 7ull) == 0) {
-        uint2 o;
-        o.x = f2bf(g4[0]) | ((unsigned)f2bf(g4[1]) << 16);
-        o.y = f2bf(g4[2]) | ((unsigned)f2bf(g4[3]) << 16);
-        *(uint2*)dst = o;
-      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = f2bf(g4[e]);
+      for (int e = 0; e < 4; ++e) da[e] = dst + e;
+    }
+    if (level_out) {
+      // ---- stores.  k % 4 == 0: every group is an aligned 8-byte word.  Otherwise (k = 91) three groups in four start at an odd 2- or
+      //      4-byte boundary: when the wave's 256 gradients form ONE contiguous run (no pixel / level / image boundary inside: the pitch of a
+      //      pixel is padded), lane L writes the aligned word that starts inside its group - its own tail and the head of lane L+1's group -
+      //      and only the first and the last lane add 2-byte stores; 2-byte stores for every element cost 3x the kernel's arithmetic.
+      const unsigned long long v64 = (unsigned long long)f2bf(g4[0]) | ((unsigned long long)f2bf(g4[1]) << 16) |
+                                     ((unsigned long long)f2bf(g4[2]) << 32) | ((unsigned long long)f2bf(g4[3]) << 48);
+      const bool own_run = da[1] == da[0] + 1 && da[2] == da[0] + 2 && da[3] == da[0] + 3;
+      if (lv.fast == 1) {
+        *(unsigned long long*)da[0] = v64;
+      } else {
+        const int lane = threadIdx.x & (WAVE - 1);
+        const unsigned long long a0 = (unsigned long long)da[0];
+        const unsigned long long b0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)a0);
+        const bool full = __ballot(1) == ~0ull;
+        const bool run = full && __all(own_run && a0 == b0 + 8ull * (unsigned long long)lane);
+        if (run) {
+          const int s = (int)((8 - (b0 & 7)) & 7) >> 1;          // first element of the run that starts an aligned word (0..3)
+          if (s == 0) {
+            *(unsigned long long*)da[0] = v64;
+          } else {
+            const unsigned nlo = (unsigned)__shfl_down((int)(unsigned)v64, 1, WAVE), nhi = (unsigned)__shfl_down((int)(unsigned)(v64 >> 32), 1, WAVE);
+            const unsigned long long nxt = ((unsigned long long)nhi << 32) | nlo;
+            if (lane < WAVE - 1) *(unsigned long long*)(da[0] + s) = (v64 >> (16 * s)) | (nxt << (16 * (4 - s)));
+            if (lane == 0)
+              for (int e = 0; e < s; ++e) da[e][0] = f2bf(g4[e]);
+            if (lane == WAVE - 1)
+              for (int e = s; e < 4; ++e) da[e][0] = f2bf(g4[e]);
+          }
+        } else if (own_run && (a0 & 7ull) == 0) {
+          *(unsigned long long*)da[0] = v64;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) da[e][0] = f2bf(g4[e]);
+        }
       }
       continue;
     }
@@ -1229,7 +1304,7 @@ int mi355det_retina_loss_lv(const float* cls_logits, const float* bbox_regressio
     const long long rows_all = (long long)n_images * rows_per_image;
     // 1: every group of four lies in one row and is 8-byte aligned in the level buffers; 2: any k (groups that straddle a row take the general
     // path, unaligned groups store element by element)
-    lv.fast = rows_all * k < (1ll << 31) ? ((k % 4 == 0 && lv.A * k % 4 == 0) ? 1 : 2) : 0;
+    lv.fast = rows_all * k < (1ll << 31) ? ((k % 4 == 0 && lv.A * k % 4 == 0) ? 1 : (k >= 4 ? 2 : 0)) : 0;      // 2: a group of four spans at most two rows
     for (int q = 0; q < lv.nlev; ++q)
       if (lv.fast == 1 && (lv.ld[q] % 4 != 0 || (((uintptr_t)lv.dst[q]) & 7) != 0)) lv.fast = 2;
     lv.dk = focal_div((unsigned)k);

@@ -203,7 +203,7 @@ def test_retina_loss_batched_vs_oracle(golden):
         np.testing.assert_allclose(greg.cpu().numpy(), gr, rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("K", [91, 36])
+@pytest.mark.parametrize("K", [91, 36, 5, 3])
 def test_retina_loss_level_gradients_equal_the_cast_of_the_fp32_gradient(golden, K):
     """mi355det_retina_loss_lv writes the class gradient as bf16 straight into the per-level NHWC buffers of the cls_logits backward
     (channel a*K + c of a pixel): bit-identical to casting the fp32 gradient of mi355det_retina_loss row by row (what the engine did
