@@ -792,17 +792,27 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
     const bool level_out = TGT_MODE == 1 && lv.nlev > 0 && lv.fast && vec && !grad;      // (wave-uniform) bf16 level output, 32-bit index arithmetic
     float g4[4] = {0.f, 0.f, 0.f, 0.f};
     bf16_t* da[4] = {nullptr, nullptr, nullptr, nullptr};                                  // destination of each of the four gradients
-    const bool straddles = level_out && lv.fast == 2 && (unsigned)i0 - fdivu((unsigned)i0, lv.dk) * (unsigned)k + 3u >= (unsigned)k;
-    if (straddles) {
-      // ---- k % 4 != 0 (the 91-class head): a group that straddles two rows.  13 % of the groups at k = 91 - through the general path below
-      //      (64-bit divisions, per-element bookkeeping) they cost more than all the others together (1.19 ms for 175 M logits against
-      //      2.2 ms for the 1.16 G of the 1204-class head).  Same 32-bit index arithmetic as the one-row path, per element; sfl() as there.
+    if (level_out) {
+      // ---- training fast path (mi355det_retina_loss_lv): 32-bit index arithmetic with multiply-shift divisions, the t = 0 form of the loss
+      //      for groups that do not contain a label (all but one group in 301 at K = 1204); the general path below spends ~100 instructions
+      //      per element on 64-bit divisions and per-element bookkeeping.  k % 4 != 0 (the 91-class head): a group may straddle two rows
+      //      (13 % of the groups at k = 91); those lanes fetch the state of the second row too, and ALL lanes run the same four loss
+      //      evaluations - as a separate branch the straddling groups made every wave execute both branches (1.05 ms for 175 M logits
+      //      against 2.2 ms for the 1.16 G of the 1204-class head).
       const unsigned iu = (unsigned)i0;
       const unsigned r0 = fdivu(iu, lv.dk), c0 = iu - r0 * (unsigned)k;
+      const bool straddles = lv.fast == 2 && c0 + 3u >= (unsigned)k;
       const float4 v = *(const float4*)(x + i0);
       const float xs[4] = {v.x, v.y, v.z, v.w};
+      bf16_t* drow[2];
+      long long mi2[2], lab2[2];
+      float wimg2[2];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
+        if (half == 1 && !straddles) {
+          drow[1] = drow[0]; mi2[1] = mi2[0]; lab2[1] = lab2[0]; wimg2[1] = wimg2[0];
+          break;
+        }
         const unsigned ru = r0 + half;
         const unsigned bu = fdivu(ru, lv.drpi), rl = ru - bu * lv.drpi.d;
         unsigned st0 = 0, px = (unsigned)lv.pixels[0];
@@ -814,79 +824,45 @@ __global__ __launch_bounds__(NT) void focal_kernel(const float* __restrict__ x, 
             st0 = (unsigned)lv.start[l]; px = (unsigned)lv.pixels[l]; base = lv.dst[l]; ldq = lv.ld[l];
           }
         const unsigned local = rl - st0, pix = fdivu(local, lv.da);
-        bf16_t* drow = base + ((size_t)bu * px + pix) * (size_t)ldq + (size_t)(local - pix * lv.da.d) * k;
-        const long long mi = matched[ru];
-        const float wimg = nfg ? inv_images / fmaxf(1.f, nfg[bu]) : 1.f;
-        const long long lab = mi >= 0 ? gt_labels[mi + (gt_off ? gt_off[bu] : 0)] : -1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool first = c0 + e < (unsigned)k;
-          if (first != (half == 0)) continue;
-          const unsigned cu = first ? c0 + e : c0 + e - (unsigned)k;
-          float g = 0.f;
-          if (mi != -2) {
-            const float sc = scale ? scale[cu] : 1.0f;
-            float l;
-            sfl(sc * xs[e], lab == (long long)cu ? 1.0f : 0.0f, alpha, gamma, l, g);
-            acc += l * wimg;
-            g *= sc * gscale * wimg;
-          }
-          g4[e] = g;
-          da[e] = drow + cu;
-        }
+        drow[half] = base + ((size_t)bu * px + pix) * (size_t)ldq + (size_t)(local - pix * lv.da.d) * k;
+        mi2[half] = matched[ru];
+        wimg2[half] = nfg ? inv_images / fmaxf(1.f, nfg[bu]) : 1.f;
+        lab2[half] = mi2[half] >= 0 ? gt_labels[mi2[half] + (gt_off ? gt_off[bu] : 0)] : -1;
       }
-    } else if (level_out) {
-      // ---- training fast path (mi355det_retina_loss_lv): one row per group, 32-bit index arithmetic with multiply-shift divisions,
-      //      the t = 0 form of the loss for groups that do not contain the row's label (all but one group in 301 at K = 1204).
-      //      The general path below spends ~100 instructions per element on 64-bit divisions and per-element bookkeeping.
-      const unsigned iu = (unsigned)i0;
-      const unsigned ru = fdivu(iu, lv.dk), cu = iu - ru * (unsigned)k;
-      const unsigned bu = fdivu(ru, lv.drpi), rl = ru - bu * lv.drpi.d;
-      unsigned st0 = 0, px = (unsigned)lv.pixels[0];
-      bf16_t* base = lv.dst[0];
-      int ldq = lv.ld[0];
+      // a label inside the group's column range of either row (BETWEEN_THRESHOLDS rows, mi == -2, have lab == -1)
+      const bool has_label = (lab2[0] >= (long long)c0 && lab2[0] < (long long)c0 + 4) ||
+                             (straddles && lab2[1] >= 0 && lab2[1] + (long long)k < (long long)c0 + 4);
 #pragma unroll
-      for (int l = 1; l < 8; ++l)
-        if (l < lv.nlev && rl >= (unsigned)lv.start[l]) {
-          st0 = (unsigned)lv.start[l]; px = (unsigned)lv.pixels[l]; base = lv.dst[l]; ldq = lv.ld[l];
+      for (int e = 0; e < 4; ++e) {
+        const bool second = c0 + e >= (unsigned)k;             // (never for groups inside one row)
+        const unsigned cu = second ? c0 + e - (unsigned)k : c0 + e;
+        const long long mi = second ? mi2[1] : mi2[0], lab = second ? lab2[1] : lab2[0];
+        const float wimg = second ? wimg2[1] : wimg2[0];
+        da[e] = (second ? drow[1] : drow[0]) + cu;
+        if (mi == -2) continue;                                // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135): gradient 0
+        const float sc = scale ? scale[cu] : 1.0f;
+        float l, g;
+        if (has_label || alpha < 0.0f || gamma != 2.0f) {
+          sfl(sc * xs[e], lab == (long long)cu ? 1.0f : 0.0f, alpha, gamma, l, g);
+        } else {
+          // t = 0, gamma = 2: loss = (1 - alpha) p^2 softplus(x); d/dx = (1 - alpha) p^2 (2 (1 - p) softplus(x) + p).  Same operations as
+          // sfl() would execute with t = 0, in the same order: bit-identical.
+          const float xx = sc * xs[e];
+          const float ee = __expf(-fabsf(xx));
+          const float inv = __builtin_amdgcn_rcpf(1.0f + ee);
+          const float ce = fmaxf(xx, 0.0f) - xx * 0.0f + __logf(1.0f + ee);
+          const float p = xx >= 0.0f ? inv : ee * inv;
+          const float p_t = p * 0.0f + (1.0f - p) * (1.0f - 0.0f);
+          const float q = 1.0f - p_t;
+          const float mf = q * q, dmf = 2.0f * q;
+          const float dpt = (2.0f * 0.0f - 1.0f) * p * (1.0f - p);
+          const float a_t = alpha * 0.0f + (1.0f - alpha) * (1.0f - 0.0f);
+          l = ce * mf * a_t;
+          g = ((p - 0.0f) * mf - ce * dmf * dpt) * a_t;
         }
-      const unsigned local = rl - st0, pix = fdivu(local, lv.da);
-      bf16_t* dst = base + ((size_t)bu * px + pix) * (size_t)ldq + (size_t)(local - pix * lv.da.d) * k + cu;
-      const float4 v = *(const float4*)(x + i0);
-      const float xs[4] = {v.x, v.y, v.z, v.w};
-      const long long mi = matched[ru];
-      if (mi != -2) {                                    // BETWEEN_THRESHOLDS rows are ignored (retinanet.py:135)
-        const float wimg = nfg ? inv_images / fmaxf(1.f, nfg[bu]) : 1.f;
-        const long long lab = mi >= 0 ? gt_labels[mi + (gt_off ? gt_off[bu] : 0)] : -1;
-        const bool has_label = lab >= (long long)cu && lab < (long long)cu + 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sc = scale ? scale[cu + e] : 1.0f;
-          float l, g;
-          if (has_label || alpha < 0.0f || gamma != 2.0f) {
-            sfl(sc * xs[e], lab == (long long)(cu + e) ? 1.0f : 0.0f, alpha, gamma, l, g);
-          } else {
-            // t = 0, gamma = 2: loss = (1 - alpha) p^2 softplus(x); d/dx = (1 - alpha) p^2 (2 (1 - p) softplus(x) + p).  Same operations as
-            // sfl() would execute with t = 0, in the same order: bit-identical.
-            const float xx = sc * xs[e];
-            const float ee = __expf(-fabsf(xx));
-            const float inv = __builtin_amdgcn_rcpf(1.0f + ee);
-            const float ce = fmaxf(xx, 0.0f) - xx * 0.0f + __logf(1.0f + ee);
-            const float p = xx >= 0.0f ? inv : ee * inv;
-            const float p_t = p * 0.0f + (1.0f - p) * (1.0f - 0.0f);
-            const float q = 1.0f - p_t;
-            const float mf = q * q, dmf = 2.0f * q;
-            const float dpt = (2.0f * 0.0f - 1.0f) * p * (1.0f - p);
-            const float a_t = alpha * 0.0f + (1.0f - alpha) * (1.0f - 0.0f);
-            l = ce * mf * a_t;
-            g = ((p - 0.0f) * mf - ce * dmf * dpt) * a_t;
-          }
-          acc += l * wimg;
-          g4[e] = g * (sc * gscale * wimg);
-        }
+        acc += l * wimg;
+        g4[e] = g * (sc * gscale * wimg);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) da[e] = dst + e;
     }
     if (level_out) {
       // ---- stores.  k % 4 == 0: every group is an aligned 8-byte word.  Otherwise (k = 91) three groups in four start at an odd 2- or
