@@ -360,6 +360,26 @@ int mi355det_conv_fwd_ex(const mi355det_conv_shape* s, const void* x, const void
 /* plan-build helper (synchronises; never part of the step): while the mode is on, mi355det_conv_fwd / _dgrad time
  * their candidate tile configurations on the caller's buffers and remember the fastest per shape. */
 int mi355det_conv_autotune_mode(int on);
+
+/* ---- tune record.  The plan build of both engines (yolo/nets/engine.py:_autotune, tvision/engine.py:_autotune; reference: none - the
+ * reference lets cuDNN pick its algorithms per process, torch.backends.cudnn.benchmark, yolo/main.py) chooses by TIMING: the tile configuration
+ * of every implicit-GEMM shape, the form of the stride-2 data gradient, the split count of every weight gradient.  Each choice fixes a
+ * summation order, so the numbers of a step depend on it.  The record makes the choices data:
+ *   export   copies the current choices as 16-byte entries sorted by (table, key) into buf (if cap suffices); returns the bytes needed
+ *   import   adds (replace = 0) or replaces (1) the choices from a record
+ *   lock     on = 1: a shape that HAS an entry is never timed again (plan builds reuse the record; shapes without an entry are timed and
+ *            added as before); returns the previous state
+ *   clear    drops every choice and the lock (the next plan build times everything)
+ * Host mirror: object_detectors_amd/tune.py (JSON files, MI355DET_TUNE_SAVE / MI355DET_TUNE_LOAD, rank-0 broadcast for N > 1). */
+typedef struct {
+  uint32_t table;   /* 0 implicit-GEMM tile configuration, 1 stride-2 data-gradient form, 2 weight-gradient split count */
+  int32_t value;
+  uint64_t key;     /* shape key of that table */
+} mi355det_tune_entry;
+size_t mi355det_tune_export(void* buf, size_t cap);
+int mi355det_tune_import(const void* buf, size_t bytes, int replace);
+int mi355det_tune_lock(int on);
+int mi355det_tune_clear(void);
 /* number of rows of the `stats` partial buffer [rows][2][cout_pad] the forward writes (one per pixel tile);
  * allocate rows+64: bn_finalize uses the 64 spare rows as scratch for its two-stage reduction */
 int mi355det_conv_stats_rows(const mi355det_conv_shape* s, int32_t cout_pad);
@@ -490,11 +510,9 @@ int mi355det_unpack_wgrad(const mi355det_conv_shape* s, const float* dw, float* 
  *   bn_act_bwd_apply: dz = scale*(dy - mean(dy) - xhat*mean(dy*xhat))  (bf16)
  * Limits and reproducibility:
  *   - c must be a multiple of 8 everywhere (MI355DET_EINVAL otherwise);
- *   - bn_act_bwd_reduce finishes every workgroup with one fp32 atomicAdd per channel into `sums`, so the two sums - and through them
- *     dz, dgamma, dbeta and everything upstream - differ from run to run in the last bits (measured ~6e-4 of max on the final
- *     gradient of a 75-layer step).  Ranks stay in sync (the all-reduce result is the same on every rank).  The plain-store
- *     alternative is mi355det_conv_dgrad_bn + mi355det_bn_bwd_sum_partials (fixed order, ~2.5 % slower on the step;
- *     the engine selects it with MI355DET_BN_FUSION=1). */
+ *   - bn_act_bwd_reduce (legacy form) finishes every workgroup with one fp32 atomicAdd per channel into `sums`, so the two sums - and
+ *     through them dz, dgamma, dbeta and everything upstream - differ from run to run in the last bits (measured ~6e-4 of max on the
+ *     final gradient of a 75-layer step).  mi355det_bn_act_bwd_reduce_det below is the fixed-order form the engines use. */
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count,
                          const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var,
@@ -519,6 +537,15 @@ int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, i
 int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
                                int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,
                                float slope, float* sums /* [2*c] zeroed by caller */, void* stream);
+/* Fixed-order form of the same sums (the engines' default since round 4; reference: torch's batch_norm_backward is deterministic too,
+ * yolo/nets/backbone/darknet.py:15-16): every workgroup stores its partial sums as one row of `workspace`, the last one to arrive (ticket
+ * per channel slab, agent-scope release / acquire) adds the rows in row order and WRITES sums[2*c] (no zeroing needed).  workspace:
+ * mi355det_bn_act_bwd_reduce_workspace(c, pixels) bytes, 16-byte aligned, its first 1024 bytes (the tickets) zeroed ONCE by the caller -
+ * the kernel resets them; launches sharing a workspace must be ordered on one stream.  Bit-reproducible from run to run. */
+size_t mi355det_bn_act_bwd_reduce_workspace(int32_t c, int64_t pixels);
+int mi355det_bn_act_bwd_reduce_det(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
+                                   int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,
+                                   float slope, float* sums, void* workspace, size_t workspace_bytes, void* stream);
 int mi355det_bn_act_bwd_apply(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
                               int32_t z_ld, const float* scale_shift, const float* sums, const float* gamma,
                               int32_t c, int64_t pixels, float slope, void* dz, int32_t dz_ld,

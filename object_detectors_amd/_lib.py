@@ -105,6 +105,10 @@ PROTOTYPES = {
     "mi355det_pack_weights_batched": (C.c_int, [vp, i32, i32, vp]),
     "mi355det_unpack_wgrad": (C.c_int, [P(ConvShape), vp, vp, vp]),
     "mi355det_conv_autotune_mode": (C.c_int, [C.c_int]),
+    "mi355det_tune_export": (sz, [vp, sz]),
+    "mi355det_tune_import": (C.c_int, [vp, sz, C.c_int]),
+    "mi355det_tune_lock": (C.c_int, [C.c_int]),
+    "mi355det_tune_clear": (C.c_int, []),
     "mi355det_conv_stats_rows": (C.c_int, [P(ConvShape), i32]),
     "mi355det_stem_im2col": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "mi355det_stem_rows": (C.c_int, [i32, i32, i32]),
@@ -143,6 +147,8 @@ PROTOTYPES = {
     "mi355det_add_bf16": (C.c_int, [vp, i32, vp, i32, i32, i64, vp, i32, vp]),
     "mi355det_bn_act_fwd": (C.c_int, [vp, i32, vp, i32, i64, f32, vp, i32, vp, i32, vp]),
     "mi355det_bn_act_bwd_reduce": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, f32, vp, vp]),
+    "mi355det_bn_act_bwd_reduce_workspace": (sz, [i32, i64]),
+    "mi355det_bn_act_bwd_reduce_det": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i64, f32, vp, vp, sz, vp]),
     "mi355det_bn_act_bwd_apply": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i64, f32, vp, i32, vp, vp, vp]),
     "mi355det_upsample2x_fwd": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "mi355det_upsample2x_bwd": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),

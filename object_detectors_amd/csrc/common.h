@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "../../include/mi355det.h"
 
@@ -72,15 +73,22 @@ __device__ __forceinline__ float ord2f(unsigned u) {
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
 // one-time-per-DEVICE guard for hipFuncSetAttribute: the attribute lives in the device's copy of the code object, so a process that uses a
-// second GPU must set it there too (a process-wide flag left kernels with > 64 KB of dynamic LDS unlaunchable on cuda:1); atomic, so two
-// host threads may race through it
+// second GPU must set it there too (a process-wide flag left kernels with > 64 KB of dynamic LDS unlaunchable on cuda:1).  The device's bit is
+// published only AFTER the attributes are set (a second host thread that raced past a bit set up front could launch before the attribute
+// applied: ADVICE r3); racing first callers serialise on the mutex, later calls are one relaxed-cost acquire load.
 struct DeviceOnce {
-  std::atomic<unsigned long long> mask{0};
-  bool first() {
+  std::atomic<unsigned long long> done{0};
+  std::mutex mu;
+  template <class F>
+  void once(F&& f) {
     int d = 0;
     (void)hipGetDevice(&d);
     const unsigned long long b = 1ull << (d & 63);
-    return (mask.fetch_or(b) & b) == 0;
+    if (done.load(std::memory_order_acquire) & b) return;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.load(std::memory_order_relaxed) & b) return;
+    f();
+    done.fetch_or(b, std::memory_order_release);
   }
 };
 

@@ -20,6 +20,8 @@
 
 #include <unordered_map>
 
+#include "tune_record.h"
+
 using namespace mi355;
 
 #include "igemm_common.h"
@@ -827,9 +829,9 @@ int launch_cfg(const IgemmParams& p_in, hipStream_t st) {
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
   auto k = igemm_kernel<WM, WN, TM, TN, BK, NST, EPI, PROF, ILV, OCC, ABL>;
   static DeviceOnce attr_done;
-  if (attr_done.first()) {
+  attr_done.once([&] {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
+  });
   hipLaunchKernelGGL(k, dim3(gm * gn * (p.ksplit > 1 ? p.ksplit : 1)), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm");
 }
@@ -843,15 +845,32 @@ int launch_il(const IgemmParams& p, hipStream_t st) {
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
   auto k = igemm_il_kernel<WM, WN, TM, TN, BK, EPI, SCHED>;
   static DeviceOnce attr_done;
-  if (attr_done.first()) {
+  attr_done.once([&] {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
+  });
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm_il");
 }
 
+// a pair of timing events destroyed on every exit path (the tuning helpers return early on launch errors)
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = false;
+  EventPair() {
+    if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+    if (hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+    ok = true;
+  }
+  ~EventPair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+  EventPair(const EventPair&) = delete;
+  EventPair& operator=(const EventPair&) = delete;
+};
+
 int g_tune = 0;   // bring-up knob (mi355det_debug_set(0, v)): forces a tile configuration
-std::unordered_map<unsigned long long, int> g_igemm_tuned;   // shape key -> configuration found by mi355det_conv_autotune
+TuneMap& g_igemm_tuned = tune_table(TUNE_IGEMM);   // shape key -> configuration found by mi355det_conv_autotune (part of the tune record)
 
 unsigned long long igemm_key(const IgemmParams& p, int epi) {
   unsigned long long k = (unsigned long long)p.M;
@@ -892,9 +911,9 @@ int launch_dx(const IgemmParams& p_in, hipStream_t st) {
   const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / BN;
   auto k = igemm_dx_kernel<WM, WN, TM, TN, EPI, NSTB, PROF, BK>;
   static DeviceOnce attr_done;
-  if (attr_done.first()) {
+  attr_done.once([&] {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
+  });
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(WM * WN * 64), lds, st, p);
   return check_launch("igemm_dx");
 }
@@ -976,12 +995,14 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // plan-build helper: time the candidate configurations of one launch and remember the fastest
 template <int EPI>
 int autotune_igemm(const IgemmParams& p, hipStream_t st) {
+  if (tune_locked_has(TUNE_IGEMM, igemm_key(p, EPI))) return launch_igemm<EPI>(p, st);      // the choice came from a tune record: not timed again
   const bool narrow32 = p.CoutPad % 128 != 0 && p.CoutPad % 64 == 0 && p.Cin % 64 != 0 && dx_applicable(p, 64, 32);      // 32 -> 64 @320
   if (narrow32 || (p.CoutPad % 128 != 0 && p.Cin % 64 == 0 && (p.CoutPad % 64 == 0 ? dx_applicable(p, 64) : dx_applicable(p, 32)))) {
     // narrow output: plain tile (id 0) against the shared-pixel-tile kernel (id 30 / 29; 31 = its 32-deep k-step for 32 input channels)
     const int alt = narrow32 ? 31 : (p.CoutPad % 64 == 0 ? 30 : 29);
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
+    EventPair ev;
+    if (!ev.ok) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     float best_ms = 1e30f;
     int best = 0;
     for (int cfg : {0, alt}) {
@@ -999,14 +1020,13 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
         best = cfg;
       }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     g_igemm_tuned[igemm_key(p, EPI)] = best;
     return best;
   }
   if (!(p.CoutPad % 128 == 0 && p.Cin % 64 == 0)) return launch_igemm<EPI>(p, st);   // nothing to choose: a plain launch, the output stays valid
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
+  EventPair ev;
+  if (!ev.ok) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_autotune");
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   int best = 1;
   float best_ms = 1e30f;
   const int cands[] = {1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28, 40};     // 35 (BK 32, 3 workgroups per CU) measured slower: not tried
@@ -1032,8 +1052,6 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
       best = cfg;
     }
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   g_igemm_tuned[igemm_key(p, EPI)] = best;
   static const bool tune_log = getenv("MI355DET_TUNE_LOG") != nullptr;
   if (tune_log) fprintf(stderr, "[mi355det] igemm tune: M=%d Cout=%d Cin=%d T=%d epi=%d -> cfg %d (%.1f us)\n", p.M, p.CoutPad, p.Cin, p.T, EPI, best, best_ms * 1e3f / 3.f);
@@ -1061,7 +1079,7 @@ __global__ __launch_bounds__(256) void lattice_fill_kernel(bf16_t* __restrict__ 
 }
 
 bool g_autotune_mode = false;   // set by mi355det_conv_autotune around a regular entry-point call
-std::unordered_map<unsigned long long, int> g_s2cat_tuned;   // stride-2 data gradient: 1 = class-concatenated form, 0 = four class launches
+TuneMap& g_s2cat_tuned = tune_table(TUNE_S2CAT);   // stride-2 data gradient: 1 = class-concatenated form, 0 = four class launches (tune record)
 int g_s2cat_force = -1;          // mi355det_debug_set(5, v): force a form (tests compare the two)
 
 template <int EPI>
@@ -1483,10 +1501,13 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
       }
       return 0;
     };
-    if (g_autotune_mode && g_s2cat_force < 0) {
+    if (g_autotune_mode && g_s2cat_force < 0 && !tune_locked_has(TUNE_S2CAT, key)) {
       // time both forms (each tunes its own tiles first); the output stays valid either way
-      hipEvent_t e0, e1;
-      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_dgrad");
+      // (outputs are scratch while tuning: with an in-place residual (residual == dx) the timing runs accumulate into dx; both engines discard
+      //  the outputs of their tuning pass)
+      EventPair ev;
+      if (!ev.ok) return fail(MI355DET_ELAUNCH, "%s: event create failed", "conv_dgrad");
+      hipEvent_t e0 = ev.e0, e1 = ev.e1;
       float ms[2] = {0.f, 0.f};
       for (int form = 0; form < 2; ++form) {
         g_s2cat_force = form;
@@ -1503,8 +1524,6 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
         g_s2cat_force = -1;
         if (e) return e;
       }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
       choice = ms[1] < ms[0] ? 1 : 0;
       g_s2cat_tuned[key] = choice;
       static const bool tune_log = getenv("MI355DET_TUNE_LOG") != nullptr;

@@ -228,9 +228,9 @@ int launch(const DgradS2Params& p, int cin, hipStream_t st) {
   const int gx = min(p.ntiles, max(1, 256 * per_cu / (cin / 32)));   // persistent: one resident round over both channel halves
   auto go = [&](auto kern) {
     static DeviceOnce attr_done;
-    if (attr_done.first()) {
+    attr_done.once([&] {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
+    });
     hipLaunchKernelGGL(kern, dim3(gx, cin / 32), dim3(256), lds, st, p);
   };
   if (p.res) go(dgrad_s2_kernel<TP, NCH, true>);

@@ -290,8 +290,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 // (256/(c/8)) pixel lanes; partial sums combined in LDS, then one atomic per channel per block.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ g1, int g1_ld, const bf16_t* __restrict__ g2, int g2_ld,
                                                             const bf16_t* __restrict__ z, int z_ld, const float* __restrict__ ss, int c,
-                                                            long long pixels, float slope, float* __restrict__ sums, int pix_per_block, int groups) {
-  __shared__ float red[256][17];
+                                                            long long pixels, float slope, float* __restrict__ sums, int pix_per_block, int groups,
+                                                            float* __restrict__ part, unsigned* __restrict__ ticket) {
+  __shared__ __attribute__((aligned(16))) float red[256][17];
   // groups = 8-channel groups per workgroup (power of two <= 256); blockIdx.y picks the channel slab when c/8 > groups
   const int gl = threadIdx.x % groups, pl = threadIdx.x / groups, npl = 256 / groups;
   const int cbase = blockIdx.y * groups * 8;
@@ -344,12 +345,69 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
   __syncthreads();
   // thread t < 2*cb handles (which = t / cb, channel = t % cb) of this workgroup's cb = groups*8 channels
   const int cb = groups * 8;
+  // Fixed-order form (part != null; the default of both engines since round 4): every workgroup stores its 2 * cb sums as one row of
+  // `part`, takes a ticket, and the workgroup that arrives LAST for its channel slab adds the rows in row order and writes `sums` - the
+  // result does not depend on the order in which workgroups finish, so the step's gradients are bit-reproducible (the atomic form below
+  // differed by ~6e-4 of max from run to run).  Visibility follows MI355X_MICROARCH.md "Valid forms": plain stores, every storing wave
+  // drained, workgroup barrier, one lane's agent-scope release before the ticket; the last arriver's agent-scope acquire, drained, barrier,
+  // then plain loads.  The ticket is reset by the last arriver: launches that share a workspace must be stream-ordered.
+  float* prow = part ? part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(2 * cb) : nullptr;
   for (int t = threadIdx.x; t < 2 * cb; t += 256) {
     const int which = t / cb, ch = t - which * cb;
     const int gi = ch >> 3, k = ch & 7;
     float s = 0.f;
     for (int p2 = 0; p2 < npl; ++p2) s += red[p2 * groups + gi][which * 8 + k];
-    if (cbase + ch < c) atomicAdd(sums + which * c + cbase + ch, s);
+    if (part) prow[t] = s;
+    else if (cbase + ch < c) atomicAdd(sums + which * c + cbase + ch, s);
+  }
+  if (!part) return;
+  __shared__ unsigned last_flag;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = old == gridDim.x - 1 ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next (stream-ordered) launch
+    }
+    last_flag = last;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // 2 * cb <= 256 columns: thread (rg, col4) adds the rows rg, rg + RG, ... of four adjacent columns, 8 loads in flight; the RG row
+  // groups are then combined in LDS in group order
+  const int ncol4 = (2 * cb) >> 2;                 // float4 columns per row (4 .. 64)
+  const int RG = 256 / ncol4;                      // row groups
+  const int col4 = threadIdx.x % ncol4, rg = threadIdx.x / ncol4;
+  const int nb = gridDim.x;
+  const float4* base = (const float4*)(part + (size_t)blockIdx.y * nb * (size_t)(2 * cb)) + col4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int r = rg;
+  for (; r + 7 * RG < nb; r += 8 * RG) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * RG) * ncol4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+    }
+  }
+  for (; r < nb; r += RG) {
+    const float4 v = base[(size_t)r * ncol4];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float* fold = &red[0][0];                        // [RG][2 * cb] floats <= 256 * 4 (red holds 256 * 17)
+  *(float4*)(fold + (size_t)rg * (2 * cb) + col4 * 4) = acc;
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * cb; t += 256) {
+    float s = 0.f;
+    for (int g = 0; g < RG; ++g) s += fold[g * (2 * cb) + t];
+    const int which = t / cb, ch = t - which * cb;
+    if (cbase + ch < c) sums[which * c + cbase + ch] = s;
   }
 }
 
@@ -759,28 +817,67 @@ int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, i
   return check_launch("bn_act_fwd");
 }
 
+namespace {
+struct BnReduceGeom {
+  int gb, slabs, blocks;
+  long long ppb;
+};
+BnReduceGeom bn_reduce_geom(int c, long long pixels) {
+  // a workgroup covers at most 64-128 channels (whole 128-byte lines per pixel) and more pixels instead: every workgroup ends with
+  // 2 * (its channels) partial sums (one row of the workspace, or float atomics in the legacy form: ~24 G atomics/s device-wide measured),
+  // so wide layers are cut into channel slabs (blockIdx.y) and large tensors get no more than ~2 workgroups per CU
+  // (any multiple of 8 channels: the last slab of a channel count that is not gb * 8 * k has idle channel groups)
+  const int groups = c / 8;
+  BnReduceGeom g;
+  g.gb = groups >= 32 ? 16 : (groups > 8 ? 8 : 1);
+  while (g.gb * 2 <= groups && g.gb < 8) g.gb *= 2;
+  g.slabs = (groups + g.gb - 1) / g.gb;
+  const int npl = 256 / g.gb;
+  g.ppb = (long long)npl * 32;   // 32 pixels per pixel-lane
+  long long blocks = (pixels + g.ppb - 1) / g.ppb;
+  const long long cap = 512 / g.slabs > 64 ? 512 / g.slabs : 64;
+  if (blocks > cap) {
+    g.ppb = ((pixels + cap - 1) / cap + npl * 4 - 1) / (npl * 4) * (npl * 4);
+    blocks = (pixels + g.ppb - 1) / g.ppb;
+  }
+  g.blocks = (int)blocks;
+  return g;
+}
+constexpr size_t kBnTicketBytes = 1024;      // 256 channel slabs
+}  // namespace
+
+size_t mi355det_bn_act_bwd_reduce_workspace(int32_t c, int64_t pixels) {
+  if (c <= 0 || c % 8 != 0 || pixels <= 0) return 0;
+  const BnReduceGeom g = bn_reduce_geom(c, pixels);
+  return kBnTicketBytes + (size_t)g.slabs * g.blocks * (size_t)(2 * g.gb * 8) * sizeof(float);
+}
+
+static int bn_reduce_launch(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift, int32_t c,
+                            int64_t pixels, float slope, float* sums, void* workspace, size_t workspace_bytes, void* stream, const char* what) {
+  if (c <= 0 || c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8 (got c=%lld)", what, c);
+  const BnReduceGeom g = bn_reduce_geom(c, pixels);
+  float* part = nullptr;
+  unsigned* ticket = nullptr;
+  if (workspace) {
+    if (g.slabs * sizeof(unsigned) > kBnTicketBytes || workspace_bytes < mi355det_bn_act_bwd_reduce_workspace(c, pixels) || ((uintptr_t)workspace & 15))
+      return fail(MI355DET_EINVAL, "%s: workspace too small or misaligned (%lld bytes given)", what, (long long)workspace_bytes);
+    ticket = (unsigned*)workspace;
+    part = (float*)((char*)workspace + kBnTicketBytes);
+  }
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks, g.slabs), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2, g2_ld,
+                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)g.ppb, g.gb, part, ticket);
+  return check_launch(what);
+}
+
 int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift,
                                int32_t c, int64_t pixels, float slope, float* sums, void* stream) {
-  const int groups = c / 8;
-  if (c <= 0 || c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8 (got c=%lld)", "bn_act_bwd_reduce", c);
-  // a workgroup covers at most 64-128 channels (whole 128-byte lines per pixel) and more pixels instead: every workgroup ends with
-  // 2 * (its channels) float atomics, ~24 G atomics/s device-wide measured (410 k of them are 17 us), so wide layers are cut into
-  // channel slabs (blockIdx.y) and large tensors get no more than ~2 workgroups per CU
-  // (any multiple of 8 channels: the last slab of a channel count that is not gb * 8 * k has idle channel groups)
-  int gb = groups >= 32 ? 16 : (groups > 8 ? 8 : 1);
-  while (gb * 2 <= groups && gb < 8) gb *= 2;
-  const int slabs = (groups + gb - 1) / gb;
-  const int npl = 256 / gb;
-  long long ppb = (long long)npl * 32;   // 32 pixels per pixel-lane
-  long long blocks = (pixels + ppb - 1) / ppb;
-  const long long cap = 512 / slabs > 64 ? 512 / slabs : 64;
-  if (blocks > cap) {
-    ppb = ((pixels + cap - 1) / cap + npl * 4 - 1) / (npl * 4) * (npl * 4);
-    blocks = (pixels + ppb - 1) / ppb;
-  }
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks, slabs), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2, g2_ld,
-                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)ppb, gb);
-  return check_launch("bn_act_bwd_reduce");
+  return bn_reduce_launch(g1, g1_ld, g2, g2_ld, z, z_ld, scale_shift, c, pixels, slope, sums, nullptr, 0, stream, "bn_act_bwd_reduce");
+}
+
+int mi355det_bn_act_bwd_reduce_det(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift,
+                                   int32_t c, int64_t pixels, float slope, float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!workspace) return fail(MI355DET_EINVAL, "%s: null workspace", "bn_act_bwd_reduce_det");
+  return bn_reduce_launch(g1, g1_ld, g2, g2_ld, z, z_ld, scale_shift, c, pixels, slope, sums, workspace, workspace_bytes, stream, "bn_act_bwd_reduce_det");
 }
 
 int mi355det_bn_act_bwd_apply(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift,

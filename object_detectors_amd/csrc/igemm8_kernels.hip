@@ -474,20 +474,20 @@ int launch8(const IgemmParams& p, hipStream_t st) {
     // diagnostic builds (tools/prof_ig8.py): [64 workgroups][8 waves][24] u64; mode 1 = phase stamps, 2 = k-step starts only
     sk.dbg = g_sk_dbg;
     static DeviceOnce attr_done_p;
-    if (attr_done_p.first()) {
+    attr_done_p.once([&] {
       (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
       (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-    }
+    });
     if (g_sk_dbg_mode >= 3) {
       static DeviceOnce attr_done_a;
-      if (attr_done_a.first()) {
+      attr_done_a.once([&] {
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
         (void)hipFuncSetAttribute((const void*)igemm8_kernel<EPI_STATS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-      }
+      });
       if (g_sk_dbg_mode == 3) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 3>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       else if (g_sk_dbg_mode == 4) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 4>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
       else if (g_sk_dbg_mode == 6) hipLaunchKernelGGL((igemm8_kernel<EPI_STATS, 6>), dim3(gm * gn), dim3(512), kLDS, st, p, sk);
@@ -502,9 +502,9 @@ int launch8(const IgemmParams& p, hipStream_t st) {
   }
   auto k = igemm8_kernel<EPI>;
   static DeviceOnce attr_done;
-  if (attr_done.first()) {
+  attr_done.once([&] {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
-  }
+  });
   hipLaunchKernelGGL(k, dim3(gm * gn), dim3(512), kLDS, st, p, sk);
   return check_launch("igemm8");
 }

@@ -934,9 +934,9 @@ int mi355det_topk(const float* x, int32_t rows, int64_t n, int64_t row_stride, i
   if (rows <= 0 || n <= 0 || k <= 0 || k > TOPK_MAXK || n >= (1ll << 32)) return fail(MI355DET_EINVAL, "%s: need 1 <= k <= 16384 and n < 2^32", "topk");
   const int lds = TOPK_MAXK * 8;
   static DeviceOnce attr_done;
-  if (attr_done.first()) {
+  attr_done.once([&] {
     (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
+  });
   hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(TOPK_THREADS), lds, S(stream), x, (long long)n, (long long)row_stride, k, min_value,
                      (long long*)idx_out, val_out, count_out);
   return check_launch("topk");
@@ -961,10 +961,10 @@ int mi355det_topk_ws(const float* x, int32_t rows, int64_t n, int64_t row_stride
   hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(1024), 0, st, x, (long long)n, (long long)row_stride, k, min_value, states, cand);
   const int lds = TOPK_MAXK * 8;
   static DeviceOnce attr_done;
-  if (attr_done.first()) {
+  attr_done.once([&] {
     (void)hipFuncSetAttribute((const void*)topk_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
+  });
   hipLaunchKernelGGL(topk_finish_kernel, dim3(rows), dim3(TOPK_THREADS), lds, st, k, states, cand, (long long*)idx_out, val_out, count_out);
   // rows whose threshold value repeats more often than the candidate list holds: exact redo by the one-workgroup form (exits at once otherwise)
   hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(TOPK_THREADS), lds, st, x, (long long)n, (long long)row_stride, k, min_value, (long long*)idx_out,
@@ -999,7 +999,7 @@ int mi355det_topk_segments(const float* x, int32_t rows, int64_t row_stride, int
   if (ns == 0) return 0;
   const int lds = TOPK_MAXK * 8;
   static DeviceOnce attr_done;
-  if (attr_done.first()) (void)hipFuncSetAttribute((const void*)topk_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  attr_done.once([&] { (void)hipFuncSetAttribute((const void*)topk_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
   hipLaunchKernelGGL(topk_seg_kernel, dim3(rows, ns), dim3(TOPK_THREADS), lds, S(stream), x, (long long)row_stride, G, min_value);
   return check_launch("topk_segments");
 }

@@ -344,7 +344,7 @@ static int stem_l1_impl(const float* img, const void* w0, const float* scale_shi
   p.slope = slope;
   constexpr int lds = 2 * IMG_BYTES + A_BYTES + 64 * 16 + 128 * 4;
   static DeviceOnce once;
-  if (once.first()) (void)hipFuncSetAttribute((const void*)stem_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  once.once([&] { (void)hipFuncSetAttribute((const void*)stem_l1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
   hipLaunchKernelGGL(stem_l1_kernel, dim3(l1_grid(p.ntiles)), dim3(256), lds, S(stream), p);
   return check_launch("stem_l1_fwd");
 }

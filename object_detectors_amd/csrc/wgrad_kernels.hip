@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <unordered_map>
 
+#include "tune_record.h"
+
 using namespace mi355;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -590,7 +592,7 @@ int choose_splits(int tiles, int M, double out_bytes) {
   return sp;
 }
 
-std::unordered_map<unsigned long long, int> g_wgrad_tuned;   // shape key -> split count found by mi355det_conv_autotune
+TuneMap& g_wgrad_tuned = tune_table(TUNE_WGRAD);   // shape key -> split count found by mi355det_conv_autotune (part of the tune record)
 int g_wgrad_force = 0;
 
 unsigned long long wgrad_key(const mi355det_conv_shape* s) {
@@ -634,6 +636,7 @@ size_t mi355det_conv_wgrad_workspace(const mi355det_conv_shape* s) {
 int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, const void* dy, float* dw, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   if (!s) return fail(MI355DET_EINVAL, "%s: null shape", "wgrad_autotune");
+  if (tune_locked_has(TUNE_WGRAD, wgrad_key(s))) return g_wgrad_tuned[wgrad_key(s)];      // the split came from a tune record: not timed again
   const int M = s->n * s->ho * s->wo;
   const size_t tiles = (size_t)((s->cout + WG_TILE - 1) / WG_TILE) * (size_t)((s->ksize * s->ksize * s->cin + WG_TILE - 1) / WG_TILE);
   const size_t per_split = tiles * WG_TILE * WG_TILE * sizeof(float);

@@ -1,0 +1,145 @@
+"""The tune record: the choices the plan build makes by timing, as data (include/mi355det.h, "tune record").
+
+Both engines choose per convolution shape, at plan-build time and by TIMING the candidates on the plan's own buffers, a tile configuration
+(forward / data gradient), the form of the stride-2 data gradient and the split count of the weight gradient.  Every choice fixes a summation
+order, so the numbers a step produces depend on what was fastest on that box at that moment (the trajectory test's worst
+step moved between 5.8 and 13.7 % across boxes of the pool with identical code).  The reference has the same property only per process
+(`torch.backends.cudnn.benchmark`, yolo/main.py / detection/train.py) and no way to pin it.  Here the choices can be
+
+  * saved   MI355DET_TUNE_SAVE=<file>  or  tune.save(path)      (JSON, one line per choice, sorted: equal records are equal files)
+  * loaded  MI355DET_TUNE_LOAD=<file>  or  tune.load(path)      (locked: a shape that has an entry is never timed again)
+  * shared  tune.sync_from_rank0(group)                         rank 0's record is broadcast and overrides the other ranks' choices: the
+                                                                same kernels, the same speed and the same summation order on every rank
+
+`plan_build(engine_build)` is what the engines wrap around their plan construction; it implements the three behaviours above.
+"""
+import ctypes as C
+import json
+import os
+
+from ._lib import check, lib
+
+ENTRY = 16          # bytes per entry: u32 table, i32 value, u64 key (mi355det_tune_entry)
+TABLES = ("igemm", "s2cat", "wgrad")
+FORMAT = "mi355det-tune-1"
+_env_loaded = False
+
+
+def export_bytes():
+    L = lib()
+    n = L.mi355det_tune_export(None, 0)
+    buf = (C.c_char * max(n, 1))()
+    got = L.mi355det_tune_export(C.cast(buf, C.c_void_p), n)
+    if got != n:
+        raise RuntimeError("tune record changed size during export")
+    return bytes(buf[:n])
+
+
+def import_bytes(raw, replace=False, lock=True):
+    raw = bytes(raw)
+    buf = C.create_string_buffer(raw, len(raw)) if raw else None
+    check(lib().mi355det_tune_import(C.cast(buf, C.c_void_p) if raw else None, len(raw), 1 if replace else 0), "tune_import")
+    if lock:
+        lib().mi355det_tune_lock(1)
+
+
+def lock(on=True):
+    return bool(lib().mi355det_tune_lock(1 if on else 0))
+
+
+def clear():
+    check(lib().mi355det_tune_clear(), "tune_clear")
+
+
+def to_entries(raw):
+    """bytes -> sorted list of (table name, key, value)."""
+    import struct
+    out = []
+    for i in range(0, len(raw), ENTRY):
+        t, v, k = struct.unpack_from("<IiQ", raw, i)
+        out.append((TABLES[t], k, v))
+    return out
+
+
+def from_entries(entries):
+    import struct
+    ents = sorted((TABLES.index(t), int(k), int(v)) for t, k, v in entries)
+    return b"".join(struct.pack("<IiQ", t, v, k) for t, k, v in ents)
+
+
+def dumps(raw=None):
+    raw = export_bytes() if raw is None else raw
+    rows = to_entries(raw)
+    body = ",\n".join('  ["%s", %d, %d]' % r for r in rows)
+    return '{"format": "%s",\n "entries": [\n%s\n]}\n' % (FORMAT, body)
+
+
+def loads(text):
+    d = json.loads(text)
+    if d.get("format") != FORMAT:
+        raise ValueError("not a %s file" % FORMAT)
+    return from_entries(d["entries"])
+
+
+def save(path, raw=None):
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(dumps(raw))
+    os.replace(tmp, path)
+
+
+def load(path, replace=False, lock=True):
+    with open(path) as f:
+        raw = loads(f.read())
+    import_bytes(raw, replace=replace, lock=lock)
+    return raw
+
+
+def sync_from_rank0(group=None, src=0):
+    """Broadcast rank `src`'s record; every other rank imports it (overriding its own choices) and every rank locks.  Collective: every rank of the group calls it at the same point."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return None
+    rank = dist.get_rank(group)
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
+    payload = [export_bytes() if rank == src else None]
+    dist.broadcast_object_list(payload, src=gsrc, group=group)
+    if rank != src:
+        import_bytes(payload[0], replace=False, lock=False)
+    lock(True)            # on every rank, `src` included: a shape of the shared record is never timed again by a later plan build
+    return payload[0]
+
+
+def _dist_world(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def plan_build(build, group=None, share=None):
+    """Run `build()` (an engine's plan construction, which autotunes) under the record policy:
+       - MI355DET_TUNE_LOAD: the file is imported (locked) once per process before the first build: shapes it covers are not timed;
+       - N > 1 (a process group is up; `share=False` or MI355DET_TUNE_SHARE=0 switches it off): every rank builds (the tuning passes may
+         contain the SyncBN collectives, so no rank can wait for another here), then rank 0's record is broadcast and overrides the others':
+         the choices live in the library keyed by shape and are looked up at launch time, so from the first real step on every rank runs the
+         same kernels in the same summation order at the same speed.  Collective: every rank must build the same plans in the same order
+         (training plans do: the reference broadcasts its multi-scale size from rank 0, train_one_epoch.py:15-26);
+       - MI355DET_TUNE_SAVE: the record is written after the build (rank 0 only)."""
+    global _env_loaded
+    if not _env_loaded:
+        _env_loaded = True
+        path = os.environ.get("MI355DET_TUNE_LOAD")
+        if path:
+            load(path, replace=False, lock=True)
+    out = build()
+    rank, world = _dist_world(group)
+    if share is None:
+        share = os.environ.get("MI355DET_TUNE_SHARE", "1") != "0"
+    if world > 1 and share:
+        sync_from_rank0(group)
+    path = os.environ.get("MI355DET_TUNE_SAVE")
+    if path and rank == 0:
+        save(path)
+    return out

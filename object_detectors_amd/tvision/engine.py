@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from .. import _lib, ops
+from .. import _lib, ops, tune
 from .._lib import check, lib
 from ..yolo.nets.engine import Act, comm_hook, _vp
 from .anchor_utils import AnchorGenerator
@@ -258,7 +258,8 @@ class RetinaNetEngine:
             while len(self.plans) >= self.MAX_PLANS:
                 torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
                 self.plans.pop(next(iter(self.plans)))
-            p = RetinaPlan(self, n, H, W, training, key[-1])
+            # (tune.plan_build: MI355DET_TUNE_LOAD / _SAVE; for N > 1 rank 0's timing choices are broadcast - training plans only)
+            p = tune.plan_build(lambda: RetinaPlan(self, n, H, W, training, key[-1]), share=None if training else False)
             if training:
                 for gs in getattr(self, "grad_syncs", ()):       # parallel.GradSync.attach(): every plan gets the bucket hooks
                     gs.install(p)

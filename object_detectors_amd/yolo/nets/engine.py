@@ -17,7 +17,7 @@ import os
 
 import torch
 
-from ... import _lib, ops
+from ... import _lib, ops, tune
 from ..._lib import check, lib
 
 BLOCKS = {"darknet_21": [1, 1, 2, 2, 1], "darknet_53": [1, 2, 8, 8, 4]}
@@ -113,7 +113,8 @@ class YoloV3Engine:
         self.backbone, self.na, self.nc = backbone, num_anchors, num_classes
         self.head_c = num_anchors * (5 + num_classes)
         self.head_ld = ops.pad_to(self.head_c, 32)
-        self._static_epoch = 0          # > 0 while the weights are declared static (freeze_inference): bumped by every change of the parameters
+        self._static_epoch = 1          # version of the parameters / buffers: strictly increasing, bumped by every change and every freeze / unfreeze
+        self._frozen = False            # True while the weights are declared static (freeze_inference)
         self.specs = arch(backbone, num_anchors, num_classes)
         self.by_name = {s.name: s for s in self.specs}
         self._layout_params()
@@ -127,11 +128,11 @@ class YoloV3Engine:
         eval-mode forwards then re-pack the bf16 weights and recompute the 72 folded BatchNorm scale / shift rows only ONCE instead of on
         every batch (0.2 ms + 72 launches).  Any load_* / reset / training forward un-freezes; code that writes `params` / `buffers`
         directly must call `freeze_inference(True)` again (or `False`)."""
-        self._static_epoch = (abs(self._static_epoch) + 1) if on else 0
+        self._static_epoch += 1         # never reused: a plan whose constants were built for an earlier freeze cannot match again
+        self._frozen = bool(on)
 
     def _weights_changed(self):
-        if self._static_epoch:
-            self._static_epoch = abs(self._static_epoch) + 1
+        self._static_epoch += 1
 
     # ------------------------------------------------------------------ parameters
     def _layout_params(self):
@@ -311,7 +312,9 @@ class YoloV3Engine:
             while len(self.plans) >= self.MAX_PLANS:
                 torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
                 self.plans.pop(next(iter(self.plans)))
-            p = Plan(self, n, H, W, training, key[-1])
+            # (tune.plan_build: MI355DET_TUNE_LOAD / _SAVE, and for N > 1 rank 0's timing choices broadcast to every rank - training plans only:
+            #  an evaluation loop may run on a subset of the ranks)
+            p = tune.plan_build(lambda: Plan(self, n, H, W, training, key[-1]), group=None, share=None if training else False)
             if training:
                 for gs in getattr(self, "grad_syncs", ()):       # parallel.GradSync.attach(): every plan gets the bucket hooks
                     gs.install(p)
@@ -625,6 +628,11 @@ class Plan:
         nsum = sum(2 * r["shp"].cout for r in self.ops if r["kind"] == "cbl") + 64
         self.sums_all = torch.zeros(nsum, device=dev, dtype=torch.float32)
         sum_off = [0]
+        # workspace of the fixed-order BatchNorm-backward sums (partial rows + tickets, zeroed once: the kernel resets its tickets); one buffer
+        # for every layer - the reduce launches are ordered on the step's stream
+        red_need = max([L.mi355det_bn_act_bwd_reduce_workspace(r["shp"].cout, r["pixels"]) for r in self.ops if r["kind"] == "cbl"] + [1024])
+        self.bn_red_ws = torch.zeros(red_need, device=dev, dtype=torch.uint8)
+        red_ptr, red_bytes = _vp(self.bn_red_ws), self.bn_red_ws.numel()
 
         def grad_of(a):
             if a.grad is None:
@@ -736,8 +744,8 @@ class Plan:
                     part, prows, cpad = rec["bn_partials"]
                     self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), prows, shp.cout, cpad, _vp(sums), self.stream)))
                 else:
-                    self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
-                                                                    _vp(sums), self.stream)))
+                    self.bwd.append((L.mi355det_bn_act_bwd_reduce_det, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
+                                                                        _vp(sums), red_ptr, red_bytes, self.stream)))
                 if self.sync_world > 1:
                     py(self._sync_avg, sums)              # SyncBN backward: (sum dy, sum dy*xhat) of the global batch
                 if wg_done[di] is not None:
@@ -842,10 +850,10 @@ class Plan:
         if self.training:
             eng._weights_changed()                 # an optimizer step may follow
             self._run(self.pack)
-        elif not (eng._static_epoch > 0 and self._const_epoch == eng._static_epoch):
+        elif not (eng._frozen and self._const_epoch == eng._static_epoch):
             self._run(self.pack)
             self._run(self.fwd_const)
-            self._const_epoch = eng._static_epoch if eng._static_epoch > 0 else -1
+            self._const_epoch = eng._static_epoch if eng._frozen else -1
         self._run(self.fwd)
         if self.training:
             eng.num_batches_tracked += 1

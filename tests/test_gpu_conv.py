@@ -174,6 +174,52 @@ def test_bn_lrelu_fwd_bwd(c, pixels, res):
     np.testing.assert_allclose(db.cpu(), br.grad, rtol=2e-2, atol=2e-2 * br.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("c,pixels", [(8, 70), (32, 4097), (64, 20000), (72, 3333), (256, 9000), (1024, 12800), (512, 200000)])
+def test_bn_bwd_reduce_fixed_order_form(c, pixels):
+    """mi355det_bn_act_bwd_reduce_det (ticket + last-arriver fold, the engines' default): equal to an fp64 evaluation to fp32 accuracy,
+    close to the atomic form, BIT-identical from launch to launch with one workspace reused (the ticket resets itself), and it WRITES
+    `sums` (no zeroing).  Channel counts: powers of two and not (72: a partly empty last slab); pixel counts from one workgroup to the cap."""
+    from object_detectors_amd._lib import check, lib, ptr, stream_ptr
+    d = dev()
+    L = lib()
+    torch.manual_seed(c + pixels)
+    z = torch.randn(pixels, c, device=d).bfloat16()
+    g = (torch.randn(pixels, c, device=d) * 0.1).bfloat16()
+    g2 = (torch.randn(pixels, c, device=d) * 0.1).bfloat16()
+    scale, shift = torch.rand(c, device=d) + 0.5, torch.randn(c, device=d) * 0.3
+    mean, invstd = torch.randn(c, device=d) * 0.1, torch.rand(c, device=d) + 0.5
+    ss = torch.cat([scale, shift, mean, invstd]).contiguous()
+    nbytes = L.mi355det_bn_act_bwd_reduce_workspace(c, pixels)
+    assert nbytes >= 1024
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=d)
+    for second in (None, g2):
+        gg = g.double() + (second.double() if second is not None else 0)
+        if second is not None:
+            gg = (g.float() + second.float()).double()
+        zz = z.double()
+        y = zz * scale.double() + shift.double()
+        dy = torch.where(y > 0, gg, gg * 0.1)
+        want = torch.cat([dy.sum(0), (dy * ((zz - mean.double()) * invstd.double())).sum(0)])
+        outs = []
+        for rep in range(3):
+            sums = torch.full((2 * c,), float("nan"), device=d)          # written, not accumulated
+            check(L.mi355det_bn_act_bwd_reduce_det(ptr(g), c, ptr(second) if second is not None else None, c if second is not None else 0, ptr(z), c,
+                                                    ptr(ss), c, pixels, 0.1, ptr(sums), ptr(ws), nbytes, stream_ptr()), "reduce_det")
+            outs.append(sums.clone())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+        tol = 2e-5 * float((dy.abs().sum(0)).max()) + 1e-6
+        assert float((outs[0].double() - want).abs().max()) < tol
+        atom = torch.zeros(2 * c, device=d)
+        check(L.mi355det_bn_act_bwd_reduce(ptr(g), c, ptr(second) if second is not None else None, c if second is not None else 0, ptr(z), c,
+                                            ptr(ss), c, pixels, 0.1, ptr(atom), stream_ptr()), "reduce")
+        assert float((atom.double() - want).abs().max()) < tol
+    assert int(ws[:1024].view(torch.int32).abs().sum()) == 0              # every ticket is back at zero
+    # too small / missing workspace: EINVAL, nothing launched
+    sums = torch.zeros(2 * c, device=d)
+    with pytest.raises(ValueError):
+        check(L.mi355det_bn_act_bwd_reduce_det(ptr(g), c, None, 0, ptr(z), c, ptr(ss), c, pixels, 0.1, ptr(sums), ptr(ws), 512, stream_ptr()), "reduce_det")
+
+
 def test_upsample_and_layout():
     from object_detectors_amd._lib import check, lib, ptr, stream_ptr
     d = dev()

@@ -1,0 +1,119 @@
+"""The tune record (include/mi355det.h "tune record", object_detectors_amd/tune.py) on the CPU: export / import / lock through the C ABI,
+the JSON file form, the environment policy of `plan_build`, and the rank-0 broadcast over gloo with world size 2.  No kernel runs here:
+the record is host state of the library (what the GPU tests check is that a LOCKED record is honoured by the plan build:
+tests/test_gpu_trajectory.py, tests/test_gpu_conv.py)."""
+import os
+import sys
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REC_A = [("igemm", 123456789012345, 40), ("igemm", 77, 3), ("s2cat", 5, 1), ("wgrad", 99, 24), ("wgrad", 1 << 62, 2)]
+REC_B = [("igemm", 123456789012345, 1), ("wgrad", 99, 8), ("wgrad", 4242, 16)]
+
+
+def test_export_import_roundtrip_and_file_form(tmp_path):
+    from object_detectors_amd import tune
+    tune.clear()
+    assert tune.export_bytes() == b""
+    raw = tune.from_entries(REC_A)
+    tune.import_bytes(raw, replace=True, lock=False)
+    out = tune.export_bytes()
+    assert out == raw and tune.to_entries(out) == sorted(REC_A, key=lambda e: (tune.TABLES.index(e[0]), e[1]))
+    # add (not replace): REC_B overrides the keys it shares and adds its own
+    tune.import_bytes(tune.from_entries(REC_B), replace=False, lock=False)
+    merged = dict(((t, k), v) for t, k, v in REC_A)
+    merged.update(((t, k), v) for t, k, v in REC_B)
+    assert dict(((t, k), v) for t, k, v in tune.to_entries(tune.export_bytes())) == merged
+    # file form: equal records are equal files; load(replace) restores exactly
+    pa, pb = str(tmp_path / "a.json"), str(tmp_path / "b.json")
+    tune.save(pa)
+    tune.save(pb, tune.export_bytes())
+    assert open(pa).read() == open(pb).read()
+    tune.clear()
+    tune.load(pa, replace=True, lock=True)
+    assert dict(((t, k), v) for t, k, v in tune.to_entries(tune.export_bytes())) == merged
+    assert tune.lock(False) is True and tune.lock(False) is False      # load() locked; lock() returns the previous state
+    tune.clear()
+
+
+def test_import_rejects_malformed_records():
+    from object_detectors_amd import tune
+    tune.clear()
+    with pytest.raises(ValueError):
+        tune.import_bytes(b"\x00" * 17)                                 # not a whole number of entries
+    import struct
+    with pytest.raises(ValueError):
+        tune.import_bytes(struct.pack("<IiQ", 9, 1, 1))                 # unknown table
+    with pytest.raises(ValueError):
+        tune.loads('{"format": "something-else", "entries": []}')
+    assert tune.export_bytes() == b""                                    # nothing was imported by the failed calls
+
+
+def test_plan_build_environment_policy(tmp_path, monkeypatch):
+    """MI355DET_TUNE_LOAD is imported (locked) before the first build; MI355DET_TUNE_SAVE is written after every build."""
+    from object_detectors_amd import tune
+    tune.clear()
+    src, dst = str(tmp_path / "in.json"), str(tmp_path / "out.json")
+    tune.save(src, tune.from_entries(REC_A))
+    monkeypatch.setenv("MI355DET_TUNE_LOAD", src)
+    monkeypatch.setenv("MI355DET_TUNE_SAVE", dst)
+    monkeypatch.setattr(tune, "_env_loaded", False)
+    seen = {}
+
+    def build():
+        seen["at_build"] = tune.to_entries(tune.export_bytes())          # the record is already there when the plan is built
+        tune.import_bytes(tune.from_entries([("wgrad", 31337, 12)]), lock=False)      # "the build tuned one more shape"
+        return "plan"
+    assert tune.plan_build(build) == "plan"
+    assert len(seen["at_build"]) == len(REC_A)
+    assert tune.lock(True) is True                                        # the loaded record was locked
+    saved = tune.to_entries(tune.loads(open(dst).read()))
+    assert ("wgrad", 31337, 12) in saved and len(saved) == len(REC_A) + 1
+    tune.clear()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("MI355DET_TUNE_LOAD", None)
+    os.environ.pop("MI355DET_TUNE_SAVE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_detectors_amd import tune
+    tune.clear()
+
+    def build():      # every rank "times" and lands on its own choices (rank 1's differ from rank 0's and it has one extra shape)
+        tune.import_bytes(tune.from_entries(REC_A if rank == 0 else REC_B), lock=False)
+        return rank
+    assert tune.plan_build(build) == rank
+    got = dict(((t, k), v) for t, k, v in tune.to_entries(tune.export_bytes()))
+    locked = tune.lock(True)
+    # eval-style build on ONE rank only (share=False): no collective, must not hang
+    if rank == 1:
+        tune.plan_build(lambda: None, share=False)
+    q.put((rank, got, locked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank0_record_is_broadcast_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want0 = dict(((t, k), v) for t, k, v in REC_A)
+    assert res[0][1] == want0 and res[0][2] is True
+    # rank 1: every shape rank 0 chose is rank 0's choice; its own extra shape stays
+    want1 = dict(((t, k), v) for t, k, v in REC_B)
+    want1.update(want0)
+    assert res[1][1] == want1 and res[1][2] is True

@@ -23,6 +23,9 @@ for c, hw in SHAPES:
     L = lib()
     f = timeit(lambda: check(L.mi355det_bn_act_fwd(ptr(z), c, ptr(ss), c, pixels, 0.1, None, 0, ptr(out), c, stream_ptr())))
     r = timeit(lambda: check(L.mi355det_bn_act_bwd_reduce(ptr(g), c, None, 0, ptr(z), c, ptr(ss), c, pixels, 0.1, ptr(sums), stream_ptr())))
+    nb = L.mi355det_bn_act_bwd_reduce_workspace(c, pixels)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    rd = timeit(lambda: check(L.mi355det_bn_act_bwd_reduce_det(ptr(g), c, None, 0, ptr(z), c, ptr(ss), c, pixels, 0.1, ptr(sums), ptr(ws), nb, stream_ptr())))
     a = timeit(lambda: check(L.mi355det_bn_act_bwd_apply(ptr(g), c, None, 0, ptr(z), c, ptr(ss), ptr(sums), None, c, pixels, 0.1, ptr(out), c, ptr(dg), ptr(db), stream_ptr())))
     e = pixels * c
-    print(f"c={c:5d} @{hw:3d}  {e * 2 / 1e6:7.1f} MB/tensor | fwd {f:7.1f} us {e * 4 / f / 1e6:5.2f} TB/s | reduce {r:7.1f} us {e * 4 / r / 1e6:5.2f} TB/s | apply {a:7.1f} us {e * 6 / a / 1e6:5.2f} TB/s", flush=True)
+    print(f"c={c:5d} @{hw:3d}  {e * 2 / 1e6:7.1f} MB/tensor | fwd {f:7.1f} us {e * 4 / f / 1e6:5.2f} TB/s | reduce (atomics) {r:7.1f} us {e * 4 / r / 1e6:5.2f} TB/s | reduce (fixed order) {rd:7.1f} us {e * 4 / rd / 1e6:5.2f} TB/s | apply {a:7.1f} us {e * 6 / a / 1e6:5.2f} TB/s", flush=True)
