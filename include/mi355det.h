@@ -537,11 +537,10 @@ int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, i
 int mi355det_bn_act_bwd_reduce(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
                                int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,
                                float slope, float* sums /* [2*c] zeroed by caller */, void* stream);
-/* Fixed-order form of the same sums (the engines' default since round 4; reference: torch's batch_norm_backward is deterministic too,
- * yolo/nets/backbone/darknet.py:15-16): every workgroup stores its partial sums as one row of `workspace`, the last one to arrive (ticket
- * per channel slab, agent-scope release / acquire) adds the rows in row order and WRITES sums[2*c] (no zeroing needed).  workspace:
- * mi355det_bn_act_bwd_reduce_workspace(c, pixels) bytes, 16-byte aligned, its first 1024 bytes (the tickets) zeroed ONCE by the caller -
- * the kernel resets them; launches sharing a workspace must be ordered on one stream.  Bit-reproducible from run to run. */
+/* Fixed-order form of the same sums (what the engines use since round 4; reference: torch's batch_norm_backward is deterministic too,
+ * yolo/nets/backbone/darknet.py:15-16): every workgroup stores its partial sums as one row of `workspace`, a second small launch adds the
+ * rows in row order and WRITES sums[2*c] (no zeroing needed).  workspace: mi355det_bn_act_bwd_reduce_workspace(c, pixels) bytes, 16-byte
+ * aligned, no initialisation; launches sharing a workspace must be ordered on one stream.  Bit-reproducible from run to run. */
 size_t mi355det_bn_act_bwd_reduce_workspace(int32_t c, int64_t pixels);
 int mi355det_bn_act_bwd_reduce_det(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z,
                                    int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels,

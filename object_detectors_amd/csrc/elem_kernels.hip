@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ g1, int g1_ld, const bf16_t* __restrict__ g2, int g2_ld,
                                                             const bf16_t* __restrict__ z, int z_ld, const float* __restrict__ ss, int c,
                                                             long long pixels, float slope, float* __restrict__ sums, int pix_per_block, int groups,
-                                                            float* __restrict__ part, unsigned* __restrict__ ticket) {
+                                                            float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float red[256][17];
   // groups = 8-channel groups per workgroup (power of two <= 256); blockIdx.y picks the channel slab when c/8 > groups
   const int gl = threadIdx.x % groups, pl = threadIdx.x / groups, npl = 256 / groups;
@@ -345,12 +345,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
   __syncthreads();
   // thread t < 2*cb handles (which = t / cb, channel = t % cb) of this workgroup's cb = groups*8 channels
   const int cb = groups * 8;
-  // Fixed-order form (part != null; the default of both engines since round 4): every workgroup stores its 2 * cb sums as one row of
-  // `part`, takes a ticket, and the workgroup that arrives LAST for its channel slab adds the rows in row order and writes `sums` - the
-  // result does not depend on the order in which workgroups finish, so the step's gradients are bit-reproducible (the atomic form below
-  // differed by ~6e-4 of max from run to run).  Visibility follows MI355X_MICROARCH.md "Valid forms": plain stores, every storing wave
-  // drained, workgroup barrier, one lane's agent-scope release before the ticket; the last arriver's agent-scope acquire, drained, barrier,
-  // then plain loads.  The ticket is reset by the last arriver: launches that share a workspace must be stream-ordered.
+  // Fixed-order form (part != null; what both engines use since round 4): every workgroup stores its 2 * cb sums as one row of `part` and
+  // bn_bwd_fold_rows_kernel (next launch on the stream) adds the rows in row order: the result does not depend on the order in which
+  // workgroups finish, so the step's gradients are bit-reproducible (the atomic form differed by ~6e-4 of max from run to run).
+  // (Measured alternative: a ticket per channel slab and the last arriver folding the rows inside this launch - agent-scope release by every
+  //  workgroup, acquire + 256 KB fold by the last one - cost 8-12 us per launch against 3-4 us for the second launch.)
   float* prow = part ? part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(2 * cb) : nullptr;
   for (int t = threadIdx.x; t < 2 * cb; t += 256) {
     const int which = t / cb, ch = t - which * cb;
@@ -360,54 +359,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     if (part) prow[t] = s;
     else if (cbase + ch < c) atomicAdd(sums + which * c + cbase + ch, s);
   }
-  if (!part) return;
-  __shared__ unsigned last_flag;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned old = __hip_atomic_fetch_add(ticket + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned last = old == gridDim.x - 1 ? 1u : 0u;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(ticket + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next (stream-ordered) launch
-    }
-    last_flag = last;
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  // 2 * cb <= 256 columns: thread (rg, col4) adds the rows rg, rg + RG, ... of four adjacent columns, 8 loads in flight; the RG row
-  // groups are then combined in LDS in group order
-  const int ncol4 = (2 * cb) >> 2;                 // float4 columns per row (4 .. 64)
-  const int RG = 256 / ncol4;                      // row groups
-  const int col4 = threadIdx.x % ncol4, rg = threadIdx.x / ncol4;
-  const int nb = gridDim.x;
-  const float4* base = (const float4*)(part + (size_t)blockIdx.y * nb * (size_t)(2 * cb)) + col4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  int r = rg;
-  for (; r + 7 * RG < nb; r += 8 * RG) {
-    float4 v[8];
+}
+
+// sums[which * c + slab * cb + ch] = sum over the nb rows (in row order within each of 32 row groups, then over the groups in group order) of
+// part[slab][row][which * cb + ch].  Grid (column groups of 32 floats, slabs); 256 threads = 8 float4 columns x 32 row groups, every load of a
+// thread in flight at once (nb <= 512: at most 16).
+__global__ __launch_bounds__(256) void bn_bwd_fold_rows_kernel(const float* __restrict__ part, int nb, int cb, int c, float* __restrict__ sums) {
+  __shared__ __attribute__((aligned(16))) float fold[32][32];
+  const int w = 2 * cb;                                    // floats per row
+  const int col4 = blockIdx.x * 8 + (threadIdx.x & 7), rg = threadIdx.x >> 3;
+  const bool live = col4 * 4 < w;
+  const float4* base = (const float4*)(part + (size_t)blockIdx.y * nb * (size_t)w) + col4;
+  float4 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(r + u * RG) * ncol4];
+  for (int u = 0; u < 16; ++u) {
+    const int r = rg + u * 32;
+    v[u] = (live && r < nb) ? base[(size_t)r * (w >> 2)] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 acc = v[0];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-    }
+  for (int u = 1; u < 16; ++u) {
+    acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
   }
-  for (; r < nb; r += RG) {
-    const float4 v = base[(size_t)r * ncol4];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-  }
-  float* fold = &red[0][0];                        // [RG][2 * cb] floats <= 256 * 4 (red holds 256 * 17)
-  *(float4*)(fold + (size_t)rg * (2 * cb) + col4 * 4) = acc;
+  *(float4*)&fold[rg][(threadIdx.x & 7) * 4] = acc;
   __syncthreads();
-  for (int t = threadIdx.x; t < 2 * cb; t += 256) {
+  if (threadIdx.x < 32) {
+    const int t = blockIdx.x * 32 + threadIdx.x;           // column of the row
     float s = 0.f;
-    for (int g = 0; g < RG; ++g) s += fold[g * (2 * cb) + t];
+#pragma unroll
+    for (int g = 0; g < 32; ++g) s += fold[g][threadIdx.x];
     const int which = t / cb, ch = t - which * cb;
-    if (cbase + ch < c) sums[which * c + cbase + ch] = s;
+    const int cg = blockIdx.y * cb + ch;
+    if (t < w && cg < c) sums[which * c + cg] = s;
   }
 }
 
@@ -843,13 +826,12 @@ BnReduceGeom bn_reduce_geom(int c, long long pixels) {
   g.blocks = (int)blocks;
   return g;
 }
-constexpr size_t kBnTicketBytes = 1024;      // 256 channel slabs
 }  // namespace
 
 size_t mi355det_bn_act_bwd_reduce_workspace(int32_t c, int64_t pixels) {
   if (c <= 0 || c % 8 != 0 || pixels <= 0) return 0;
   const BnReduceGeom g = bn_reduce_geom(c, pixels);
-  return kBnTicketBytes + (size_t)g.slabs * g.blocks * (size_t)(2 * g.gb * 8) * sizeof(float);
+  return (size_t)g.slabs * g.blocks * (size_t)(2 * g.gb * 8) * sizeof(float);
 }
 
 static int bn_reduce_launch(const void* g1, int32_t g1_ld, const void* g2, int32_t g2_ld, const void* z, int32_t z_ld, const float* scale_shift, int32_t c,
@@ -857,15 +839,17 @@ static int bn_reduce_launch(const void* g1, int32_t g1_ld, const void* g2, int32
   if (c <= 0 || c % 8 != 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8 (got c=%lld)", what, c);
   const BnReduceGeom g = bn_reduce_geom(c, pixels);
   float* part = nullptr;
-  unsigned* ticket = nullptr;
   if (workspace) {
-    if (g.slabs * sizeof(unsigned) > kBnTicketBytes || workspace_bytes < mi355det_bn_act_bwd_reduce_workspace(c, pixels) || ((uintptr_t)workspace & 15))
+    if (g.blocks > 512 || workspace_bytes < mi355det_bn_act_bwd_reduce_workspace(c, pixels) || ((uintptr_t)workspace & 15))
       return fail(MI355DET_EINVAL, "%s: workspace too small or misaligned (%lld bytes given)", what, (long long)workspace_bytes);
-    ticket = (unsigned*)workspace;
-    part = (float*)((char*)workspace + kBnTicketBytes);
+    part = (float*)workspace;
   }
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.blocks, g.slabs), dim3(256), 0, S(stream), (const bf16_t*)g1, g1_ld, (const bf16_t*)g2, g2_ld,
-                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)g.ppb, g.gb, part, ticket);
+                     (const bf16_t*)z, z_ld, scale_shift, c, (long long)pixels, slope, sums, (int)g.ppb, g.gb, part);
+  if (part) {
+    const int cb = g.gb * 8;
+    hipLaunchKernelGGL(bn_bwd_fold_rows_kernel, dim3((2 * cb + 31) / 32, g.slabs), dim3(256), 0, S(stream), (const float*)part, g.blocks, cb, c, sums);
+  }
   return check_launch(what);
 }
 

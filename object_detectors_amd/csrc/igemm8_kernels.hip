@@ -20,6 +20,13 @@
 // re-staging a half no earlier than two phases after its last read, which covers the one-barrier stagger).
 // Addressing, zero padding (out-of-range buffer offsets), swizzle and the epilogues are those of igemm_kernel.
 //
+// Tile heights below 256 (round 4): T1A / T1B = the number of 16-pixel tiles in X half 1 of the waves with wm = 0 / 1
+// (half 0 always has four), i.e. a tile of 128 + 16 * (T1A + T1B) pixels: (4, 4) = 256, (3, 3) = 224, (3, 2) = 208 ((2, 2) = 192 was measured and dropped).  The LDS
+// image keeps its 64-row slots per wave half (rows a wave does not have are staged as out-of-range lanes: zeros, no memory traffic), the
+// phases that multiply X half 1 run 4 * T1 MFMAs instead of 16, and the epilogue skips the missing tiles.  With 208-pixel tiles the three
+// big layer families have 985 / 494 / 248 tiles instead of 800 / 400 / 200 on 256 CUs (0.96 / 0.96 / 0.97 of whole rounds instead of 0.78);
+// what that buys against the per-tile costs that do not shrink (weight staging, prologue, epilogue) is in profiles/r04_ab_results.md.
+//
 // Tile quantisation: the big Darknet layers have 800 / 400 / 200 tiles on 256 CUs.  A stream-K form of this kernel (one persistent
 // workgroup per CU over (tile, k-step) units, fp32 slab hand-off) and a persistent whole-tile form were built and measured in round 2
 // (profiles/r02_streamk_timeline.txt, r02_igemm8_persistent_whole_tiles.txt): slower on every YOLO shape, removed in round 3.
@@ -62,9 +69,19 @@ __device__ __forceinline__ void bar() {
   asm volatile("" ::: "memory");
 }
 
-template <int EPI, int PROF = 0>
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+
+template <int EPI, int PROF = 0, int T1A = 4, int T1B = 4>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, const SkParams sk) {
   constexpr int WM = 2, WN = 4, TM = 8, TN = 4;
+  constexpr int BM = 128 + 16 * (T1A + T1B);              // pixel-tile height (kBM for the full tile)
+  constexpr int WB1 = 64 + 16 * T1A;                       // first tile row of the second wave half
+  constexpr bool VAR = BM != kBM;
+  static_assert(T1A >= 1 && T1A <= 4 && T1B >= 1 && T1B <= 4 && T1A >= T1B, "X half 1 has 1..4 tiles per wave half");
+  static_assert(!VAR || PROF == 0, "the diagnostic builds exist for the full tile only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid0 = threadIdx.x;
 
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       // very wide outputs (the 1204-class head: 43 channel tiles): the 32 workgroups an XCD runs at once would be ONE pixel tile x 32 weight
       // tiles (33 operand tiles through its L2 per round).  Order the tiles so that 32 consecutive ones form an 8 x 4 block (12 operand
       // tiles): channel-tile groups of 4 (the last group may be narrower), inside a group panels of 8 pixel tiles.
-      const int gmt = (p.M + kBM - 1) / kBM;
+      const int gmt = (p.M + BM - 1) / BM;
       const int full = gmt * 4, ngrp = (ntn + 3) / 4;
       int g = tile / full;
       if (g > ngrp - 1) g = ngrp - 1;
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       mt = panel * 8 + rr;
       nt = g * 4 + (r - rr * w);
     }
-    const int m0 = mt * kBM, n0 = nt * kBN;
+    const int m0 = mt * BM, n0 = nt * kBN;
 
     const int n_first = (int)fdiv(fdiv((unsigned)m0, p.dMW), p.dMH);
     const srd_t rsrc_x = make_srd(p.x + (long long)n_first * p.Hin * p.Win * p.ldin - p.tap_pad, 0x7FFFFFF0u);
@@ -131,8 +148,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
         const int r2 = (2 * wid + i) * 8 + lrow;                  // row inside the half, 0..127
         const int sw = ((h * 128 + r2) >> 1) & 7;
         {
-          const int row = (r2 >> 6) * 128 + h * 64 + (r2 & 63);   // pixel row of the tile
-          const int m = m0 + row;
+          // pixel row of the tile: wave half (r2 >> 6) owns tile rows [0, WB1) / [WB1, BM), its X half h the rows h * 64 + 0..63 of those
+          const int row = VAR ? ((r2 >> 6) ? WB1 : 0) + h * 64 + (r2 & 63) : (r2 >> 6) * 128 + h * 64 + (r2 & 63);
+          const bool have = !VAR || h == 0 || (r2 & 63) < 16 * ((r2 >> 6) ? T1B : T1A);      // rows of X half 1 that exist
+          const int m = have ? m0 + row : 0x7FFFFFFF;
           unsigned vm = 0;
           int voff = OOB_VOFF;
           if (p.lin_in) {
@@ -248,30 +267,33 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
     };
-    auto rdx = [&](int h, int ks, bool nxt) {
+    auto rdx = [&](int h, int ks, bool nxt, auto ntc) {
       if (PROF == 4) return;
+      constexpr int NT = decltype(ntc)::value;            // 16-pixel tiles of this X half (4, or T1 for half 1)
       const int base = nxt ? (xrd ^ kSTAGE) : xrd;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
+      for (int jj = 0; jj < NT; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
     };
-    // the 8 MFMAs of one (W half, X half, k-substep)
-    auto mf = [&](int hw, int hx, int ks) {
+    // the 2 * NT MFMAs of one (W half, X half, k-substep)
+    auto mf = [&](int hw, int hx, int ks, auto ntc) {
       if (PROF == 5) return;
+      constexpr int NT = decltype(ntc)::value;
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < NT; ++jj)
           acc[hw * 2 + ii][hx * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj], 0, 0, 0);
     };
     // scheduling hint for a segment of `nm` MFMAs and `nr` independent fragment reads written before it: one read after each of the
     // first MFMAs (a ds_read_b128 fits the 16-cycle shadow of an MFMA), the rest of the MFMAs behind
 #define IG8_INTERLEAVE(nm, nr)                                                     \
   do {                                                                            \
-    _Pragma("unroll") for (int q_ = 0; q_ < (nr); ++q_) {                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < ((nr) < (nm) ? (nr) : (nm)); ++q_) {   \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
     }                                                                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, (nm) - (nr), 0);                  \
+    if constexpr ((nm) > (nr)) __builtin_amdgcn_sched_group_barrier(0x008, (nm) > (nr) ? (nm) - (nr) : 0, 0); \
+    if constexpr ((nr) > (nm)) __builtin_amdgcn_sched_group_barrier(0x100, (nr) > (nm) ? (nr) - (nm) : 0, 0); \
   } while (0)
     auto mfma_q = [&](int hw, int hx) {
       if (PROF == 5) return;
@@ -335,9 +357,15 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     // A fragment register set is re-loaded only after its last use, so at most 72 fragment VGPRs are live (64 before).  The reads of the
     // leading half now come one barrier earlier than the lagging half's counted wait used to cover, hence the vmcnt(6) in front of every
     // trailing barrier (the pieces of the last three phases may stay in flight); no region is read later than before.
+    // The loop body per X-half-1 tile count: the two wave halves of a 208-pixel tile have 3 and 2 tiles there, so each half runs its own
+    // instantiation (wave-uniform branch; the full tile has one).
+    auto main_loop = [&](auto t1c) {
+    constexpr int T1 = decltype(t1c)::value;
+    const IntC<4> N4{};
+    const IntC<T1> N1{};
     rdw(0, 0, false);
-    rdx(0, 0, false);
-    rdx(0, 1, false);
+    rdx(0, 0, false, N4);
+    rdx(0, 1, false, N4);
     int buf = 0;
     for (int t = k0; t < k1; ++t) {
       PH_STAMP(-1, 0);
@@ -359,10 +387,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       __builtin_amdgcn_s_setprio(1);
       rdw(0, 1, false);
       rdw(1, 0, false);
-      mf(0, 0, 0);
+      mf(0, 0, 0, N4);
       IG8_INTERLEAVE(8, 4);
       rdw(1, 1, false);
-      mf(0, 0, 1);
+      mf(0, 0, 1, N4);
       IG8_INTERLEAVE(8, 2);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
@@ -378,12 +406,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       PH_STAMP(1, 6);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      rdx(1, 0, false);
-      mf(1, 0, 0);
-      IG8_INTERLEAVE(8, 4);
-      rdx(1, 1, false);
-      mf(1, 0, 1);
-      IG8_INTERLEAVE(8, 4);
+      rdx(1, 0, false, N1);
+      mf(1, 0, 0, N4);
+      IG8_INTERLEAVE(8, T1);
+      rdx(1, 1, false, N1);
+      mf(1, 0, 1, N4);
+      IG8_INTERLEAVE(8, T1);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 7);
@@ -398,8 +426,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       PH_STAMP(1, 10);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      mf(1, 1, 0);
-      mf(1, 1, 1);
+      mf(1, 1, 0, N1);
+      mf(1, 1, 1, N1);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 11);
@@ -414,13 +442,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       PH_STAMP(1, 14);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
-      rdx(0, 0, true);
-      mf(0, 1, 0);
-      IG8_INTERLEAVE(8, 4);
+      rdx(0, 0, true, N4);
+      mf(0, 1, 0, N1);
+      IG8_INTERLEAVE(2 * T1, 4);
       rdw(0, 0, true);
-      rdx(0, 1, true);
-      mf(0, 1, 1);
-      IG8_INTERLEAVE(8, 6);
+      rdx(0, 1, true, N4);
+      mf(0, 1, 1, N1);
+      IG8_INTERLEAVE(2 * T1, 6);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       PH_STAMP(2, 15);
@@ -432,6 +460,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       buf ^= 1;
       xrd ^= kSTAGE;
       wrd ^= kSTAGE;
+    }
+    };
+    if constexpr (T1A == T1B) {
+      main_loop(IntC<T1A>{});
+    } else {
+      if (wm == 0) main_loop(IntC<T1A>{});
+      else main_loop(IntC<T1B>{});
     }
 #undef PH_STAMP
 #undef IG8_INTERLEAVE
@@ -456,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     __builtin_amdgcn_s_waitcnt(0xC07F);
     bar();                          // the epilogue reuses smem
 
-    igemm_epilogue<WM, WN, TM, TN, EPI>(p, acc, smem, tid, 512, true, wm, wn, lane, mt, n0, m0);
+    igemm_epilogue<WM, WN, TM, TN, EPI, VAR ? BM : 0>(p, acc, smem, tid, 512, true, wm, wn, lane, mt, n0, m0, 0, wm ? WB1 : 0, 4 + (wm ? T1B : T1A));
     if (PROF == 2 && !SK && sk.dbg && lane == 0 && bid < 64) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's stores have left
       sk.dbg[((size_t)bid * 8 + wid) * 24 + 20] = __builtin_amdgcn_s_memrealtime();
@@ -509,6 +544,32 @@ int launch8(const IgemmParams& p, hipStream_t st) {
   return check_launch("igemm8");
 }
 
+// the 224 / 208-pixel tiles (T1A, T1B) = (3, 3) / (3, 2)
+template <int EPI, int T1A, int T1B>
+int launch8v(const IgemmParams& p, hipStream_t st) {
+  constexpr int BM = 128 + 16 * (T1A + T1B);
+  const int gm = (p.M + BM - 1) / BM, gn = p.CoutPad / kBN;
+  SkParams sk{};
+  auto k = igemm8_kernel<EPI, 0, T1A, T1B>;
+  static DeviceOnce attr_done;
+  attr_done.once([&] {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLDS);
+  });
+  hipLaunchKernelGGL(k, dim3(gm * gn), dim3(512), kLDS, st, p, sk);
+  return check_launch("igemm8v");
+}
+
+template <int EPI>
+int launch8_rows(const IgemmParams& p, hipStream_t st, int rows) {
+  switch (rows) {
+    case 256: return launch8<EPI>(p, st);
+    case 224: return launch8v<EPI, 3, 3>(p, st);
+    case 208: return launch8v<EPI, 3, 2>(p, st);
+    default: break;
+  }
+  return fail(MI355DET_EINVAL, "%s: pixel-tile height %lld not built (256, 224, 208)", "igemm8", rows);
+}
+
 }  // namespace
 
 bool igemm8_applicable(const IgemmParams& p) {
@@ -520,14 +581,14 @@ bool igemm8_applicable(const IgemmParams& p) {
 void igemm8_set_dbg(unsigned long long* ptr) { g_sk_dbg = ptr; }
 void igemm8_set_dbg_mode(int mode) { g_sk_dbg_mode = mode; }
 
-int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st) {
+int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, int rows) {
   if (!igemm8_applicable(p)) return fail(MI355DET_EINVAL, "%s: shape not supported by the phase-staggered kernel", "igemm8");
   switch (epi) {
-    case EPI_STATS: return launch8<EPI_STATS>(p, st);
-    case EPI_PLAIN: return launch8<EPI_PLAIN>(p, st);
-    case EPI_RES: return launch8<EPI_RES>(p, st);
-    case EPI_AFF: return launch8<EPI_AFF>(p, st);
-    case EPI_F32: return launch8<EPI_F32>(p, st);      // fp32 head outputs (the 1204-class cls_logits: Cout padded to 256)
+    case EPI_STATS: return launch8_rows<EPI_STATS>(p, st, rows);
+    case EPI_PLAIN: return launch8_rows<EPI_PLAIN>(p, st, rows);
+    case EPI_RES: return launch8_rows<EPI_RES>(p, st, rows);
+    case EPI_AFF: return launch8_rows<EPI_AFF>(p, st, rows);
+    case EPI_F32: return rows == 256 ? launch8<EPI_F32>(p, st) : fail(MI355DET_EINVAL, "%s: the fp32 head epilogue is built for the 256-pixel tile only", "igemm8");      // (the 1204-class cls_logits: Cout padded to 256)
     default: break;
   }
   return fail(MI355DET_EINVAL, "%s: epilogue not built for the phase-staggered kernel", "igemm8");

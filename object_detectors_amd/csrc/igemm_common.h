@@ -67,7 +67,7 @@ enum { EPI_STATS = 0, EPI_F32 = 1, EPI_RES = 2, EPI_PLAIN = 3, EPI_AFF = 4, EPI_
 
 // phase-staggered 256x256x64 kernel (igemm8_kernels.hip)
 bool igemm8_applicable(const IgemmParams& p);
-int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st);
+int igemm8_launch(int epi, const IgemmParams& p, hipStream_t st, int rows = 256);      // rows: pixel-tile height 256 (default), 224 or 208
 void igemm8_set_dbg(unsigned long long* ptr);
 void igemm8_set_dbg_mode(int mode);
 
@@ -159,13 +159,43 @@ __device__ __forceinline__ void write_partial_rows(const IgemmParams& p, const f
   }
 }
 
+// The same rows for a tile height that is NOT a multiple of 128 pixels (the 224 / 208 / 192-pixel tiles of igemm8_kernel): tile t covers
+// lattice pixels [t * BMV, (t + 1) * BMV) and OWNS the rows [floor(t * BMV / 128), floor((t + 1) * BMV / 128)) - the row its first pixel lies
+// in (no other tile starts there, since BMV >= 128) and the rows up to the one the next tile starts in; the last tile owns the rest.  The
+// tile's sums (both wave halves) go to its first row, zeros to the others (at most three rows in all): the finalisation kernels add all rows,
+// so the partial buffer keeps its configuration-independent shape and no row is ever stale.
+template <int BMV, int BN>
+__device__ __forceinline__ void write_partial_rows_var(const IgemmParams& p, const float* sred, int tid, int nthreads, int mt, int n0) {
+  static_assert(BMV >= 128 && BMV <= 256, "every tile starts in a row of its own");
+  const int nrows = (p.M + 127) / 128;
+  const int last = (p.M + BMV - 1) / BMV - 1;
+  const int r0 = (mt * BMV) >> 7, r1 = mt == last ? nrows : ((mt + 1) * BMV) >> 7;      // owned rows [r0, r1)
+  for (int i = tid; i < BN * 3; i += nthreads) {
+    const int c = i % BN, g = i / BN;
+    const int row = r0 + g;
+    if (row >= r1 || row >= nrows) continue;
+    float s1 = 0.f, s2 = 0.f;
+    if (g == 0) {
+      s1 = sred[(0 * BN + c) * 2 + 0] + sred[(1 * BN + c) * 2 + 0];
+      s2 = sred[(0 * BN + c) * 2 + 1] + sred[(1 * BN + c) * 2 + 1];
+    }
+    float* dst = p.stats + (long long)row * 2 * p.CoutPad;
+    dst[n0 + c] = s1;
+    dst[p.CoutPad + n0 + c] = s2;
+  }
+}
+
 // ---- shared epilogue.  `consumer` = this wave holds accumulators (false for a dedicated loader wave, which only
 //      takes part in the barrier and the final statistics write)
-template <int WM, int WN, int TM, int TN, int EPI>
+//      BMV > 0 (igemm8_kernel's 224 / 208 / 192-pixel tiles, WM == 2): the wave's rows start at tile row `wrow` instead of wm * TM * 16 and only
+//      its first `jlim` 16-pixel tiles exist (the accumulators of the others are zero and are neither staged nor stored)
+template <int WM, int WN, int TM, int TN, int EPI, int BMV = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&acc)[TN][TM], char* smem, int tid, int nthreads, bool consumer,
-                                               int wm, int wn, int lane, int mt, int n0, int m0, long long yoff = 0) {
+                                               int wm, int wn, int lane, int mt, int n0, int m0, long long yoff = 0, int wrow = 0, int jlim = TM) {
   constexpr int BN = WN * TN * 16;
   const int fr = lane & 15, fq = lane >> 4;
+  const int wbase = BMV > 0 ? wrow : wm * (TM * 16);          // first tile row of this wave
+  const int rlim = BMV > 0 ? jlim * 16 : TM * 16;             // rows of this wave that exist
   // ---- epilogue: lane holds channels co = n0 + wn*TN*16 + i*16 + fq*4 + r (r=0..3) of pixel
   //      m = m0 + wm*TM*16 + j*16 + fr
   if (EPI == EPI_STATS) {
@@ -192,15 +222,16 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       }
     }
     __syncthreads();
-    write_partial_rows<WM, TM, BN>(p, (const float*)smem, tid, nthreads, mt, n0);
+    if constexpr (BMV > 0) write_partial_rows_var<BMV, BN>(p, (const float*)smem, tid, nthreads, mt, n0);
+    else write_partial_rows<WM, TM, BN>(p, (const float*)smem, tid, nthreads, mt, n0);
   }
   if (!consumer) return;
   if (EPI == EPI_F32) {
     // head conv_out: fp32 + bias, 255 channels (tiny layers): direct stores from the accumulator layout
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * (TM * 16) + j * 16 + fr;
-      if (m >= p.M) continue;
+      const int m = m0 + wbase + j * 16 + fr;
+      if (m >= p.M || (BMV > 0 && j >= jlim)) continue;
       const int t1 = (int)fdiv((unsigned)m, p.dMW), xx = m - t1 * p.MW;
       const int n = (int)fdiv((unsigned)t1, p.dMH), yy = t1 - n * p.MH;
       const int oy = yy * p.so + p.oy0, ox = xx * (p.sox ? p.sox : p.so) + p.ox0;
@@ -282,7 +313,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       const bool want_res = EPI == EPI_RES || p.res != nullptr;
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
-        const int m = m0 + wm * (TM * 16) + jh * 64 + pass * RPP + rsub;
+        const int lr = jh * 64 + pass * RPP + rsub;
+        const int m = (BMV > 0 && lr >= rlim) ? 0x7FFFFFFF : m0 + wbase + lr;
         int pixi = -1;
         if (p.lin_out) {
           if (m < p.M && co < p.Cout) pixi = m;
@@ -297,7 +329,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
         if (EPI == EPI_BNRED) zpre[pass] = pixi >= 0 ? *(const uint4*)(p.z + (long long)pixi * p.ldz + co) : make_uint4(0, 0, 0, 0);
       }
     } else {
-      const int m = m0 + wm * (TM * 16) + jh * 64 + lane;
+      const int m = (BMV > 0 && jh * 64 + lane >= rlim) ? 0x7FFFFFFF : m0 + wbase + jh * 64 + lane;
       int pixi = -1;
       if (p.lin_out) {
         if (m < p.M) pixi = m;
@@ -312,6 +344,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = jh * 4 + jj;
+      if (BMV > 0 && j >= jlim) continue;           // (wave-uniform) tiles this wave does not have
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         f32x4_t v = acc[i][j];
@@ -399,7 +432,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
       }
     }
     __syncthreads();
-    write_partial_rows<WM, TM, BN>(p, sred, tid, nthreads, mt, n0);
+    if constexpr (BMV > 0) write_partial_rows_var<BMV, BN>(p, sred, tid, nthreads, mt, n0);
+    else write_partial_rows<WM, TM, BN>(p, sred, tid, nthreads, mt, n0);
   }
 }
 

@@ -628,7 +628,7 @@ class Plan:
         nsum = sum(2 * r["shp"].cout for r in self.ops if r["kind"] == "cbl") + 64
         self.sums_all = torch.zeros(nsum, device=dev, dtype=torch.float32)
         sum_off = [0]
-        # workspace of the fixed-order BatchNorm-backward sums (partial rows + tickets, zeroed once: the kernel resets its tickets); one buffer
+        # workspace of the fixed-order BatchNorm-backward sums (one partial row per workgroup, folded by a second small launch); one buffer
         # for every layer - the reduce launches are ordered on the step's stream
         red_need = max([L.mi355det_bn_act_bwd_reduce_workspace(r["shp"].cout, r["pixels"]) for r in self.ops if r["kind"] == "cbl"] + [1024])
         self.bn_red_ws = torch.zeros(red_need, device=dev, dtype=torch.uint8)

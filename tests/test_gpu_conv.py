@@ -176,9 +176,9 @@ def test_bn_lrelu_fwd_bwd(c, pixels, res):
 
 @pytest.mark.parametrize("c,pixels", [(8, 70), (32, 4097), (64, 20000), (72, 3333), (256, 9000), (1024, 12800), (512, 200000)])
 def test_bn_bwd_reduce_fixed_order_form(c, pixels):
-    """mi355det_bn_act_bwd_reduce_det (ticket + last-arriver fold, the engines' default): equal to an fp64 evaluation to fp32 accuracy,
-    close to the atomic form, BIT-identical from launch to launch with one workspace reused (the ticket resets itself), and it WRITES
-    `sums` (no zeroing).  Channel counts: powers of two and not (72: a partly empty last slab); pixel counts from one workgroup to the cap."""
+    """mi355det_bn_act_bwd_reduce_det (partial rows + a fold launch, what the engines use): equal to an fp64 evaluation to fp32 accuracy,
+    close to the atomic form, BIT-identical from launch to launch with one (uninitialised) workspace reused, and it WRITES `sums` (no
+    zeroing).  Channel counts: powers of two and not (72: a partly empty last slab); pixel counts from one workgroup to the cap."""
     from object_detectors_amd._lib import check, lib, ptr, stream_ptr
     d = dev()
     L = lib()
@@ -190,8 +190,8 @@ def test_bn_bwd_reduce_fixed_order_form(c, pixels):
     mean, invstd = torch.randn(c, device=d) * 0.1, torch.rand(c, device=d) + 0.5
     ss = torch.cat([scale, shift, mean, invstd]).contiguous()
     nbytes = L.mi355det_bn_act_bwd_reduce_workspace(c, pixels)
-    assert nbytes >= 1024
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device=d)
+    assert nbytes >= 64
+    ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=d)      # NaN bit patterns: every row the fold reads must have been written
     for second in (None, g2):
         gg = g.double() + (second.double() if second is not None else 0)
         if second is not None:
@@ -213,11 +213,10 @@ def test_bn_bwd_reduce_fixed_order_form(c, pixels):
         check(L.mi355det_bn_act_bwd_reduce(ptr(g), c, ptr(second) if second is not None else None, c if second is not None else 0, ptr(z), c,
                                             ptr(ss), c, pixels, 0.1, ptr(atom), stream_ptr()), "reduce")
         assert float((atom.double() - want).abs().max()) < tol
-    assert int(ws[:1024].view(torch.int32).abs().sum()) == 0              # every ticket is back at zero
     # too small / missing workspace: EINVAL, nothing launched
     sums = torch.zeros(2 * c, device=d)
     with pytest.raises(ValueError):
-        check(L.mi355det_bn_act_bwd_reduce_det(ptr(g), c, None, 0, ptr(z), c, ptr(ss), c, pixels, 0.1, ptr(sums), ptr(ws), 512, stream_ptr()), "reduce_det")
+        check(L.mi355det_bn_act_bwd_reduce_det(ptr(g), c, None, 0, ptr(z), c, ptr(ss), c, pixels, 0.1, ptr(sums), ptr(ws), 32, stream_ptr()), "reduce_det")
 
 
 def test_upsample_and_layout():
@@ -749,3 +748,55 @@ def test_dgrad_with_relu_affine_backward_in_the_epilogue(case, relu, with_scale)
         L.mi355det_debug_set(0, 0)
     s2 = ops.conv_shape(n, h - h % 2, w - w % 2, cin, cout, 3, 2)
     assert L.mi355det_conv_dgrad_mask(C.byref(s2), ptr(gyd), ptr(wd), ptr(got), ptr(act), cin, None, 1, stream_ptr()) == -1      # stride 2 refused
+
+
+@pytest.mark.parametrize("case", [(3, 24, 24, 128, 256, 3), (2, 40, 40, 256, 512, 3), (1, 20, 20, 512, 1024, 3), (5, 13, 11, 256, 256, 1), (1, 9, 7, 64, 256, 3),
+                                  (2, 52, 52, 64, 256, 3)])
+def test_phase_staggered_kernel_on_shorter_pixel_tiles(case):
+    """Tile configurations 44 / 45 (igemm8_kernel on 224 / 208-pixel tiles: VERDICT r3 item 1a, tile quantisation) against
+    configuration 40 (the same loop on 256 pixels): the convolution sums the same products in the same k order, so the stored tensors are
+    BIT-identical - forward (+ BN partial statistics, whose rows are laid out differently but must add up to the same per-channel sums),
+    data gradient with and without the residual, the FrozenBN-affine epilogue of inference plans.  Pixel counts that are no multiple of
+    any tile height (tail tiles, the tile that ends inside a 128-pixel statistics row) and one that spans several images per tile."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout, k = case
+    x = rnd((n, cin, h, w), 1)
+    wt = rnd((cout, cin, k, k), 2, (2.0 / (cin * k * k)) ** 0.5)
+    gy = rnd((n, cout, h, w), 3)
+    shape = ops.conv_shape(n, h, w, cin, cout, k, 1)
+    wf, wd = ops.pack_weights(shape, wt.to(dev()))
+    xd, gyd = nhwc(x), nhwc(gy)
+    res = nhwc(rnd((n, cin, h, w), 4))
+    rows = ops.conv_stats_rows(shape)
+    dgrad_ok = cin % 256 == 0                     # the data gradient's output channels must fill a 256-wide tile
+    aff_s, aff_b = (1.0 + 0.3 * rnd((cout,), 6)).to(dev()), (0.2 * rnd((cout,), 7)).to(dev())
+    resy = nhwc(rnd((n, cout, h, w), 8))
+    outs = {}
+    try:
+        for cfg in (40, 44, 45, 44, 40):
+            lib().mi355det_debug_set(0, cfg)
+            y = torch.full((n, h, w, cout), 5.0, device=dev(), dtype=torch.bfloat16)
+            stats = torch.full((rows + 64, 2, ops.cout_pad_of(cout)), 77.0, device=dev())       # stale values: every row must be rewritten
+            ops.conv_fwd(shape, xd, wf, y, stats=stats)
+            dx = torch.full((n, h, w, cin), 5.0, device=dev(), dtype=torch.bfloat16)
+            dxr = torch.full((n, h, w, cin), 5.0, device=dev(), dtype=torch.bfloat16)
+            if dgrad_ok:
+                ops.conv_dgrad(shape, gyd, wd, dx)
+                ops.conv_dgrad(shape, gyd, wd, dxr, residual=res, residual_ld=cin)
+            ya = torch.full((n, h, w, cout), 5.0, device=dev(), dtype=torch.bfloat16)
+            ops.conv_fwd_ex(shape, xd, wf, ya, scale=aff_s, shift=aff_b, residual=resy, residual_ld=cout, leaky_slope=0.1)
+            torch.cuda.synchronize()
+            outs.setdefault(cfg, []).append((y.clone(), stats[:rows].double().sum(0).cpu(), dx.clone(), dxr.clone(), ya.clone()))
+    finally:
+        lib().mi355det_debug_set(0, 0)
+    y0, st0, dx0, dxr0, ya0 = outs[40][0]
+    yr = F.conv2d(x, wt, padding=k // 2).permute(0, 2, 3, 1)
+    assert float((y0.float().cpu() - yr).abs().max()) <= 2e-2 * float(yr.abs().max())
+    yf = y0.float().reshape(-1, cout).double().cpu()
+    for cfg, runs in outs.items():
+        for y, st, dx, dxr, ya in runs:
+            assert torch.equal(y, y0) and torch.equal(ya, ya0), cfg
+            assert torch.equal(dx, dx0) and torch.equal(dxr, dxr0), cfg
+            torch.testing.assert_close(st[0, :cout], yf.sum(0), rtol=1e-4, atol=1e-3, msg=f"cfg {cfg} sum")
+            torch.testing.assert_close(st[1, :cout], (yf * yf).sum(0), rtol=1e-4, atol=1e-3, msg=f"cfg {cfg} sumsq")
