@@ -67,7 +67,7 @@ typedef struct {
   float lambda_iou, lambda_xy, lambda_wh, lambda_conf, lambda_no_conf, lambda_cls;
   float alpha, gamma;          /* custom.FocalLoss (yolo/utilities/custom.py:40-67) */
   float grad_scale;            /* multiplies every gradient (1/sum(M) is applied internally) */
-  int32_t grad_is_bf16;        /* grad views hold bf16 (engine) instead of fp32 */
+  int32_t grad_is_bf16;        /* format of the grad views: 0 = fp32, 1 = bf16 (engine default), 2 = IEEE fp16 (engine with fp16 storage) */
   const float* class_weights;  /* device [C] or NULL: nn.CrossEntropyLoss(weight=..., reduction='sum') class weights
                                   (yolo_forw.py:50-62,72: tf-idf / effective-number re-weighting); for class_loss 0 / 2 the same
                                   row is BCEWithLogitsLoss's pos_weight (yolo_forw.py:70-71,74-75) */

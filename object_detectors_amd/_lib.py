@@ -163,6 +163,17 @@ PROTOTYPES = {
     "mi355det_fastrcnn_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, sz, vp]),
 }
 
+def _f16_twins():
+    """Entry points that exist a second time with fp16 storage (csrc/f16_names.h): same prototype, suffix _f16."""
+    import re
+    txt = open(os.path.join(HERE, "csrc", "f16_names.h")).read().split("// ---- cross-file symbols")[0]
+    return re.findall(r"#define (mi355det_[a-z0-9_]+) \1_f16", txt)
+
+
+F16_TWINS = _f16_twins()
+for _n in F16_TWINS:
+    PROTOTYPES[_n + "_f16"] = PROTOTYPES[_n]
+
 _lib = None
 
 
@@ -192,6 +203,35 @@ def lib():
             raise Mi355detError(f"{LIB_PATH} lacks symbols {missing}: rebuild with `python -m object_detectors_amd.build --force`")
         _lib = L
     return _lib
+
+
+class _StorageLib:
+    """The library as seen by an engine that stores fp16: every entry point that has an fp16 twin resolves to the twin, everything else
+    (fp32 statistics, optimizers, the criterion, box kernels) to the one function there is."""
+
+    def __init__(self, L):
+        self._L = L
+        self._twins = set(F16_TWINS)
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name + "_f16" if name in self._twins else name)
+        setattr(self, name, fn)
+        return fn
+
+
+_storage_libs = {}
+
+
+def storage_lib(storage="bf16"):
+    """lib() for the given storage format of activations / gradients / packed weights: "bf16" (default) or "fp16" (the reference's apex-O2
+    format, yolo/procedures/initialize.py:44-45)."""
+    if storage in ("bf16", None):
+        return lib()
+    if storage != "fp16":
+        raise ValueError("storage must be 'bf16' or 'fp16'")
+    if "fp16" not in _storage_libs:
+        _storage_libs["fp16"] = _StorageLib(lib())
+    return _storage_libs["fp16"]
 
 
 def check(status, what=""):

@@ -35,6 +35,10 @@ SOURCES = [
     ("stem_l1_kernels.hip", ["-fno-slp-vectorize"]),     # packed fp32 adds cost more moves than they save (and 36 VGPRs)
     ("rstem_kernels.hip", ["-fno-slp-vectorize"]),
 ]
+# Files that touch stored activations are compiled a second time with -DMI355_F16=1 (fp16 storage instead of bf16: csrc/common.h); the
+# entry points of those objects carry the suffix _f16 (csrc/f16_names.h, include/mi355det_f16.h).
+F16_TWINS = ["conv_kernels.hip", "igemm8_kernels.hip", "wgrad_kernels.hip", "dgrad_s2_kernels.hip", "elem_kernels.hip", "stem_kernels.hip",
+             "stem_l1_kernels.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-value", "-x", "hip"]
 
 
@@ -60,6 +64,11 @@ def build(force=False, verbose=False):
         objs.append(op)
         if force or _stale(op, [sp] + headers):
             jobs.append([HIPCC] + COMMON + extra + ["-c", sp, "-o", op])
+        if src in F16_TWINS:
+            op16 = os.path.join(OBJ, os.path.splitext(src)[0] + "_f16.o")
+            objs.append(op16)
+            if force or _stale(op16, [sp] + headers):
+                jobs.append([HIPCC] + COMMON + extra + ["-DMI355_F16=1", "-c", sp, "-o", op16])
 
     def run(cmd):
         if verbose:

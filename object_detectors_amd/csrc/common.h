@@ -7,6 +7,9 @@
 #include <atomic>
 #include <mutex>
 
+#if defined(MI355_F16) && MI355_F16
+#include "f16_names.h"      // entry points and cross-file symbols of the fp16-storage objects get the suffix _f16
+#endif
 #include "../../include/mi355det.h"
 
 #define WAVE 64
@@ -29,7 +32,7 @@ inline int check_launch(const char* what) {
   return MI355DET_OK;
 }
 
-typedef unsigned short bf16_t;  // raw bits
+typedef unsigned short bf16_t;  // raw bits of a 16-bit storage element (bf16; IEEE fp16 in the *_f16 objects, see below)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -37,6 +40,36 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+
+// ---- storage format of the convolution engine's activations, gradients and packed weights.
+// The reference trains either in fp32 (apex O0, its default) or with fp16 storage (apex O2: yolo/batch_files/sample.txt:28-44,
+// yolo/procedures/initialize.py:44-45).  This library stores bf16 by default; the files that touch stored activations (conv_kernels, igemm8_kernels,
+// wgrad_kernels, dgrad_s2_kernels, elem_kernels, stem_kernels, stem_l1_kernels) are compiled a SECOND time with -DMI355_F16=1 into *_f16 objects
+// whose entry points carry the suffix _f16 (f16_names.h; declared in include/mi355det_f16.h): the same loops on the f16 MFMA forms, fp32
+// accumulation and fp32 masters unchanged.  s2f / f2s convert one stored element, st16x8_t / st16x4_t are the MFMA operand vectors.
+#ifndef MI355_F16
+#define MI355_F16 0
+#endif
+#if MI355_F16
+typedef _Float16 st16_scalar_t;
+#define MI355_MFMA_BUILTIN_16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define MI355_MFMA_BUILTIN_32 __builtin_amdgcn_mfma_f32_32x32x16_f16
+__device__ __forceinline__ float s2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2s(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }      // round to nearest even, overflow -> inf, NaN stays NaN
+#else
+typedef __bf16 st16_scalar_t;
+#define MI355_MFMA_BUILTIN_16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define MI355_MFMA_BUILTIN_32 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+__device__ __forceinline__ float s2f(bf16_t v) { return bf2f(v); }
+__device__ __forceinline__ bf16_t f2s(float f) { return f2bf(f); }
+#endif
+typedef __attribute__((ext_vector_type(8))) st16_scalar_t st16x8_t;
+typedef __attribute__((ext_vector_type(4))) st16_scalar_t st16x4_t;
+typedef __attribute__((ext_vector_type(4))) float mi355_f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float mi355_f32x16_t;
+// D = A * B + C on the matrix cores in the storage format (v_mfma_f32_16x16x32_{bf16,f16} / 32x32x16: the same rate for both formats)
+__device__ __forceinline__ mi355_f32x4_t MI355_MFMA_16x16x32(st16x8_t a, st16x8_t b, mi355_f32x4_t c) { return MI355_MFMA_BUILTIN_16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ mi355_f32x16_t MI355_MFMA_32x32x16(st16x8_t a, st16x8_t b, mi355_f32x16_t c) { return MI355_MFMA_BUILTIN_32(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

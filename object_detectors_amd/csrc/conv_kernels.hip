@@ -224,18 +224,18 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
     const char* sb = sa + BM * ROWB;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8_t wf[TN], af[TM];
+      st16x8_t wf[TN], af[TM];
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn * (TN * 16) + i * 16 + fr;
-        if (ABL == 2) { wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(row, s, ks, i)); asm volatile("" : "+v"(wf[i])); }
-        else wf[i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        if (ABL == 2) { wf[i] = __builtin_bit_cast(st16x8_t, make_uint4(row, s, ks, i)); asm volatile("" : "+v"(wf[i])); }
+        else wf[i] = *(const st16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm * (TM * 16) + j * 16 + fr;
-        if (ABL == 2) { af[j] = __builtin_bit_cast(bf16x8_t, make_uint4(row, s, ks, j)); asm volatile("" : "+v"(af[j])); }
-        else af[j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        if (ABL == 2) { af[j] = __builtin_bit_cast(st16x8_t, make_uint4(row, s, ks, j)); asm volatile("" : "+v"(af[j])); }
+        else af[j] = *(const st16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
       constexpr int NMF = TN * TM * (BK / 32);            // MFMAs per k-step per wave
       constexpr int G = NMF / PER > 0 ? NMF / PER : 1;     // MFMAs between two LDS-DMA pieces
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC > 0 ? OCC : (WM * WN >= 8 ? 2 : 1
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           if (ABL == 3) { asm volatile("" ::"v"(wf[i]), "v"(af[j])); acc[i][j][0] += 1.0f; }
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = MI355_MFMA_16x16x32(wf[i], af[j], acc[i][j]);
           if (ILV) {
             // spread the next stage's LDS-DMA pieces between the MFMAs: a piece costs ~100+ issue cycles, which
             // then overlap with this wave's own MFMAs still running in the matrix pipe
@@ -478,12 +478,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
       STAMP(t_d);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        bf16x8_t wf[TN], af[TM];
+        st16x8_t wf[TN], af[TM];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) wf[t] = *(const bf16x8_t*)(bb + (wfrag[t] ^ (ks << 6)));
+        for (int t = 0; t < TN; ++t) wf[t] = *(const st16x8_t*)(bb + (wfrag[t] ^ (ks << 6)));
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          af[j] = *(const bf16x8_t*)(ab + (afrag[i][j] ^ (ks << 6)));
+          af[j] = *(const st16x8_t*)(ab + (afrag[i][j] ^ (ks << 6)));
         }
         if (PROF) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // diagnostic build: separate the fragment reads from the MFMAs
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 || TM >= 8 || NSTB > 2 ?
 #pragma unroll
         for (int t = 0; t < TN; ++t)
 #pragma unroll
-          for (int j = 0; j < TM; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af[j], acc[t][j], 0, 0, 0);
+          for (int j = 0; j < TM; ++j) acc[t][j] = MI355_MFMA_16x16x32(wf[t], af[j], acc[t][j]);
         if (PROF) {
           asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[TN - 1][TM - 1][3]));
           STAMP(t_f);
@@ -636,18 +636,18 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_il_
     }
     const char* sa = smem + buf * STAGE;
     const char* sb = sa + BM * ROWB;
-    bf16x8_t wf[KS][TN], af[KS][TM];
+    st16x8_t wf[KS][TN], af[KS][TM];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn * (TN * 16) + i * 16 + fr;
-        wf[ks][i] = *(const bf16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        wf[ks][i] = *(const st16x8_t*)(sb + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm * (TM * 16) + j * 16 + fr;
-        af[ks][j] = *(const bf16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
+        af[ks][j] = *(const st16x8_t*)(sa + row * ROWB + (((ks * 4 + fq) ^ swz<BK>(row)) << 4));
       }
     }
 #pragma unroll
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN >= 8 ? 2 : 1)) void igemm_il_
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = MI355_MFMA_16x16x32(wf[ks][i], af[ks][j], acc[i][j]);
           const int cnt = (ks * TN + i) * TM + j + 1;
           if (cnt % G == 0 && cnt / G - 1 < PER) piece(cnt / G - 1, s + 1, soff, tap, buf ^ 1, live);
         }
@@ -687,7 +687,7 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, bf16_t* __restrict_
     const int co = (int)(i / ((long long)cin_pad * kk));
     float v = 0.f;
     if (co < cout && c < cin) v = w[co * s_co + c * s_ci + t * s_t];
-    out[i] = f2bf(v);
+    out[i] = f2s(v);
   }
 }
 
@@ -708,7 +708,7 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, bf16_t* __restric
       if (j == q) tap = taps[q];
     float v = 0.f;
     if (ci < cin) v = w[co * s_co + ci * s_ci + tap * s_t];
-    out[i] = f2bf(v);
+    out[i] = f2s(v);
   }
 }
 
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
     if (x >= w) continue;
     unsigned short v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = lrow[j] >= 0 ? f2bf(tile[lrow[j]][p + lcol[j]]) : (unsigned short)0;
+    for (int j = 0; j < 8; ++j) v[j] = lrow[j] >= 0 ? f2s(tile[lrow[j]][p + lcol[j]]) : (unsigned short)0;
     uint4 u;
     u.x = v[0] | ((unsigned)v[1] << 16);
     u.y = v[2] | ((unsigned)v[3] << 16);
@@ -801,7 +801,7 @@ __global__ void pack_s2cat_kernel(const float* __restrict__ w, bf16_t* __restric
     const int kh = s2cat_k(py, oy), kw = s2cat_k(px, ox);
     float v = 0.f;
     if (kh >= 0 && kw >= 0) v = w[co * s_co + ci * s_ci + (kh * 3 + kw) * s_t];
-    out[i] = f2bf(v);
+    out[i] = f2s(v);
   }
 }
 
@@ -900,6 +900,7 @@ unsigned long long igemm_key(const IgemmParams& p, int epi) {
   k = k * 7 + p.sin * 2 + p.so;
   k = k * 3 + p.sox;
   k = k * 5 + epi;
+  k = k * 2 + MI355_F16;      // the fp16-storage objects keep their own choices in the shared tune record
   return k;
 }
 
@@ -1040,6 +1041,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
       }
     }
     g_igemm_tuned[igemm_key(p, EPI)] = best;
+    tune_mark_timed(TUNE_IGEMM, igemm_key(p, EPI));
     return best;
   }
   if (!(p.CoutPad % 128 == 0 && p.Cin % 64 == 0)) return launch_igemm<EPI>(p, st);   // nothing to choose: a plain launch, the output stays valid
@@ -1068,6 +1070,7 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
     }
   }
   g_igemm_tuned[igemm_key(p, EPI)] = best;
+  tune_mark_timed(TUNE_IGEMM, igemm_key(p, EPI));
   static const bool tune_log = getenv("MI355DET_TUNE_LOG") != nullptr;
   if (tune_log) fprintf(stderr, "[mi355det] igemm tune: M=%d Cout=%d Cin=%d T=%d epi=%d -> cfg %d (%.1f us)\n", p.M, p.CoutPad, p.Cin, p.T, EPI, best, best_ms * 1e3f / 3.f);
   return best;
@@ -1320,7 +1323,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
       const int kh = s2cat_k(py, oy), kw = s2cat_k(px, ox);
       float v = 0.f;
       if (kh >= 0 && kw >= 0) v = e.src[co * e.s_co + ci * e.s_ci + (kh * 3 + kw) * e.s_t];
-      e.dst[i] = f2bf(v);
+      e.dst[i] = f2s(v);
     }
     return;
   }
@@ -1331,7 +1334,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
       const int c = i % e.cin, t = (i / e.cin) % e.kk, co = i / (e.cin * e.kk);
       float v = 0.f;
       if (co < e.rows_valid) v = e.src[co * e.s_co + c * e.s_ci + t * e.s_t];
-      e.dst[i] = f2bf(v);
+      e.dst[i] = f2s(v);
     }
     return;
   }
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const PackEntry* __re
   const int col = threadIdx.x % e.cob;
   for (int r = threadIdx.x / e.cob; r < 32; r += 256 / e.cob) {
     const long long ci = ci_blk * 32 + r;
-    e.dst[(ci * e.ntaps + j) * e.cdim + co_blk * e.cob + col] = f2bf(tl[col][r]);
+    e.dst[(ci * e.ntaps + j) * e.cdim + co_blk * e.cob + col] = f2s(tl[col][r]);
   }
 }
 
@@ -1481,7 +1484,7 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
   const int classes = s->stride == 1 ? 1 : 4;
   if (!partials && s2cat_eligible(s) && (!residual || residual_ld == s->cin)) {
     // class-concatenated form (two wide GEMMs) or the four class launches: per shape, whichever the plan-build timing found faster
-    const unsigned long long key = ((((unsigned long long)s->n * 4099 + s->h) * 4099 + s->w) * 4099 + s->cin) * 4099 + s->cout + (residual ? 1ull << 62 : 0);
+    const unsigned long long key = ((((unsigned long long)s->n * 4099 + s->h) * 4099 + s->w) * 4099 + s->cin) * 4099 + s->cout + (residual ? 1ull << 62 : 0) + (MI355_F16 ? 1ull << 61 : 0);
     int choice = -1;
     auto it = g_s2cat_tuned.find(key);
     if (it != g_s2cat_tuned.end()) choice = it->second;
@@ -1535,6 +1538,7 @@ static int conv_dgrad_impl(const mi355det_conv_shape* s, const void* dy, const v
       }
       choice = ms[1] < ms[0] ? 1 : 0;
       g_s2cat_tuned[key] = choice;
+      tune_mark_timed(TUNE_S2CAT, key);
       static const bool tune_log = getenv("MI355DET_TUNE_LOG") != nullptr;
       if (tune_log) fprintf(stderr, "[mi355det] stride-2 dgrad %d->%d @%dx%d: four classes %.1f us, concatenated %.1f us\n", s->cin, s->cout, s->h, s->w,
                             ms[0] * 1e3f / 3.f, ms[1] * 1e3f / 3.f);
@@ -1670,15 +1674,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       const unsigned rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        a[2 * k] += bf2f((unsigned short)(rr[k] & 0xFFFFu));
-        a[2 * k + 1] += bf2f((unsigned short)(rr[k] >> 16));
+        a[2 * k] += s2f((unsigned short)(rr[k] & 0xFFFFu));
+        a[2 * k + 1] += s2f((unsigned short)(rr[k] >> 16));
       }
     }
     uint4 o;
-    o.x = f2bf(a[0]) | ((unsigned)f2bf(a[1]) << 16);
-    o.y = f2bf(a[2]) | ((unsigned)f2bf(a[3]) << 16);
-    o.z = f2bf(a[4]) | ((unsigned)f2bf(a[5]) << 16);
-    o.w = f2bf(a[6]) | ((unsigned)f2bf(a[7]) << 16);
+    o.x = f2s(a[0]) | ((unsigned)f2s(a[1]) << 16);
+    o.y = f2s(a[2]) | ((unsigned)f2s(a[3]) << 16);
+    o.z = f2s(a[4]) | ((unsigned)f2s(a[5]) << 16);
+    o.w = f2s(a[6]) | ((unsigned)f2s(a[7]) << 16);
     *(uint4*)(dx + m * ld + c) = o;
   }
 }

@@ -16,7 +16,6 @@
 
 using namespace mi355;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) int srd_t;
 
@@ -132,21 +131,21 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void dgrad_s2_kernel(const D
     for (int q = 0; q < NCH; ++q)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t af[2][2];
+        st16x8_t af[2][2];
 #pragma unroll
         for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
           for (int ox = 0; ox < 2; ++ox) {
             const int r = wp * 16 + fr + ox;
-            af[oy][ox] = *(const bf16x8_t*)(ab + ((oy * NCH + q) * AR + r) * 128 + (((ks * 4 + fq) ^ (r & 7)) << 4));
+            af[oy][ox] = *(const st16x8_t*)(ab + ((oy * NCH + q) * AR + r) * 128 + (((ks * 4 + fq) ^ (r & 7)) << 4));
           }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
           for (int h = 0; h < CHF; ++h) {
             const int r = (wc * CHF + h) * 16 + fr;
-            const bf16x8_t wf = *(const bf16x8_t*)(wl + ((t * NCH + q) * 32 + r) * 128 + (((ks * 4 + fq) ^ ((r >> 1) & 7)) << 4));
-            acc[kCls[t]][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kOy[t]][kOx[t]], acc[kCls[t]][h], 0, 0, 0);
+            const st16x8_t wf = *(const st16x8_t*)(wl + ((t * NCH + q) * 32 + r) * 128 + (((ks * 4 + fq) ^ ((r >> 1) & 7)) << 4));
+            acc[kCls[t]][h] = MI355_MFMA_16x16x32(wf, af[kOy[t]][kOx[t]], acc[kCls[t]][h]);
           }
         }
       }
@@ -166,8 +165,8 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void dgrad_s2_kernel(const D
           const int pix = (c >> 1) * (2 * TP) + 2 * (wp * 16 + fr) + (c & 1);
           const int ch = (wc * CHF + h) * 16 + fq * 4;
           uint2 o;
-          o.x = (unsigned)f2bf(acc[c][h][0]) | ((unsigned)f2bf(acc[c][h][1]) << 16);
-          o.y = (unsigned)f2bf(acc[c][h][2]) | ((unsigned)f2bf(acc[c][h][3]) << 16);
+          o.x = (unsigned)f2s(acc[c][h][0]) | ((unsigned)f2s(acc[c][h][1]) << 16);
+          o.y = (unsigned)f2s(acc[c][h][2]) | ((unsigned)f2s(acc[c][h][3]) << 16);
           *(uint2*)(stg + pix * 32 + ch) = o;
         }
       lds_barrier();
@@ -204,14 +203,14 @@ __global__ __launch_bounds__(256, NCH == 1 ? 2 : 1) void dgrad_s2_kernel(const D
           const unsigned rr[4] = {ru.x, ru.y, ru.z, ru.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            v[2 * k] += bf2f((bf16_t)(rr[k] & 0xFFFF));
-            v[2 * k + 1] += bf2f((bf16_t)(rr[k] >> 16));
+            v[2 * k] += s2f((bf16_t)(rr[k] & 0xFFFF));
+            v[2 * k + 1] += s2f((bf16_t)(rr[k] >> 16));
           }
           uint4 o;
-          o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-          o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-          o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+          o.x = (unsigned)f2s(v[0]) | ((unsigned)f2s(v[1]) << 16);
+          o.y = (unsigned)f2s(v[2]) | ((unsigned)f2s(v[3]) << 16);
+          o.z = (unsigned)f2s(v[4]) | ((unsigned)f2s(v[5]) << 16);
+          o.w = (unsigned)f2s(v[6]) | ((unsigned)f2s(v[7]) << 16);
           *(uint4*)(p.dx + (opix + pix) * p.lddx + cobase + part * 8) = o;
         }
       }

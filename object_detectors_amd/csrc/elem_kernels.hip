@@ -14,27 +14,27 @@ struct bf8 {
 };
 __device__ __forceinline__ bf8 unpack8(const uint4 u) {
   bf8 r;
-  r.v[0] = bf2f((bf16_t)(u.x & 0xFFFF)); r.v[1] = bf2f((bf16_t)(u.x >> 16));
-  r.v[2] = bf2f((bf16_t)(u.y & 0xFFFF)); r.v[3] = bf2f((bf16_t)(u.y >> 16));
-  r.v[4] = bf2f((bf16_t)(u.z & 0xFFFF)); r.v[5] = bf2f((bf16_t)(u.z >> 16));
-  r.v[6] = bf2f((bf16_t)(u.w & 0xFFFF)); r.v[7] = bf2f((bf16_t)(u.w >> 16));
+  r.v[0] = s2f((bf16_t)(u.x & 0xFFFF)); r.v[1] = s2f((bf16_t)(u.x >> 16));
+  r.v[2] = s2f((bf16_t)(u.y & 0xFFFF)); r.v[3] = s2f((bf16_t)(u.y >> 16));
+  r.v[4] = s2f((bf16_t)(u.z & 0xFFFF)); r.v[5] = s2f((bf16_t)(u.z >> 16));
+  r.v[6] = s2f((bf16_t)(u.w & 0xFFFF)); r.v[7] = s2f((bf16_t)(u.w >> 16));
   return r;
 }
 __device__ __forceinline__ bf8 ld8(const bf16_t* p) {
   const uint4 u = *(const uint4*)p;
   bf8 r;
-  r.v[0] = bf2f((bf16_t)(u.x & 0xFFFF)); r.v[1] = bf2f((bf16_t)(u.x >> 16));
-  r.v[2] = bf2f((bf16_t)(u.y & 0xFFFF)); r.v[3] = bf2f((bf16_t)(u.y >> 16));
-  r.v[4] = bf2f((bf16_t)(u.z & 0xFFFF)); r.v[5] = bf2f((bf16_t)(u.z >> 16));
-  r.v[6] = bf2f((bf16_t)(u.w & 0xFFFF)); r.v[7] = bf2f((bf16_t)(u.w >> 16));
+  r.v[0] = s2f((bf16_t)(u.x & 0xFFFF)); r.v[1] = s2f((bf16_t)(u.x >> 16));
+  r.v[2] = s2f((bf16_t)(u.y & 0xFFFF)); r.v[3] = s2f((bf16_t)(u.y >> 16));
+  r.v[4] = s2f((bf16_t)(u.z & 0xFFFF)); r.v[5] = s2f((bf16_t)(u.z >> 16));
+  r.v[6] = s2f((bf16_t)(u.w & 0xFFFF)); r.v[7] = s2f((bf16_t)(u.w >> 16));
   return r;
 }
 __device__ __forceinline__ void st8(bf16_t* p, const bf8& r) {
   uint4 u;
-  u.x = (unsigned)f2bf(r.v[0]) | ((unsigned)f2bf(r.v[1]) << 16);
-  u.y = (unsigned)f2bf(r.v[2]) | ((unsigned)f2bf(r.v[3]) << 16);
-  u.z = (unsigned)f2bf(r.v[4]) | ((unsigned)f2bf(r.v[5]) << 16);
-  u.w = (unsigned)f2bf(r.v[6]) | ((unsigned)f2bf(r.v[7]) << 16);
+  u.x = (unsigned)f2s(r.v[0]) | ((unsigned)f2s(r.v[1]) << 16);
+  u.y = (unsigned)f2s(r.v[2]) | ((unsigned)f2s(r.v[3]) << 16);
+  u.z = (unsigned)f2s(r.v[4]) | ((unsigned)f2s(r.v[5]) << 16);
+  u.w = (unsigned)f2s(r.v[6]) | ((unsigned)f2s(r.v[7]) << 16);
   *(uint4*)p = u;
 }
 
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const long long b = i / hw, p = i - b * hw;
     for (int ch = 0; ch < c; ++ch) {
       const float v = x[(b * c + ch) * hw + p];
-      if (OUT_BF16) ((bf16_t*)out)[i * out_ld + ch] = f2bf(v);
+      if (OUT_BF16) ((bf16_t*)out)[i * out_ld + ch] = f2s(v);
       else ((float*)out)[i * out_ld + ch] = v;
     }
   }
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
     const int ch = (int)((i / hw) % c);
     const long long b = i / ((long long)hw * c);
     const long long src = (b * hw + p) * x_ld + ch;
-    out[i] = IN_BF16 ? bf2f(((const bf16_t*)x)[src]) : ((const float*)x)[src];
+    out[i] = IN_BF16 ? s2f(((const bf16_t*)x)[src]) : ((const float*)x)[src];
   }
 }
 
@@ -643,6 +643,7 @@ inline int grid_for(long long total) { return (int)min((long long)256 * 16, (tot
 }  // namespace
 
 
+#if !MI355_F16      // format-independent (fp32) parts exist once, in the bf16 object
 // ---- fused optimizer steps on the flat fp32 parameter / gradient buffers ------------------------------------------------------
 // torch.optim.SGD (yolo/procedures/initialize.py:38) and torch.optim.Adam (initialize.py:41) semantics, one pass over
 // {w, g, state}: 16-B accesses, grid-stride.  HBM bound: 20 B/param (SGD), 28 B/param (Adam).
@@ -719,8 +720,11 @@ __global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict_
   if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *flag = 1;      // every writer stores the same value: no atomic needed
 }
 
+#endif
+
 extern "C" {
 
+#if !MI355_F16
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
@@ -786,6 +790,8 @@ int mi355det_bn_eval_scale_shift(int32_t c, const float* gamma, const float* bet
   return check_launch("bn_eval");
 }
 
+#endif
+
 int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, int32_t c, int64_t pixels, float slope, const void* residual,
                         int32_t res_ld, void* out, int32_t out_ld, void* stream) {
   if (c <= 0 || c % 8 != 0 || pixels <= 0) return fail(MI355DET_EINVAL, "%s: channels must be a multiple of 8", "bn_act_fwd");
@@ -800,12 +806,11 @@ int mi355det_bn_act_fwd(const void* z, int32_t z_ld, const float* scale_shift, i
   return check_launch("bn_act_fwd");
 }
 
-namespace {
 struct BnReduceGeom {
   int gb, slabs, blocks;
   long long ppb;
 };
-BnReduceGeom bn_reduce_geom(int c, long long pixels) {
+static BnReduceGeom bn_reduce_geom(int c, long long pixels) {
   // a workgroup covers at most 64-128 channels (whole 128-byte lines per pixel) and more pixels instead: every workgroup ends with
   // 2 * (its channels) partial sums (one row of the workspace, or float atomics in the legacy form: ~24 G atomics/s device-wide measured),
   // so wide layers are cut into channel slabs (blockIdx.y) and large tensors get no more than ~2 workgroups per CU
@@ -826,7 +831,6 @@ BnReduceGeom bn_reduce_geom(int c, long long pixels) {
   g.blocks = (int)blocks;
   return g;
 }
-}  // namespace
 
 size_t mi355det_bn_act_bwd_reduce_workspace(int32_t c, int64_t pixels) {
   if (c <= 0 || c % 8 != 0 || pixels <= 0) return 0;
@@ -919,6 +923,7 @@ int mi355det_nhwc_to_nchw_f32(const void* x, int x_is_bf16, int32_t x_ld, int32_
   return check_launch("nhwc_to_nchw_f32");
 }
 
+#if !MI355_F16
 int mi355det_sgd_step_guarded(float* w, float* g, float* momentum_buf, int64_t n, float lr, float momentum, float dampening, float weight_decay,
                               float grad_scale, int nesterov, int first_step, int zero_grad, const int32_t* skip_flag, void* stream) {
   if (n <= 0) return MI355DET_OK;
@@ -956,5 +961,7 @@ int mi355det_grad_nonfinite(const float* g, int64_t n, int32_t* flag, void* stre
   hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, S(stream), g, (long long)(n / 4), (long long)n, (int*)flag);
   return check_launch("grad_nonfinite");
 }
+
+#endif
 
 }  // extern "C"

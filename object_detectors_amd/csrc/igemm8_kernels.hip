@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
     bar();
     if (wm == 1) bar();             // the second pixel half runs one barrier behind
 
-    bf16x8_t xf[2][4][2], wf[2][2][2];    // [half][tile][k-substep]
+    st16x8_t xf[2][4][2], wf[2][2][2];    // [half][tile][k-substep]
     // (measured and removed: software-pipelining the quarters by one phase - phase 1 multiplying the (W1, X1) fragments of the previous
     //  k-step so that every fragment read has a whole barrier interval to land - keeps all 96 fragment VGPRs live, hits the 256-VGPR cap
     //  with spills and is equal within noise: fragment-read latency is not what the loop waits for)
@@ -251,28 +251,28 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (xrd ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
+        for (int jj = 0; jj < 4; ++jj) xf[h][jj][ks] = *(const st16x8_t*)(smem + (xrd ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
     };
     auto read_w = [&](int h) {
       if (PROF == 4) return;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (wrd ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
+        for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const st16x8_t*)(smem + (wrd ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
     };
     // fragment reads at (half, k-substep) granularity: 2 W tiles / 4 X tiles of 16 rows each; `nxt` addresses the other k-step buffer
     auto rdw = [&](int h, int ks, bool nxt) {
       if (PROF == 4) return;
       const int base = nxt ? (wrd ^ kSTAGE) : wrd;
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
+      for (int ii = 0; ii < 2; ++ii) wf[h][ii][ks] = *(const st16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + ii * 16 * kROWB);
     };
     auto rdx = [&](int h, int ks, bool nxt, auto ntc) {
       if (PROF == 4) return;
       constexpr int NT = decltype(ntc)::value;            // 16-pixel tiles of this X half (4, or T1 for half 1)
       const int base = nxt ? (xrd ^ kSTAGE) : xrd;
 #pragma unroll
-      for (int jj = 0; jj < NT; ++jj) xf[h][jj][ks] = *(const bf16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
+      for (int jj = 0; jj < NT; ++jj) xf[h][jj][ks] = *(const st16x8_t*)(smem + (base ^ (ks << 6)) + h * kHALF + jj * 16 * kROWB);
     };
     // the 2 * NT MFMAs of one (W half, X half, k-substep)
     auto mf = [&](int hw, int hx, int ks, auto ntc) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int jj = 0; jj < NT; ++jj)
-          acc[hw * 2 + ii][hx * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj], 0, 0, 0);
+          acc[hw * 2 + ii][hx * 4 + jj] = MI355_MFMA_16x16x32(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj]);
     };
     // scheduling hint for a segment of `nm` MFMAs and `nr` independent fragment reads written before it: one read after each of the
     // first MFMAs (a ds_read_b128 fits the 16-cycle shadow of an MFMA), the rest of the MFMAs behind
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
 #pragma unroll
             for (int jj = 0; jj < 4; jj += 2) {
               f32x16_t* a16 = (f32x16_t*)&acc[hw * 2 + ii][hx * 4 + (jj & 2) * 2];
-              *a16 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[hw][ii][ks], xf[hx][jj + ii][ks], *a16, 0, 0, 0);      // every fragment read stays live
+              *a16 = MI355_MFMA_32x32x16(wf[hw][ii][ks], xf[hx][jj + ii][ks], *a16);      // every fragment read stays live
             }
         __builtin_amdgcn_s_setprio(0);
         return;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmParams p, con
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj)
-            acc[hw * 2 + ii][hx * 4 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj], 0, 0, 0);
+            acc[hw * 2 + ii][hx * 4 + jj] = MI355_MFMA_16x16x32(wf[hw][ii][ks], xf[hx][jj][ks], acc[hw * 2 + ii][hx * 4 + jj]);
       __builtin_amdgcn_s_setprio(0);
     };
 

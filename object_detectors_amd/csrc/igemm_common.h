@@ -6,7 +6,6 @@
 
 using namespace mi355;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
 
@@ -208,7 +207,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           // statistics of the STORED (bf16-rounded) tensor: the BN backward formulas then hold exactly
-          const float v = bf2f(f2bf(acc[i][j][r]));
+          const float v = s2f(f2s(acc[i][j][r]));
           s1 += v;
           s2 += v * v;
         }
@@ -356,8 +355,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
           }
         }
         uint2 o;
-        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        o.x = (unsigned)f2s(v[0]) | ((unsigned)f2s(v[1]) << 16);
+        o.y = (unsigned)f2s(v[2]) | ((unsigned)f2s(v[3]) << 16);
         *(uint2*)(reg + (jj * 16 + fr) * PITCH + (i * 16 + fq * 4) * 2) = o;
       }
     }
@@ -374,18 +373,18 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
           unsigned oo[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float lo = bf2f((bf16_t)(vi[q] & 0xFFFF)) + bf2f((bf16_t)(ri[q] & 0xFFFF));
-            float hi = bf2f((bf16_t)(vi[q] >> 16)) + bf2f((bf16_t)(ri[q] >> 16));
+            float lo = s2f((bf16_t)(vi[q] & 0xFFFF)) + s2f((bf16_t)(ri[q] & 0xFFFF));
+            float hi = s2f((bf16_t)(vi[q] >> 16)) + s2f((bf16_t)(ri[q] >> 16));
             if (EPI == EPI_RES && mask_mode) {
-              const float alo = bf2f((bf16_t)(ri[q] & 0xFFFF)), ahi = bf2f((bf16_t)(ri[q] >> 16));
-              lo = (p.relu == 4 || alo > 0.f) ? bf2f((bf16_t)(vi[q] & 0xFFFF)) * msc[EPI == EPI_RES ? 2 * q : 0] : 0.f;
-              hi = (p.relu == 4 || ahi > 0.f) ? bf2f((bf16_t)(vi[q] >> 16)) * msc[EPI == EPI_RES ? 2 * q + 1 : 0] : 0.f;
+              const float alo = s2f((bf16_t)(ri[q] & 0xFFFF)), ahi = s2f((bf16_t)(ri[q] >> 16));
+              lo = (p.relu == 4 || alo > 0.f) ? s2f((bf16_t)(vi[q] & 0xFFFF)) * msc[EPI == EPI_RES ? 2 * q : 0] : 0.f;
+              hi = (p.relu == 4 || ahi > 0.f) ? s2f((bf16_t)(vi[q] >> 16)) * msc[EPI == EPI_RES ? 2 * q + 1 : 0] : 0.f;
             }
             if (relu) {
               lo = fmaxf(lo, 0.f);
               hi = fmaxf(hi, 0.f);
             }
-            oo[q] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+            oo[q] = (unsigned)f2s(lo) | ((unsigned)f2s(hi) << 16);
           }
           v = make_uint4(oo[0], oo[1], oo[2], oo[3]);
         }
@@ -399,8 +398,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
 #pragma unroll
             for (int hsel = 0; hsel < 2; ++hsel) {
               const int k = q * 2 + hsel;
-              const float gv = bf2f((bf16_t)(hsel ? gi[q] >> 16 : gi[q] & 0xFFFF));
-              const float zv = bf2f((bf16_t)(hsel ? zi[q] >> 16 : zi[q] & 0xFFFF));
+              const float gv = s2f((bf16_t)(hsel ? gi[q] >> 16 : gi[q] & 0xFFFF));
+              const float zv = s2f((bf16_t)(hsel ? zi[q] >> 16 : zi[q] & 0xFFFF));
               const float yv = zv * bn_sc[k] + bn_sh[k];
               const float dy = yv > 0.f ? gv : gv * p.slope;
               bn_a1[k] += dy;

@@ -13,6 +13,10 @@ TuneMap& tune_table(int id) {
   static TuneMap tables[TUNE_TABLES];
   return tables[(unsigned)id < (unsigned)TUNE_TABLES ? id : 0];
 }
+TuneMap& tune_timed(int id) {
+  static TuneMap tables[TUNE_TABLES];
+  return tables[(unsigned)id < (unsigned)TUNE_TABLES ? id : 0];
+}
 }  // namespace mi355
 
 using namespace mi355;
@@ -40,7 +44,10 @@ int mi355det_tune_import(const void* buf, size_t bytes, int replace) {
   for (size_t i = 0; i < n; ++i)
     if (e[i].table >= (uint32_t)TUNE_TABLES) return fail(MI355DET_EINVAL, "%s: unknown table id %lld", "tune_import", (long long)e[i].table);
   if (replace)
-    for (int t = 0; t < TUNE_TABLES; ++t) tune_table(t).clear();
+    for (int t = 0; t < TUNE_TABLES; ++t) {
+      tune_table(t).clear();
+      tune_timed(t).clear();
+    }
   for (size_t i = 0; i < n; ++i) tune_table((int)e[i].table)[(unsigned long long)e[i].key] = (int)e[i].value;
   return MI355DET_OK;
 }
@@ -52,7 +59,10 @@ int mi355det_tune_lock(int on) {
 }
 
 int mi355det_tune_clear(void) {
-  for (int t = 0; t < TUNE_TABLES; ++t) tune_table(t).clear();
+  for (int t = 0; t < TUNE_TABLES; ++t) {
+    tune_table(t).clear();
+    tune_timed(t).clear();
+  }
   g_tune_locked = false;
   return MI355DET_OK;
 }

@@ -27,8 +27,6 @@
 
 using namespace mi355;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -75,9 +73,9 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
+__device__ __forceinline__ st16x4_t lds_tr(const char* p) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-  return __builtin_bit_cast(bf16x4_t, v);
+  return __builtin_bit_cast(st16x4_t, v);
 }
 
 template <int MODE>
@@ -89,11 +87,11 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
   const int fr = lane & 15, fq = lane >> 4;
 
   // ---- weight fragments (A operand: row fr of fragment i = channel (fr/4)*8 + i*4 + fr%4, k chunk fq)
-  bf16x8_t wf[2];
+  st16x8_t wf[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ch = (fr >> 2) * 8 + i * 4 + (fr & 3);
-    wf[i] = *(const bf16x8_t*)(p.w + ch * 32 + fq * 8);
+    wf[i] = *(const st16x8_t*)(p.w + ch * 32 + fq * 8);
   }
   // ---- im2col fragment (B operand): this lane's 8 k values of a pixel = 8 LDS element offsets relative to the pixel's halo position
   int koff[8];
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
     constexpr int s_ = decltype(SLOT)::value;
     bf16_t* s = (bf16_t*)(smem + buf * IMG_BYTES);
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) s[h_lds[i]] = f2bf(hv[s_][i]);
+    for (int i = 0; i < PER_T; ++i) s[h_lds[i]] = f2s(hv[s_][i]);
   };
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   // activation / gradient tile: fragment f = 16 consecutive pixels of tile row 2*wid + f/2; scalar offset = the fragment's first pixel
@@ -211,7 +209,7 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
 
   // the zero slots behind both image buffers (store_halo never touches them), and the ones slots
   if (tid < 64) *(unsigned*)(smem + (tid >> 5) * IMG_BYTES + ZBASE + (tid & 31) * 4) = 0u;
-  if (tid >= 64 && tid < 112) *(unsigned*)(smem + ((tid - 64) / 24) * IMG_BYTES + ONES + ((tid - 64) % 24) * 4) = 0x3F803F80u;
+  if (tid >= 64 && tid < 112) *(unsigned*)(smem + ((tid - 64) / 24) * IMG_BYTES + ONES + ((tid - 64) % 24) * 4) = MI355_F16 ? 0x3C003C00u : 0x3F803F80u;      // two stored 1.0
 
   typedef std::integral_constant<int, 0> S0;
   typedef std::integral_constant<int, 1> S1;
@@ -252,10 +250,10 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
       u.y = v[2] | ((unsigned)v[3] << 16);
       u.z = v[4] | ((unsigned)v[5] << 16);
       u.w = v[6] | ((unsigned)v[7] << 16);
-      const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, u);
+      const st16x8_t xf = __builtin_bit_cast(st16x8_t, u);
       f32x4_t acc[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = MI355_MFMA_16x16x32(wf[i], xf, f32x4_t{0.f, 0.f, 0.f, 0.f});
       if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float y = acc[k >> 2][k & 3] * sc[k] + sh[k];
-          o[k] = f2bf(fmaxf(y, y * p.slope));         // LeakyReLU, 0 < slope < 1
+          o[k] = f2s(fmaxf(y, y * p.slope));         // LeakyReLU, 0 < slope < 1
         }
         uint4 w4;
         w4.x = o[0] | ((unsigned)o[1] << 16);
@@ -288,7 +286,7 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float z = acc[k >> 2][k & 3];
-          const float gg = __uint_as_float((k & 1) ? (gi[k >> 1] & 0xFFFF0000u) : (gi[k >> 1] << 16));
+          const float gg = s2f((bf16_t)((k & 1) ? gi[k >> 1] >> 16 : gi[k >> 1] & 0xFFFFu));
           const float y = z * sc[k] + sh[k];
           const float dy = y > 0.f ? gg : gg * p.slope;
           s1[k] += dy;
@@ -302,10 +300,10 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float z = acc[k >> 2][k & 3];
-          const float gg = __uint_as_float((k & 1) ? (gi[k >> 1] & 0xFFFF0000u) : (gi[k >> 1] << 16));
+          const float gg = s2f((bf16_t)((k & 1) ? gi[k >> 1] >> 16 : gi[k >> 1] & 0xFFFFu));
           const float y = z * sc[k] + sh[k];
           const float dy = y > 0.f ? gg : gg * p.slope;
-          o[k] = f2bf(MODE == 4 ? dy : ca[k] * dy + (cb[k] * z + cc[k]));
+          o[k] = f2s(MODE == 4 ? dy : ca[k] * dy + (cb[k] * z + cc[k]));
         }
         uint4 w4;
         w4.x = o[0] | ((unsigned)o[1] << 16);
@@ -325,14 +323,14 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
       const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        bf16x8_t af[2], bfr[2];
+        st16x8_t af[2], bfr[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int prow = rr * 32 + 8 * g4 + 4 * h + q;
           const int sw = (prow >> 3) & 1;
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const bf16x4_t t4 = lds_tr(dzt + prow * 64 + ((i ^ sw) << 5) + pp * 8);
+            const st16x4_t t4 = lds_tr(dzt + prow * 64 + ((i ^ sw) << 5) + pp * 8);
             af[i][4 * h + 0] = t4[0];
             af[i][4 * h + 1] = t4[1];
             af[i][4 * h + 2] = t4[2];
@@ -349,18 +347,18 @@ __global__ __launch_bounds__(256, (MODE == 4 ? 2 : MODE >= 2 ? 3 : 4)) void stem
           u.y = v[2] | ((unsigned)v[3] << 16);
           u.z = v[4] | ((unsigned)v[5] << 16);
           u.w = v[6] | ((unsigned)v[7] << 16);
-          bfr[jb] = __builtin_bit_cast(bf16x8_t, u);
+          bfr[jb] = __builtin_bit_cast(st16x8_t, u);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int jb = 0; jb < 2; ++jb) accw[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[jb], accw[i][jb], 0, 0, 0);
+          for (int jb = 0; jb < 2; ++jb) accw[i][jb] = MI355_MFMA_16x16x32(af[i], bfr[jb], accw[i][jb]);
         if constexpr (MODE == 4) {
           // Gram matrix of the (im2col | 1) operand: the B fragment of columns ja*16 + fr IS the A fragment of rows ja*16 + fr of its transpose
 #pragma unroll
           for (int ja = 0; ja < 2; ++ja)
 #pragma unroll
-            for (int jb = 0; jb < 2; ++jb) accg[ja][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ja], bfr[jb], accg[ja][jb], 0, 0, 0);
+            for (int jb = 0; jb < 2; ++jb) accg[ja][jb] = MI355_MFMA_16x16x32(bfr[ja], bfr[jb], accg[ja][jb]);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -463,7 +461,7 @@ __global__ __launch_bounds__(64) void stem_bwd_sums_kernel(const float* __restri
   const int c = threadIdx.x;
   if (c >= 32) return;
   float dot = 0.f;
-  for (int j = 0; j < 27; ++j) dot += bf2f(w[c * 32 + j]) * ag[c * 32 + j];
+  for (int j = 0; j < 27; ++j) dot += s2f(w[c * 32 + j]) * ag[c * 32 + j];
   const float sdy = ag[c * 32 + 27];
   sums[c] = sdy;
   sums[32 + c] = ss[96 + c] * (dot - ss[64 + c] * sdy);
@@ -479,7 +477,7 @@ __global__ __launch_bounds__(1024) void stem_bwd_finish_kernel(const float* __re
   __shared__ float w_s[1024];
   const int t = threadIdx.x;
   g_s[t] = ag[1024 + t];
-  w_s[t] = bf2f(w[t]);
+  w_s[t] = s2f(w[t]);
   __syncthreads();
   const int c = t >> 5, j = t & 31;
   if (j < 27) {

@@ -16,7 +16,6 @@
 
 using namespace mi355;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
@@ -78,16 +77,16 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
   if (p.ss1 && tid < 128) aff1[tid] = p.ss1[tid];
 
   // ---- stem weights (row fr of fragment i = channel (fr/4)*8 + i*4 + fr%4: a lane's accumulators are 8 consecutive channels)
-  bf16x8_t wf0[2];
+  st16x8_t wf0[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) wf0[i] = *(const bf16x8_t*)(p.w0 + ((fr >> 2) * 8 + i * 4 + (fr & 3)) * 32 + fq * 8);
+  for (int i = 0; i < 2; ++i) wf0[i] = *(const st16x8_t*)(p.w0 + ((fr >> 2) * 8 + i * 4 + (fr & 3)) * 32 + fq * 8);
   // ---- 32 -> 64 weights of this wave's 32 channels, all nine taps, resident in registers
-  bf16x8_t wf1[9][2];
+  st16x8_t wf1[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      wf1[t][i] = *(const bf16x8_t*)(p.w1 + (ch_half * 32 + (fr >> 2) * 8 + i * 4 + (fr & 3)) * 288 + t * 32 + fq * 8);
+      wf1[t][i] = *(const st16x8_t*)(p.w1 + (ch_half * 32 + (fr >> 2) * 8 + i * 4 + (fr & 3)) * 288 + t * 32 + fq * 8);
   // ---- im2col offsets of the stem: k = fq*8 + e -> (tap, c)
   int koff[8];
 #pragma unroll
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
   auto store_halo = [&](int buf) {
     bf16_t* s = (bf16_t*)(smem + buf * IMG_BYTES);
 #pragma unroll
-    for (int i = 0; i < PER_T; ++i) s[h_lds[i]] = f2bf(hv[i]);
+    for (int i = 0; i < PER_T; ++i) s[h_lds[i]] = f2s(hv[i]);
   };
   if (tid < 64) *(unsigned*)(smem + (tid >> 5) * IMG_BYTES + ZBASE + (tid & 31) * 4) = 0u;
 
@@ -190,17 +189,17 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
       u.y = v[2] | ((unsigned)v[3] << 16);
       u.z = v[4] | ((unsigned)v[5] << 16);
       u.w = v[6] | ((unsigned)v[7] << 16);
-      const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, u);
+      const st16x8_t xf = __builtin_bit_cast(st16x8_t, u);
       f32x4_t acc[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = MI355_MFMA_16x16x32(wf0[i], xf, f32x4_t{0.f, 0.f, 0.f, 0.f});
       const int ay = 2 * oy0 - 1 + r, ax = 2 * ox0 - 1 + lc;        // activation pixel in the image frame
       const bool inside = ay >= 0 && ax >= 0;                       // row / column -1 is the convolution's zero padding, not a stem output
       unsigned short o[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float y = acc[k >> 2][k & 3] * sc[k] + sh[k];
-        o[k] = inside ? f2bf(fmaxf(y, y * p.slope)) : (unsigned short)0;
+        o[k] = inside ? f2s(fmaxf(y, y * p.slope)) : (unsigned short)0;
       }
       uint4 w4;
       w4.x = o[0] | ((unsigned)o[1] << 16);
@@ -230,9 +229,9 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
         const int col = (kw & 1) * A_PLANE + idx * 64 + ((fq ^ ((idx >> 1) & 3)) << 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const bf16x8_t xf = *(const bf16x8_t*)(a0s + (2 * (row_half * 4 + j) + kh) * A_ROW + col);
+          const st16x8_t xf = *(const st16x8_t*)(a0s + (2 * (row_half * 4 + j) + kh) * A_ROW + col);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[kh * 3 + kw][i], xf, acc[j][i], 0, 0, 0);
+          for (int i = 0; i < 2; ++i) acc[j][i] = MI355_MFMA_16x16x32(wf1[kh * 3 + kw][i], xf, acc[j][i]);
         }
       }
 #pragma unroll
@@ -246,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void stem_l1_kernel(const StemL1Params p) {
           zz = zz * aff1[ch] + aff1[64 + ch];
           zz = fmaxf(zz, zz * p.slope);
         }
-        o[k] = f2bf(zz);
-        const float v = bf2f(o[k]);                 // statistics of the STORED tensor (igemm_common.h, EPI_STATS)
+        o[k] = f2s(zz);
+        const float v = s2f(o[k]);                 // statistics of the STORED tensor (igemm_common.h, EPI_STATS)
         s1[k] += v;
         s2[k] += v * v;
       }

@@ -13,10 +13,16 @@ typedef std::unordered_map<unsigned long long, int> TuneMap;
 TuneMap& tune_table(int id);       // defined in lib.cpp (one copy for the whole library)
 extern bool g_tune_locked;         // true: a shape that has an entry is never timed again (the entry came from a record)
 
+TuneMap& tune_timed(int id);       // shapes timed in THIS process (value unused): the 11 equal layers of a Darknet stage are timed once, not 11 times
+
+// true: do not time this shape - its choice came from a locked record, or this process has timed it already (the choice stands either way)
 inline bool tune_locked_has(int id, unsigned long long key) {
-  if (!g_tune_locked) return false;
   const TuneMap& m = tune_table(id);
-  return m.find(key) != m.end();
+  if (m.find(key) == m.end()) return false;
+  if (g_tune_locked) return true;
+  const TuneMap& t = tune_timed(id);
+  return t.find(key) != t.end();
 }
+inline void tune_mark_timed(int id, unsigned long long key) { tune_timed(id)[key] = 1; }
 
 }  // namespace mi355

@@ -18,8 +18,6 @@
 
 using namespace mi355;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -89,9 +87,9 @@ __device__ __forceinline__ void bufld16(srd_t rsrc, const void* lds_dst_uniform,
 
 __device__ __forceinline__ int rowf(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-__device__ __forceinline__ bf16x4_t lds_tr(const char* p) {
+__device__ __forceinline__ st16x4_t lds_tr(const char* p) {
   s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-  return __builtin_bit_cast(bf16x4_t, v);
+  return __builtin_bit_cast(st16x4_t, v);
 }
 
 // CI x CJ = 16-wide fragments per wave along cout / n': 4 x 4 is the full 128x128 tile; layers whose Cout or k*k*Cin is 32 / 64 (the
@@ -301,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     const char* sx = sd + WG_BKP * WG_ROWB;
 #pragma unroll
     for (int ks = 0; ks < WG_BKP / 32; ++ks) {
-      bf16x8_t af[CI], bfr[CJ];
+      st16x8_t af[CI], bfr[CJ];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = ks * 32 + 8 * g + 4 * h + q;
@@ -309,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < CI; ++i) {
           const int blk = wr * CI + i;   // 32-byte block index of this 16-channel group
-          const bf16x4_t v = lds_tr(sd + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
+          const st16x4_t v = lds_tr(sd + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
           af[i][4 * h + 0] = v[0];
           af[i][4 * h + 1] = v[1];
           af[i][4 * h + 2] = v[2];
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
           const int blk = wc * CJ + j;
-          const bf16x4_t v = lds_tr(sx + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
+          const st16x4_t v = lds_tr(sx + row * WG_ROWB + ((blk ^ f) << 5) + pp * 8);
           bfr[j][4 * h + 0] = v[0];
           bfr[j][4 * h + 1] = v[1];
           bfr[j][4 * h + 2] = v[2];
@@ -328,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int i = 0; i < CI; ++i)
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < CJ; ++j) acc[i][j] = MI355_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   __shared__ float red[4][64];
   float s = 0.f;
   if (ch < c)
-    for (long long m = blockIdx.y * 4 + pl; m < pixels; m += (long long)gridDim.y * 4) s += bf2f(x[m * ld + ch]);
+    for (long long m = blockIdx.y * 4 + pl; m < pixels; m += (long long)gridDim.y * 4) s += s2f(x[m * ld + ch]);
   red[pl][threadIdx.x & 63] = s;
   __syncthreads();
   if (pl == 0 && ch < c) atomicAdd(out + ch, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
@@ -482,8 +480,8 @@ __global__ __launch_bounds__(256) void colsum8p_kernel(const bf16_t* __restrict_
         const unsigned uu[4] = {u[q].x, u[q].y, u[q].z, u[q].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          a[2 * e] += bf2f((bf16_t)(uu[e] & 0xFFFF));
-          a[2 * e + 1] += bf2f((bf16_t)(uu[e] >> 16));
+          a[2 * e] += s2f((bf16_t)(uu[e] & 0xFFFF));
+          a[2 * e + 1] += s2f((bf16_t)(uu[e] >> 16));
         }
       }
     }
@@ -492,8 +490,8 @@ __global__ __launch_bounds__(256) void colsum8p_kernel(const bf16_t* __restrict_
       const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a[2 * e] += bf2f((bf16_t)(uu[e] & 0xFFFF));
-        a[2 * e + 1] += bf2f((bf16_t)(uu[e] >> 16));
+        a[2 * e] += s2f((bf16_t)(uu[e] & 0xFFFF));
+        a[2 * e + 1] += s2f((bf16_t)(uu[e] >> 16));
       }
     }
   }
@@ -550,8 +548,8 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
       const unsigned uu[4] = {u.x, u.y, u.z, u.w}, vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        a[2 * q] += bf2f((bf16_t)(uu[q] & 0xFFFF)) + bf2f((bf16_t)(vv[q] & 0xFFFF));
-        a[2 * q + 1] += bf2f((bf16_t)(uu[q] >> 16)) + bf2f((bf16_t)(vv[q] >> 16));
+        a[2 * q] += s2f((bf16_t)(uu[q] & 0xFFFF)) + s2f((bf16_t)(vv[q] & 0xFFFF));
+        a[2 * q + 1] += s2f((bf16_t)(uu[q] >> 16)) + s2f((bf16_t)(vv[q] >> 16));
       }
     }
     for (; m < pixels; m += stride) {
@@ -559,8 +557,8 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
       const unsigned uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        a[2 * q] += bf2f((bf16_t)(uu[q] & 0xFFFF));
-        a[2 * q + 1] += bf2f((bf16_t)(uu[q] >> 16));
+        a[2 * q] += s2f((bf16_t)(uu[q] & 0xFFFF));
+        a[2 * q + 1] += s2f((bf16_t)(uu[q] >> 16));
       }
     }
   }
@@ -600,6 +598,7 @@ unsigned long long wgrad_key(const mi355det_conv_shape* s) {
   k = k * 4099 + s->cout;
   k = k * 4099 + s->cin;
   k = k * 17 + s->ksize * 4 + s->stride;
+  k = k * 2 + MI355_F16;
   return k;
 }
 
@@ -676,7 +675,10 @@ int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, co
   g_wgrad_force = 0;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (best > 0) g_wgrad_tuned[wgrad_key(s)] = best;
+  if (best > 0) {
+    g_wgrad_tuned[wgrad_key(s)] = best;
+    tune_mark_timed(TUNE_WGRAD, wgrad_key(s));
+  }
   return best;
 }
 

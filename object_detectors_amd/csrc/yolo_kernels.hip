@@ -247,14 +247,19 @@ __device__ __forceinline__ void bce_class(float x, float y, float pw, bool eql, 
   grad = w * af * (dbce * mf + bce * dmf);
 }
 
-template <bool BF16>
+// gradient view format GF: 0 = fp32, 1 = bf16, 2 = IEEE fp16 (the engine's fp16 storage: yolo/procedures/initialize.py:44-45, apex O2)
+__device__ __forceinline__ bf16_t f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ __forceinline__ float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+template <int GF>
 __device__ __forceinline__ void grad_store(void* base, long long off, float v) {
-  if (BF16) ((bf16_t*)base)[off] = f2bf(v);
+  if (GF == 1) ((bf16_t*)base)[off] = f2bf(v);
+  else if (GF == 2) ((bf16_t*)base)[off] = f2h(v);
   else ((float*)base)[off] = v;
 }
-template <bool BF16>
+template <int GF>
 __device__ __forceinline__ void grad_add(void* base, long long off, float v) {
-  if (BF16) ((bf16_t*)base)[off] = f2bf(bf2f(((bf16_t*)base)[off]) + v);
+  if (GF == 1) ((bf16_t*)base)[off] = f2bf(bf2f(((bf16_t*)base)[off]) + v);
+  else if (GF == 2) ((bf16_t*)base)[off] = f2h(h2f(((bf16_t*)base)[off]) + v);
   else ((float*)base)[off] += v;
 }
 
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(1024) void yolo_noobj_count_kernel(const unsigned c
 // No-object confidence term (yolo_forw.py:131-133,144): one thread per (image, anchor), lanes run
 // over pixels within an anchor plane.  Per-block partials {loss, sum sigmoid, count}.
 #define DENSE_THREADS 256
-template <bool BF16>
+template <int GF>
 __global__ __launch_bounds__(DENSE_THREADS) void yolo_noobj_kernel(mi355det_yolo_geom geom, Views heads, Views grads, int has_grad,
                                                                     const unsigned char* __restrict__ noobj, float alpha,
                                                                     float gamma, float gscale, float* __restrict__ partials,
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void yolo_noobj_kernel(mi355det_yolo
       c = 1.0f;
       if (has_grad) {
         const mi355det_head_view gv = grads.h[k];
-        grad_store<BF16>(gv.ptr, b * gv.sb + ch * gv.sc + pix * gv.sp, grad * gscale);
+        grad_store<GF>(gv.ptr, b * gv.sb + ch * gv.sc + pix * gv.sp, grad * gscale);
       }
     }
   }
@@ -384,7 +389,7 @@ __device__ __forceinline__ D4 iou_metric_dual(const DBox a, const DBox b, int io
 // partial layout per image: xy, wh, iou_loss, pos_conf, cls, iou_sum, pconf_sum, pcls_sum, sum of sigmoid(raw) over all classes
 // (class_loss 0/2 statistics), sum of the target class weights (CrossEntropyLoss(weight, 'mean') divisor)
 #define POS_NP 10
-template <bool BF16>
+template <int GF>
 __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom, mi355det_yolo_loss_cfg cfg, Views heads, Views grads,
                                                          int has_grad, const int* __restrict__ gt_off,
                                                          const long long* __restrict__ gt_label,
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
         ss += 1.0f / (1.0f + __expf(-raw));
         if (has_grad) {
           const mi355det_head_view gv = grads.h[an.scale];
-          grad_add<BF16>(gv.ptr, b * gv.sb + (long long)an.pix * gv.sp + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * w * gr * gs_cls);
+          grad_add<GF>(gv.ptr, b * gv.sb + (long long)an.pix * gv.sp + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * w * gr * gs_cls);
         }
       }
       acc[4] += cfg.lambda_cls * wave_sum(ls);
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
         else if (lane == 2) gr = cfg.lambda_wh * 2.0f * dwh0 * gs_xy - cfg.lambda_iou * iou.d[2] * gs;
         else if (lane == 3) gr = cfg.lambda_wh * 2.0f * dwh1 * gs_xy - cfg.lambda_iou * iou.d[3] * gs;
         else gr = cfg.lambda_conf * pg * gs;
-        grad_add<BF16>(gv.ptr, gb0 + (ch0 + lane) * gv.sc, gr);
+        grad_add<GF>(gv.ptr, gb0 + (ch0 + lane) * gv.sc, gr);
       }
       if (cfg.class_loss == 1) {
         for (int c = lane; c < C; c += WAVE) {
@@ -518,7 +523,7 @@ __global__ __launch_bounds__(WAVE) void yolo_pos_kernel(mi355det_yolo_geom geom,
           const float w = idf ? idf[c] : 1.0f;
           const float z = w * raw;
           float gr = __expf(z - m) / se - (c == label ? 1.0f : 0.0f);
-          grad_add<BF16>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * wy * w * gr * gs_cls);
+          grad_add<GF>(gv.ptr, gb0 + (ch0 + 5 + c) * gv.sc, cfg.lambda_cls * wy * w * gr * gs_cls);
         }
       }
     }
@@ -1154,17 +1159,18 @@ int mi355det_yolo_loss(const mi355det_yolo_geom* geom, const mi355det_yolo_loss_
   const float inv_ng = 1.0f / (float)num_gt;
   const float gscale = cfg->lambda_no_conf * cfg->grad_scale * (mean ? 1.0f : inv_ng);
   const int* cnt = mean ? count_p : nullptr;
-  if (cfg->grad_is_bf16) {
-    hipLaunchKernelGGL(yolo_noobj_kernel<true>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,
-                       cfg->alpha, cfg->gamma, gscale, dense_p, N, cnt);
-    hipLaunchKernelGGL(yolo_pos_kernel<true>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,
-                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, bs, pos_p);
-  } else {
-    hipLaunchKernelGGL(yolo_noobj_kernel<false>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,
-                       cfg->alpha, cfg->gamma, gscale, dense_p, N, cnt);
-    hipLaunchKernelGGL(yolo_pos_kernel<false>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,
-                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, bs, pos_p);
-  }
+  if (cfg->grad_is_bf16 < 0 || cfg->grad_is_bf16 > 2) return fail(MI355DET_EINVAL, "%s: grad_is_bf16 must be 0 (fp32), 1 (bf16) or 2 (fp16)", "yolo_loss");
+#define YOLO_LOSS_LAUNCH(GF)                                                                                                                  \
+  do {                                                                                                                                        \
+    hipLaunchKernelGGL(yolo_noobj_kernel<GF>, dim3(dblocks, bs), dim3(DENSE_THREADS), 0, S(stream), *geom, hv, gv, has_grad, noobj,           \
+                       cfg->alpha, cfg->gamma, gscale, dense_p, N, cnt);                                                                      \
+    hipLaunchKernelGGL(yolo_pos_kernel<GF>, dim3(bs), dim3(WAVE), 0, S(stream), *geom, *cfg, hv, gv, has_grad, gt_off,                        \
+                       (const long long*)gt_label, (const long long*)obj_idx, tgt, idf, inv_ng, bs, pos_p);                                   \
+  } while (0)
+  if (cfg->grad_is_bf16 == 1) YOLO_LOSS_LAUNCH(1);
+  else if (cfg->grad_is_bf16 == 2) YOLO_LOSS_LAUNCH(2);
+  else YOLO_LOSS_LAUNCH(0);
+#undef YOLO_LOSS_LAUNCH
   hipLaunchKernelGGL(yolo_reduce_kernel, dim3(1), dim3(256), 0, S(stream), dense_p, bs * dblocks, pos_p, bs, cfg->lambda_no_conf,
                      (float)num_gt, geom->num_classes, cfg->class_loss, cfg->reduction_mean, out12);
   return check_launch("yolo_loss");

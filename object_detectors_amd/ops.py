@@ -9,7 +9,36 @@ import math
 import torch
 
 from . import _lib
-from ._lib import HeadView, YoloGeom, YoloLossCfg, check, lib, ptr, stream_ptr
+from ._lib import HeadView, YoloGeom, YoloLossCfg, check, ptr, stream_ptr
+
+# ---- storage format seen by the convolution helpers below: "bf16" (default) or, inside `with ops.storage("fp16"):`, the fp16 twins of the
+#      entry points (include/mi355det_f16.h) and torch.float16 buffers.  The engines carry their own format (YoloV3Engine(storage=...)).
+_STORAGE = ["bf16"]
+
+
+def lib():
+    return _lib.storage_lib(_STORAGE[0])
+
+
+def act_dtype():
+    return torch.float16 if _STORAGE[0] == "fp16" else torch.bfloat16
+
+
+class storage:
+    def __init__(self, fmt):
+        if fmt not in ("bf16", "fp16"):
+            raise ValueError("storage must be 'bf16' or 'fp16'")
+        self.fmt = fmt
+
+    def __enter__(self):
+        self.prev = _STORAGE[0]
+        _STORAGE[0] = self.fmt
+        return self
+
+    def __exit__(self, *exc):
+        _STORAGE[0] = self.prev
+        return False
+
 
 
 def _f32c(t):
@@ -431,9 +460,9 @@ def pack_weights(shape, w_master, want_dgrad=True, ohwi=False, wf=None, wd=None)
     cp = cout_pad_of(shape.cout)
     kk = shape.ksize * shape.ksize
     if wf is None:
-        wf = torch.empty(cp * kk * shape.cin, device=dev, dtype=torch.bfloat16)
+        wf = torch.empty(cp * kk * shape.cin, device=dev, dtype=act_dtype())
     if want_dgrad and wd is None:
-        wd = torch.empty(lib().mi355det_dgrad_pack_elems(C.byref(shape)), device=dev, dtype=torch.bfloat16)
+        wd = torch.empty(lib().mi355det_dgrad_pack_elems(C.byref(shape)), device=dev, dtype=act_dtype())
     check(lib().mi355det_pack_weights(C.byref(shape), ptr(w_master.contiguous()), int(ohwi), ptr(wf), cp, ptr(wd), stream_ptr()),
           "pack_weights")
     return wf, wd

@@ -96,11 +96,22 @@ def bn_name(conv_name):
 
 
 class YoloV3Engine:
-    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0, sync_bn=False, process_group=None):
-        """sync_bn: the `batch_norm_sync` switch of the reference (yolo/procedures/initialize.py:31-32, apex convert_syncbn_model): every
+    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0, sync_bn=False, process_group=None, storage="bf16"):
+        """storage: format of every stored activation, activation gradient and packed weight - "bf16" (default) or "fp16", the format of the
+        reference's mixed-precision recipe (apex O2: yolo/batch_files/sample.txt:28-44, initialize.py:44-45); accumulation, BatchNorm statistics,
+        master weights and gradients stay fp32 either way.  fp16 has three more mantissa bits and five fewer exponent bits: train it with a loss
+        scale (optim.DynamicLossScaler, train_step(..., grad_scale=S)) exactly as the reference does.  MI355DET_STORAGE overrides the default.
+        sync_bn: the `batch_norm_sync` switch of the reference (yolo/procedures/initialize.py:31-32, apex convert_syncbn_model): every
         BatchNorm layer normalises with the statistics of the GLOBAL batch - one all-reduce of the per-channel (sum, sum of squares) in
         forward and one of (sum dy, sum dy*xhat) in backward per layer (2C floats each: latency-bound, 72 layers)."""
         lib()   # fail loudly if the HIP library is missing
+        storage = os.environ.get("MI355DET_STORAGE", storage) if storage == "bf16" else storage
+        if storage not in ("bf16", "fp16"):
+            raise ValueError("storage must be 'bf16' or 'fp16'")
+        self.storage = storage
+        self.L = _lib.storage_lib(storage)                 # entry points of this storage format (fp16: the *_f16 twins)
+        self.adt = torch.float16 if storage == "fp16" else torch.bfloat16
+        self.grad_fmt = 2 if storage == "fp16" else 1       # mi355det_yolo_loss_cfg.grad_is_bf16
         self.sync_bn, self.process_group = bool(sync_bn), process_group
         if self.sync_bn and process_group is None:
             import torch.distributed as dist
@@ -178,10 +189,10 @@ class YoloV3Engine:
         for s in self.specs:
             shp = self._wshape(s, 1, 8, 8)   # geometry-independent sizes
             cp = ops.cout_pad_of(shp.cout)
-            wf = torch.zeros(cp * shp.ksize * shp.ksize * shp.cin, device=self.device, dtype=torch.bfloat16)
+            wf = torch.zeros(cp * shp.ksize * shp.ksize * shp.cin, device=self.device, dtype=self.adt)
             wd = None
             if s.name != "backbone.conv1":
-                wd = torch.zeros(lib().mi355det_dgrad_pack_elems(C.byref(shp)), device=self.device, dtype=torch.bfloat16)
+                wd = torch.zeros(self.L.mi355det_dgrad_pack_elems(C.byref(shp)), device=self.device, dtype=self.adt)
             self.packed[s.name] = (wf, wd)
 
     def _wshape(self, s, n, h, w, in_ld=None, out_ld=None):
@@ -341,8 +352,8 @@ class YoloV3Engine:
         heads = self.forward(images, training=True)
         p = self._last_plan
         p.zero_head_grads()
-        gv, _keep = ops.head_views(p.head_grad_views(), self.head_c, dtype=torch.bfloat16)
-        out12, _ = criterion._loss_impl(heads, targets, want_grad=True, grad_views=gv, grad_is_bf16=True, grad_scale=grad_scale)
+        gv, _keep = ops.head_views(p.head_grad_views(), self.head_c, dtype=self.adt)
+        out12, _ = criterion._loss_impl(heads, targets, want_grad=True, grad_views=gv, grad_is_bf16=self.grad_fmt, grad_scale=grad_scale)
         p.run_backward()
         return out12
 
@@ -368,8 +379,8 @@ class Plan:
         self.dz_elems = 0
         self.layers = {}
         dev = eng.device
-        L = lib()
-        bf = torch.bfloat16
+        L = eng.L
+        bf = eng.adt
 
         def new_act(n_, h_, w_, c_, buf=None, ld=None, off=0):
             if buf is None:
@@ -432,7 +443,7 @@ class Plan:
                 return a
             shp.out_ld = shp.cout   # z pitch
             z = torch.zeros((x.n, shp.ho, shp.wo, shp.cout), device=dev, dtype=bf)
-            rows = fused[0] if fused else ops.conv_stats_rows(shp)
+            rows = fused[0] if fused else L.mi355det_conv_stats_rows(C.byref(shp), ops.cout_pad_of(shp.cout))
             stats = torch.zeros((rows + 64, 2, cp), device=dev, dtype=torch.float32)
             self.keep += [shp, z, stats, ss]
             if fused:
@@ -539,7 +550,7 @@ class Plan:
             self._autotune_eval()
 
     def _stem(self, n, H, W, new_act, sync_sum):
-        eng, L, dev = self.eng, lib(), self.eng.device
+        eng, L, dev = self.eng, self.eng.L, self.eng.device
         name, b = "backbone.conv1", "backbone.bn1"
         s = eng.by_name[name]
         wf, _ = eng.packed[name]
@@ -601,8 +612,8 @@ class Plan:
 
     # ------------------------------------------------------------------
     def _build_backward(self):
-        eng, L, dev = self.eng, lib(), self.eng.device
-        bf = torch.bfloat16
+        eng, L, dev = self.eng, self.eng.L, self.eng.device
+        bf = eng.adt
         # two dz buffers (ping-pong) so the weight-gradient GEMM of layer L can run on a SECOND stream while the main
         # stream already does the BN backward / dgrad of the next layers: wgrad is off the dependency chain
         # (reduce -> apply -> dgrad), and the HBM-bound BN passes overlap with its MFMA work.
@@ -780,7 +791,7 @@ class Plan:
     def _autotune(self):
         """Plan-build time only: let the library time its candidate tile configurations / split counts for every
         conv shape of this plan on the plan's own buffers (mi355det_conv_autotune_mode, _wgrad_autotune)."""
-        eng, L = self.eng, lib()
+        eng, L = self.eng, self.eng.L
         saved = {k: v.clone() for k, v in eng.buffers.items()}
         img = torch.randn((self.n, 3, self.H, self.W), device=eng.device)
         self._set_image(img)
@@ -815,7 +826,7 @@ class Plan:
         """Eval plans run the convolutions with the BatchNorm + LeakyReLU (+ residual) epilogue, whose tile choices are keyed separately
         from the training forward's: time the candidates once on this plan's buffers (round 2 ran every eval convolution on the default
         128 x 128 tile: 9.2 ms against 7.0 ms for the same 75 convolutions in the training step)."""
-        L = lib()
+        L = self.eng.L
         img = torch.randn((self.n, 3, self.H, self.W), device=self.eng.device)
         self._set_image(img)
         self._run(self.pack)

@@ -31,7 +31,11 @@ class YoloHead(nn.Module):
         nc = config["yolo"]["classes"]
         # `batch_norm_sync` is the reference's switch for apex SyncBN (yolo/procedures/initialize.py:31-32; yolo/hydra/config.yaml)
         sync = bool(config.get("batch_norm_sync", False)) if hasattr(config, "get") else bool(getattr(config, "batch_norm_sync", False))
-        self.engine = YoloV3Engine(cfgb.get("backbone_name", "darknet_53"), na, nc, sync_bn=sync)
+        # `apex_opt` (yolo/hydra/config.yaml:6, initialize.py:44-45): O1 / O2 / O3 store fp16 -> the engine's fp16 storage; O0 (fp32 in the
+        # reference) -> the engine's default bf16 storage.  `storage` ("bf16" / "fp16") in the config overrides the mapping.
+        opt = (config.get("apex_opt", "O0") if hasattr(config, "get") else getattr(config, "apex_opt", "O0")) or "O0"
+        storage = (config.get("storage", None) if hasattr(config, "get") else getattr(config, "storage", None)) or ("fp16" if str(opt).upper() in ("O1", "O2", "O3") else "bf16")
+        self.engine = YoloV3Engine(cfgb.get("backbone_name", "darknet_53"), na, nc, sync_bn=sync, storage=storage)
         self.layers_out_filters = [64, 128, 256, 512, 1024]
         # parameters are views into the engine's flat master buffer (conv weights in OHWI layout)
         self._pnames, self._plist = [], nn.ParameterList()

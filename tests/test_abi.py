@@ -11,10 +11,35 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "mi355det.h")
 
 
+HEADER_F16 = os.path.join(ROOT, "include", "mi355det_f16.h")
+
+
 def declared_symbols():
-    txt = open(HEADER).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(mi355det_[a-z0-9_]+)\s*\(", txt)))
+    names = set()
+    for h in (HEADER, HEADER_F16):
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(mi355det_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_f16_header_is_the_generated_one():
+    """include/mi355det_f16.h = tools/gen_f16_header.py applied to mi355det.h and csrc/f16_names.h (the twin list the build renames by)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_f16_header", os.path.join(ROOT, "tools", "gen_f16_header.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert open(HEADER_F16).read() == mod.generate()
+    assert len(mod.twin_names()) >= 40
+
+
+def test_no_undeclared_exports(libpath):
+    """Every mi355det_* symbol the library exports is declared in one of the two headers (nothing leaks out of the twin build)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("mi355det_")))
+    extra = [n for n in exported if n not in set(declared_symbols()) and not n.startswith("mi355det_internal_")]
+    assert not extra, extra
 
 
 @pytest.fixture(scope="module")

@@ -64,9 +64,13 @@ def _oracle_run(quant):
 RECORD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tune_trajectory.json")
 
 
-def _engine_run(record=None):
+LOSS_SCALE = 1024.0      # fp16 arm: a constant power-of-two loss scale (apex's dynamic scaler settles on one; a power of two changes no mantissa)
+
+
+def _engine_run(record=None, storage="bf16"):
     """record: raw tune-record bytes imported LOCKED before the engine is built (the plan build then times nothing it covers), or None = the
-    plan build times its candidates on this box.  Returns (losses, final state, the record the run ended with)."""
+    plan build times its candidates on this box.  storage "fp16": the engine's fp16 arm, trained with a loss scale like the reference's apex
+    recipe (train_one_epoch.py:88-94).  Returns (losses, final state, the record the run ended with)."""
     from object_detectors_amd import tune
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.yolo.nets.engine import YoloV3Engine
@@ -75,16 +79,17 @@ def _engine_run(record=None):
     if record is not None:
         tune.import_bytes(record, replace=True, lock=True)
     dev = torch.device("cuda:0")
-    eng = YoloV3Engine(BNAME, 3, 80, device=dev)
+    eng = YoloV3Engine(BNAME, 3, 80, device=dev, storage=storage)
     eng.load_reference_state_dict(_state())
     crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=PX).to(dev)
     opt = FlatSGD.for_engine(eng, lr=LR, momentum=0.9, weight_decay=5e-4)
+    S = LOSS_SCALE if storage == "fp16" else 1.0
     losses = []
     for step in range(STEPS):
         x, tg = _batch(step)
         t = [{"bbox": torch.from_numpy(b).to(dev), "category_id": torch.from_numpy(l).to(dev)} for b, l in tg]
-        out12 = eng.train_step(torch.from_numpy(x).to(dev), t, crit)
-        opt.step()
+        out12 = eng.train_step(torch.from_numpy(x).to(dev), t, crit, grad_scale=S)
+        opt.step(grad_scale=1.0 / S)
         losses.append(float(out12[0]))
     torch.cuda.synchronize()
     used = tune.export_bytes()
@@ -138,6 +143,9 @@ def test_twelve_sgd_steps_track_the_fp32_oracle():
     lossC, sdC = _oracle_arm("fp16")
     rec = _committed_record()
     lossE, sdE, used = _engine_run(rec)
+    lossH, sdH, usedH = _engine_run(rec if rec is not None else used, storage="fp16")      # the engine with fp16 storage (its choices have their own keys)
+    assert all(np.isfinite(lossH)), lossH
+    used = usedH                                                                              # (a superset of the bf16 run's record)
     os.makedirs("gpurun_out", exist_ok=True)
     if rec is None:
         tune.save(os.path.join("gpurun_out", "tune_trajectory.json"), used)      # to be committed as tests/golden/tune_trajectory.json
@@ -152,10 +160,11 @@ def test_twelve_sgd_steps_track_the_fp32_oracle():
     table = {"config": f"{BNAME} {PX}px bs{BS}, {STEPS} SGD steps lr {LR} momentum 0.9 wd 5e-4, residual BN gammas x0.2",
              "tune_record": "tests/golden/tune_trajectory.json (locked)" if rec is not None else "timed on this box",
              "loss_fp32_oracle": [round(v, 4) for v in lossA],
-             "loss_engine": [round(v, 4) for v in lossE], "loss_bf16_oracle": [round(v, 4) for v in lossB], "loss_fp16_oracle": [round(v, 4) for v in lossC],
-             "loss_rel_err": {"engine": [round(v, 4) for v in rel(lossE)], "bf16_oracle": [round(v, 4) for v in rel(lossB)],
+             "loss_engine": [round(v, 4) for v in lossE], "loss_engine_fp16": [round(v, 4) for v in lossH], "loss_bf16_oracle": [round(v, 4) for v in lossB], "loss_fp16_oracle": [round(v, 4) for v in lossC],
+             "loss_rel_err": {"engine": [round(v, 4) for v in rel(lossE)], "engine_fp16": [round(v, 4) for v in rel(lossH)], "bf16_oracle": [round(v, 4) for v in rel(lossB)],
                               "fp16_oracle": [round(v, 4) for v in rel(lossC)]},
              "final_state_vs_fp32_oracle": {"engine": {**_cmp(sdE, sdA), **_update_cmp(sdE, sdA, init)},
+                                            "engine_fp16": {**_cmp(sdH, sdA), **_update_cmp(sdH, sdA, init)},
                                             "bf16_oracle": {**_cmp(sdB, sdA), **_update_cmp(sdB, sdA, init)},
                                             "fp16_oracle": {**_cmp(sdC, sdA), **_update_cmp(sdC, sdA, init)}},
              "engine_vs_bf16_oracle": {**_cmp(sdE, sdB), **_update_cmp(sdE, sdB, init)}}
@@ -178,6 +187,12 @@ def test_twelve_sgd_steps_track_the_fp32_oracle():
     assert E["weights_cos"] > 0.9999 and E["weights_rel"] < B["weights_rel"] * 1.3 + 1e-3, fin
     assert E["running_rel"] < 0.03 and E["running_rel"] < B["running_rel"] + 0.01, fin
     assert E["update_cos"] > 0.5 and E["update_cos"] > B["update_cos"] - 0.1, fin
+    # the fp16-storage engine against the fp16-storage oracle arm, same bars
+    eH, Hh, Cc = rel(lossH), fin["engine_fp16"], fin["fp16_oracle"]
+    assert max(eH) < 0.14 and mean(eH) < 0.05 and mean(eH) < max(mean(eB), mean(eC)) + 0.02, (eH, eC)
+    assert Hh["weights_cos"] > 0.9999 and Hh["weights_rel"] < Cc["weights_rel"] * 1.3 + 1e-3, fin
+    assert Hh["running_rel"] < 0.03 and Hh["running_rel"] < Cc["running_rel"] + 0.01, fin
+    assert Hh["update_cos"] > 0.5 and Hh["update_cos"] > Cc["update_cos"] - 0.1, fin
 
 
 def _alt_record(raw):
