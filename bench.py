@@ -80,11 +80,13 @@ def pmc_traffic(batch, px):
     return (round(b / n) if n else None), "profiles/r03_pmc_summary.md", (round(mu, 1) if mu is not None else None)
 
 
-def cpu_baseline(px, sample_bs=1, warmup=3, iters=10):
+def cpu_baseline(px, sample_bs=2, warmup=1, iters=5):
     """SURVEY 8(d) protocol: the CPU restatement of the SAME step - oracle/net_oracle.py (torch-fp32 Darknet-53 + YoloHead, forward and
     autograd backward) driven by the criterion oracle/yolo_oracle.py:yolo_loss (assignment, six loss terms, head gradients) - on the host
     cores of this box: `warmup` + `iters` iterations on a bounded sample of the workload (`sample_bs` images of the same size and GT
-    density), median.  Baseline only: a large GPU/CPU ratio says nothing about kernel quality."""
+    density), median.  Second leg: the box operations the north star names - pairwise box_iou of the ground truth against the
+    25 200 anchors, the Matcher, batched_nms of 2 000 candidates per image - on the C/OpenMP restatement oracle/c/box_oracle.c (all host
+    threads), reported next to the step.  Baseline only: a large GPU/CPU ratio says nothing about kernel quality."""
     from oracle import net_oracle
     from oracle import yolo_oracle as yo
     torch.manual_seed(0)
@@ -111,9 +113,47 @@ def cpu_baseline(px, sample_bs=1, warmup=3, iters=10):
         times.append(time.perf_counter() - t0)
     timed = sorted(times[warmup:])
     t = timed[len(timed) // 2]
-    return {"value": round(sample_bs / t, 4), "unit": "images/s", "cores": cores, "torch_threads": threads, "kind": "port",
-            "sample": f"{warmup} warm-up + {iters} timed iterations of fwd + criterion + bwd on {sample_bs} image(s) at {px}px, 7 GT/img "
-                      f"(oracle/net_oracle.py torch-CPU fp32 + oracle/yolo_oracle.py numpy criterion), median; {sum(times):.0f} s of CPU work"}
+    out = {"value": round(sample_bs / t, 4), "unit": "images/s", "cores": cores, "torch_threads": threads, "kind": "port",
+           "sample": f"{warmup} warm-up + {iters} timed iterations of fwd + criterion + bwd on {sample_bs} image(s) at {px}px, 7 GT/img "
+                     f"(oracle/net_oracle.py torch-CPU fp32 + oracle/yolo_oracle.py numpy criterion), median; {sum(times):.0f} s of CPU work"}
+    try:
+        out["box_ops"] = cpu_box_leg(px)
+    except Exception as e:      # the C oracle is test infrastructure: a box without gcc / OpenMP reports why instead of failing the bench
+        out["box_ops"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def cpu_box_leg(px, images=8, reps=5):
+    """The box operations of the path on oracle/c/box_oracle.c (C + OpenMP): per image box_iou(7 GT x 25 200 anchors) + Matcher(0.5, 0.4) +
+    batched_nms(2 000 candidates, 80 classes, IoU 0.5).  -> images/s over `images` images, best of `reps`."""
+    import numpy as np
+    from oracle import box_oracle_c as bc
+    from oracle import detrand
+    bc.build()
+    n_anchor = sum(3 * (px // s) ** 2 for s in (32, 16, 8))
+    data = []
+    for i in range(images):
+        c = detrand.uniform(100 + i, (n_anchor, 2), 0, px)
+        wh = detrand.uniform(200 + i, (n_anchor, 2), 8, px / 2)
+        anchors = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+        gc = detrand.uniform(300 + i, (7, 2), 0.2 * px, 0.8 * px)
+        gwh = detrand.uniform(400 + i, (7, 2), 0.02 * px, 0.32 * px)
+        gt = np.concatenate([gc - gwh / 2, gc + gwh / 2], 1).astype(np.float32)
+        cand = anchors[:2000] + detrand.uniform(500 + i, (2000, 4), -2, 2).astype(np.float32)
+        scores = detrand.uniform(600 + i, (2000,), 0, 1).astype(np.float32)
+        idxs = detrand.randint(700 + i, (2000,), 0, 80)
+        data.append((gt, anchors, cand, scores, idxs))
+    best = 1e30
+    kept = 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for gt, anchors, cand, scores, idxs in data:
+            q = bc.box_iou(gt, anchors)
+            bc.matcher(q, 0.5, 0.4, True)
+            kept = len(bc.batched_nms(cand, scores, idxs, 0.5))
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(images / best, 2), "unit": "images/s", "kind": "port (oracle/c/box_oracle.c, C + OpenMP)",
+            "sample": f"box_iou 7 x {n_anchor} + Matcher + batched_nms of 2000 candidates per image, {images} images, best of {reps}; last keep count {kept}"}
 
 
 def launch_ranks(n):
@@ -156,6 +196,10 @@ def main():
     ap.add_argument("--px", type=int, default=640)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--storage", choices=["bf16", "fp16"], default="bf16",
+                    help="format of stored activations / gradients / packed weights (fp16: the reference's apex-O2 format, with a loss scale of 1024)")
+    ap.add_argument("--atomic-bn-sums", action="store_true",
+                    help="A/B: BatchNorm-backward sums ending in fp32 atomics (round 3's form: not reproducible run to run) instead of the fixed-order form")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (pure timing run)")
     ap.add_argument("--event-steps", type=int, default=1,
                     help="timed steps (spread evenly) in which every forward-conv launch is bracketed by HIP events; each event pair "
@@ -205,7 +249,8 @@ def main():
     from object_detectors_amd.yolo.nets.engine import YoloV3Engine
     from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
 
-    eng = YoloV3Engine("darknet_53", 3, 80, device=dev, seed=0)
+    eng = YoloV3Engine("darknet_53", 3, 80, device=dev, seed=0, storage=args.storage, deterministic=not args.atomic_bn_sums)
+    loss_scale = 1024.0 if eng.storage == "fp16" else 1.0      # apex-style static scale for the timing run (train_one_epoch.py:88-94)
     crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=args.px).to(dev)
     imgs, targets = synth_batch(args.batch, args.px, rank, dev)
     sync = GradSync(eng.flat_g).attach(eng) if world > 1 else None      # every plan the engine builds gets the bucket hooks
@@ -214,10 +259,10 @@ def main():
     opt = FlatSGD.for_engine(eng, lr=args.lr, momentum=0.9, weight_decay=5e-4)
 
     def step():
-        out12 = eng.train_step(imgs, targets, crit)
+        out12 = eng.train_step(imgs, targets, crit, grad_scale=loss_scale)
         if sync is not None:
             sync.wait()
-        opt.step()
+        opt.step(grad_scale=1.0 / loss_scale)
         return out12
 
     for _ in range(max(1, args.warmup)):
@@ -304,7 +349,7 @@ def main():
         line = {
             "metric": f"images/sec (fwd+bwd) YOLOv3 {args.px}px bs={args.batch}", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": eng.storage, "data": "synthetic",
             "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+loss+bwd{'+grad all-reduce' if world > 1 else ''}+SGD step), "
                                    f"synthetic COCO {args.px}px, per-GPU bs={args.batch}, 7 GT/img, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},

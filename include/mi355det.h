@@ -247,6 +247,10 @@ int mi355det_anchor_grid(const float* cell, int32_t a, int32_t gh, int32_t gw, i
 int mi355det_sigmoid_focal_loss(const float* x, const float* t, const float* scale, const uint8_t* valid,
                                 int64_t rows, int32_t k, float alpha, float gamma, float grad_scale,
                                 float* loss_sum, float* grad, void* stream);
+/* reduction = 'none' - torchvision's DEFAULT (the reference only calls 'sum': tvision/retinanet.py:137-141, roi_heads.py:57-58): the
+ * unreduced loss per element and, if grad != NULL, d loss / d x per element; x, t, loss, grad are n contiguous floats. */
+int mi355det_sigmoid_focal_loss_elem(const float* x, const float* t, int64_t n, float alpha, float gamma, float* loss,
+                                     float* grad, void* stream);
 
 /* RetinaNet classification loss without the dense one-hot target (retinanet.py:107-143):
  *   logits [rows,k], matched [rows] int64 (Matcher output), gt_labels [M] int64. Same outputs. */

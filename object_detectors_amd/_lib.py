@@ -86,6 +86,7 @@ PROTOTYPES = {
     "mi355det_box_decode": (C.c_int, [vp, vp, vp, i64, i32, f32, f32, f32, f32, f32, vp]),
     "mi355det_anchor_grid": (C.c_int, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "mi355det_sigmoid_focal_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
+    "mi355det_sigmoid_focal_loss_elem": (C.c_int, [vp, vp, i64, f32, f32, vp, vp, vp]),
     "mi355det_retina_cls_loss": (C.c_int, [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp, vp, vp]),
     "mi355det_roi_align_nhwc": (C.c_int, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, C.c_int, i32, i32, vp, vp, vp, vp]),
     "mi355det_roi_align": (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, C.c_int, i32, i32, vp, vp, vp, vp]),
@@ -199,7 +200,7 @@ def lib():
                 missing.append(name)
                 continue
             fn.restype, fn.argtypes = res, args
-        if missing and os.environ.get("MI355DET_PARTIAL") != "1":
+        if missing:
             raise Mi355detError(f"{LIB_PATH} lacks symbols {missing}: rebuild with `python -m object_detectors_amd.build --force`")
         _lib = L
     return _lib

@@ -57,8 +57,6 @@ def build(force=False, verbose=False):
     for src, extra in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
-            if os.environ.get("MI355DET_PARTIAL") == "1":   # bring-up only
-                continue
             raise FileNotFoundError(sp)
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(op)

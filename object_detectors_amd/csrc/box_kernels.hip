@@ -1200,6 +1200,17 @@ int mi355det_anchor_grid(const float* cell, int32_t a, int32_t gh, int32_t gw, i
 // Launch geometry of the focal kernels.  Small problems (K = 91: 11 M elements, 87 MB) finish in a few iterations per thread, and the ONE
 // atomic each workgroup adds to the loss word then matters (atomics to one address retire at ~90 per microsecond): 512 workgroups of 1024
 // threads.  Large ones (K = 1204: 145 M elements) are bandwidth / VALU bound and balance better over many small workgroups.
+// reduction = 'none' (torchvision's default): the unreduced loss (and d loss / d x) per element, the same evaluation `sfl` as the summed form
+__global__ __launch_bounds__(256) void focal_elem_kernel(const float* __restrict__ x, const float* __restrict__ t, long long n, float alpha, float gamma,
+                                                         float* __restrict__ loss, float* __restrict__ grad) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float l, g;
+    sfl(x[i], t[i], alpha, gamma, l, g);
+    loss[i] = l;
+    if (grad) grad[i] = g;
+  }
+}
+
 #define FOCAL_LAUNCH(MODE, total_elems, ...)                                                                                                   \
   do {                                                                                                                                         \
     const long long q4_ = (total_elems) / 4 + 1;                                                                                               \
@@ -1211,6 +1222,14 @@ int mi355det_anchor_grid(const float* cell, int32_t a, int32_t gh, int32_t gw, i
       hipLaunchKernelGGL((focal_kernel<MODE, FOCAL_THREADS>), dim3(blocks_), dim3(FOCAL_THREADS), 0, __VA_ARGS__);                             \
     }                                                                                                                                          \
   } while (0)
+
+int mi355det_sigmoid_focal_loss_elem(const float* x, const float* t, int64_t n, float alpha, float gamma, float* loss, float* grad, void* stream) {
+  if (n < 0 || !x || !t || !loss) return fail(MI355DET_EINVAL, "%s: bad arguments", "sigmoid_focal_loss_elem");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(focal_elem_kernel, dim3((int)min((long long)4096, (long long)((n + 255) / 256))), dim3(256), 0, S(stream), x, t, (long long)n, alpha, gamma,
+                     loss, grad);
+  return check_launch("sigmoid_focal_loss_elem");
+}
 
 int mi355det_sigmoid_focal_loss(const float* x, const float* t, const float* scale, const uint8_t* valid, int64_t rows, int32_t k, float alpha,
                                 float gamma, float grad_scale, float* loss_sum, float* grad, void* stream) {

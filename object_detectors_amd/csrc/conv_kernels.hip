@@ -1054,9 +1054,8 @@ int autotune_igemm(const IgemmParams& p, hipStream_t st) {
   for (int cfg : cands) {
     // data gradients run next to the weight-gradient stream: only tiles of <= 64 KB LDS (two workgroups per CU), which can share a CU
     // with a 64 KB weight-gradient workgroup; the one-per-CU tiles are a little faster alone and slower in the step (same-box A/B:
-    // 1046-1047 vs 1039-1041 images/s).  MI355DET_DGRAD_BIG_LDS=1 restores the full candidate list.
-    static const bool small_lds = getenv("MI355DET_DGRAD_BIG_LDS") == nullptr;
-    if (small_lds && (EPI == EPI_PLAIN || EPI == EPI_RES) && (cfg == 3 || cfg == 6 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 26 || cfg == 27 || cfg == 28)) continue;
+    // 1046-1047 vs 1039-1041 images/s; round 3's knob for the full list showed no difference on YOLO and is gone).
+    if ((EPI == EPI_PLAIN || EPI == EPI_RES) && (cfg == 3 || cfg == 6 || cfg == 16 || cfg == 17 || cfg == 18 || cfg == 19 || cfg == 26 || cfg == 27 || cfg == 28)) continue;
     if ((cfg == 3 || cfg == 6) && p.CoutPad % 256 != 0) continue;
     if (cfg == 40 && !(igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF || EPI == EPI_F32))) continue;
     if ((cfg == 44 || cfg == 45) && !(igemm8_applicable(p) && (EPI == EPI_STATS || EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_AFF))) continue;

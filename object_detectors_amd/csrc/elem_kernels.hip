@@ -728,8 +728,7 @@ extern "C" {
 int mi355det_bn_finalize(const float* stats, int32_t rows, int32_t c, int32_t c_pad, int64_t count, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean, float* running_var, float* scale_shift, void* stream) {
   if (c <= 0 || rows <= 0 || count <= 0) return fail(MI355DET_EINVAL, "%s: bad arguments", "bn_finalize");
-  static const bool wide_off = getenv("MI355DET_BN_FINALIZE_TWO_STAGE") != nullptr;     // A/B knob
-  if (rows > 32 && rows <= 8192 && !wide_off) {
+  if (rows > 32 && rows <= 8192) {
     hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3((c + 7) / 8), dim3(1024), 0, S(stream), stats, rows, c, c_pad, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale_shift);
     return check_launch("bn_finalize");

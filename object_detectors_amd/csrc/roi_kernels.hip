@@ -908,8 +908,7 @@ int mi355det_roi_align_nhwc(const void* const* feats, const int32_t* hs, const i
   }
   bool separable = pooled_h == RSEP_BINS && pooled_w == RSEP_BINS;
   for (int q = 0; q < num_levels; ++q) separable = separable && hs[q] <= RSEP_CAP && ws[q] <= RSEP_CAP;
-  static const bool sep_off = getenv("MI355DET_ROI_ALIGN_PER_SAMPLE") != nullptr;     // A/B: the per-sample kernel for every shape
-  if (separable && !sep_off) {          // the 7x7 box head: one workgroup per RoI, footprint weights in LDS
+  if (separable) {          // the 7x7 box head: one workgroup per RoI, footprint weights in LDS
     if (grad_out)
       hipLaunchKernelGGL(roi_align_sep_kernel<true>, dim3(num_rois), dim3(256), 0, S(stream), L, num_levels, rois, channels, sampling_ratio, aligned,
                          k_min, k_max, out, grad_out);

@@ -644,9 +644,7 @@ int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, co
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: event create failed", "wgrad_autotune");
   int best = -1;
   float best_ms = 1e30f;
-  static const int max_split = getenv("MI355DET_WGRAD_MAXSPLIT") ? atoi(getenv("MI355DET_WGRAD_MAXSPLIT")) : 1024;      // A/B knob: cap the split-K factor
   for (int sp : cands) {
-    if (sp > max_split) continue;
     if (sp > 1 && (sp * per_split > workspace_bytes || M / sp < 512 || (size_t)sp * tiles > 4096)) continue;
     if (!split_valid(M, sp)) continue;
     g_wgrad_force = sp;

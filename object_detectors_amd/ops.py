@@ -426,6 +426,18 @@ def sigmoid_focal_loss_sum(x, t, alpha, gamma, scale=None, valid=None, want_grad
     return loss[0], grad
 
 
+def sigmoid_focal_loss_elem(x, t, alpha, gamma, want_grad=True):
+    """Unreduced focal loss (reduction='none') and its derivative, elementwise on any shape."""
+    x, t = _f32c(x), _f32c(t)
+    if x.shape != t.shape:
+        raise ValueError("inputs and targets must have the same shape")
+    loss = torch.empty_like(x)
+    grad = torch.empty_like(x) if want_grad else None
+    check(lib().mi355det_sigmoid_focal_loss_elem(ptr(x), ptr(t), x.numel(), float(alpha), float(gamma), ptr(loss), ptr(grad), stream_ptr()),
+          "sigmoid_focal_loss_elem")
+    return loss, grad
+
+
 def retina_cls_loss_sum(logits, matched, gt_labels, alpha, gamma, scale=None, want_grad=True, grad_scale=1.0):
     logits = _f32c(logits)
     rows, k = logits.shape

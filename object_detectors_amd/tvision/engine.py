@@ -310,17 +310,12 @@ class RetinaNetEngine:
         self.match(p, targets)
         self.forward(images, training=True)
         assert self._last_plan is p
-        # the class gradient goes straight into the bf16 per-level buffers the cls_logits backward reads (no fp32 gradient tensor, no cast);
-        # MI355DET_HEAD_GRAD_FP32=1 keeps the round-2 route (fp32 glogits + cast_rows) for A/B
-        if os.environ.get("MI355DET_HEAD_GRAD_FP32", "0") == "1":
-            losses, nfg, _, _ = ops.retina_loss(p.logits, p.bbox_reg, p.anchors, p.matched, gt_boxes, gt_labels, offs, class_scale=class_scale,
-                                                grad_scale=grad_scale, grad_logits=p.glogits, grad_regression=p.gbbox)
-            p.load_head_grads()
-        else:
-            levels = [p.head_grads[("cls_logits", lvl)] for lvl in range(len(p.level_sizes))]
-            losses, nfg, _, _ = ops.retina_loss(p.logits, p.bbox_reg, p.anchors, p.matched, gt_boxes, gt_labels, offs, class_scale=class_scale,
-                                                grad_scale=grad_scale, grad_regression=p.gbbox, cls_levels=levels, anchors_per_pixel=self.na)
-            p.load_head_grads(cls=False)
+        # the class gradient goes straight into the bf16 per-level buffers the cls_logits backward reads (no fp32 gradient tensor, no cast:
+        # the round-2 route through fp32 glogits + cast_rows was 2.0 ms slower per R101-LVIS step, profiles/r03_ab_results.md)
+        levels = [p.head_grads[("cls_logits", lvl)] for lvl in range(len(p.level_sizes))]
+        losses, nfg, _, _ = ops.retina_loss(p.logits, p.bbox_reg, p.anchors, p.matched, gt_boxes, gt_labels, offs, class_scale=class_scale,
+                                            grad_scale=grad_scale, grad_regression=p.gbbox, cls_levels=levels, anchors_per_pixel=self.na)
+        p.load_head_grads(cls=False)
         self.last_num_foreground = nfg
         p.run_backward()
         return losses
@@ -457,7 +452,7 @@ class RetinaPlan:
         h2, w2 = down(H, 1), down(W, 1)
         s1 = eng.by_name["backbone.body.conv1"]
         self.img_call = len(self.fwd)
-        if not s1.trainable and H % 32 == 0 and W % 32 == 0 and os.environ.get("MI355DET_RSTEM", "1") != "0":
+        if not s1.trainable and H % 32 == 0 and W % 32 == 0:
             # frozen stem (the reference default, backbone_utils.py:89-104): one direct 7x7/2 convolution kernel, no im2col matrix
             wf1, _ = eng.packed["backbone.body.conv1"]
             aff1 = eng.affine[s1.bn]
@@ -605,7 +600,7 @@ class RetinaPlan:
 
         # ---- FrozenBN / ReLU backward folded into the data gradient that produces its input (mi355det_conv_dgrad_mask): possible when the
         #      activation has exactly ONE consumer, a stride-1 convolution, and its producer is a plain conv (+affine) (+ReLU) without a
-        #      residual - conv1 -> conv2 -> conv3 inside a bottleneck, the head towers, FPN laterals.  MI355DET_DGRAD_MASK=0 keeps the pass.
+        #      residual - conv1 -> conv2 -> conv3 inside a bottleneck, the head towers, FPN laterals (-0.2 ... -0.5 ms per step, profiles/r03_ab_results.md).
         uses = {}
         for r in self.ops:
             for key in ("x", "res", "lat", "top"):
@@ -615,7 +610,7 @@ class RetinaPlan:
         for f in self.features:                        # the heads (and, Faster R-CNN, RoIAlign) read the pyramid levels as well
             uses[id(f)] = uses.get(id(f), 0) + (1 if getattr(self, "roi_grads", None) else 0)
         producer = {id(r["a"]): r for r in self.ops if r["kind"] == "conv" and r.get("a") is not None}
-        fuse_ok = os.environ.get("MI355DET_DGRAD_MASK", "1") != "0"
+        fuse_ok = True
 
         def mask_fusable(x, shp):
             pr = producer.get(id(x))

@@ -19,12 +19,27 @@ class _FocalSum(torch.autograd.Function):
         return (None if ctx.grad is None else ctx.grad * g), None, None, None
 
 
+class _FocalElem(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, targets, alpha, gamma):
+        loss, grad = ops.sigmoid_focal_loss_elem(inputs, targets, alpha, gamma, want_grad=inputs.requires_grad)
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None if ctx.grad is None else ctx.grad * g), None, None, None
+
+
 def sigmoid_focal_loss(inputs, targets, alpha=0.25, gamma=2, reduction="none"):
+    """torchvision.ops.sigmoid_focal_loss: 'none' (torchvision's default: elementwise loss), 'mean', 'sum' (what the reference calls)."""
     if reduction == "sum":
         return _FocalSum.apply(inputs, targets, alpha, gamma)
     if reduction == "mean":
         return _FocalSum.apply(inputs, targets, alpha, gamma) / inputs.numel()
-    raise NotImplementedError("only 'sum'/'mean' reductions are on the fused path (the reference uses 'sum')")
+    if reduction == "none":
+        return _FocalElem.apply(inputs, targets, alpha, gamma)
+    raise ValueError(f"Invalid Value for arg 'reduction': '{reduction}' \n Supported reduction modes: 'none', 'mean', 'sum'")
 
 
 class _RetinaCls(torch.autograd.Function):

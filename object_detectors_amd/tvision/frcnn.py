@@ -18,7 +18,6 @@ Where the work runs:
 Inputs as in tvision/retinanet.py: a list of [3,H,W] images goes through the GPU GeneralizedRCNNTransform (generalized_rcnn.py:78-79,110), a ready
 [N,3,H,W] batch skips it.
 """
-import os
 
 import torch
 from torch import nn
@@ -35,11 +34,12 @@ from .rpn import RPNTargets
 from .transform import GeneralizedRCNNTransform
 
 
-_RPN_FUSED = os.environ.get("MI355DET_RPN_FUSED", "1") != "0"      # 0: box_decode of every anchor + the torch-composed filter (A/B, tests)
-_ROI_FUSED = os.environ.get("MI355DET_ROI_FUSED", "1") != "0"      # 0: the per-image torch-composed select_training_samples
-_ROI_DET_FUSED = os.environ.get("MI355DET_ROI_DET_FUSED", "1") != "0"      # 0: inference through proposal lists and the per-image post-processing
-_RPN_LOSS_FUSED = os.environ.get("MI355DET_RPN_LOSS_FUSED", "1") != "0"      # 0: the autograd-composed RPN losses
-_RPN_LOSS_SIDE = os.environ.get("MI355DET_RPN_LOSS_SIDE", "0") != "0"      # 1: RPN losses on the target stream beside the proposal kernels (A/B: no gain)
+# Route switches, module attributes on purpose: the composed routes stay as the bit-exact references of tests/test_gpu_proposals.py and
+# tools/bench_frcnn.py (monkeypatch / assignment), not as production knobs (round 3 read them from the environment).
+_RPN_FUSED = True           # False: box_decode of every anchor + the torch-composed proposal filter
+_ROI_FUSED = True           # False: the per-image torch-composed select_training_samples
+_ROI_DET_FUSED = True       # False: inference through proposal lists and the per-image post-processing
+_RPN_LOSS_FUSED = True      # False: the autograd-composed RPN losses
 
 
 class TwoMLPHead(nn.Module):
@@ -215,13 +215,7 @@ class FasterRCNN(nn.Module):
             fwd_done.record(cur)
             with torch.cuda.stream(self._tgt_stream):
                 rpn_side = self.rpn_targets.prepare([plan.anchors] * n, targets)
-                if _RPN_LOSS_SIDE:
-                    # the RPN losses too (leaf copies of the engine's outputs: their .grad is the engine's head gradient): ~10 small
-                    # launches that need the forward's outputs but not the RoI branch - beside the proposal kernels instead of behind them
-                    self._tgt_stream.wait_event(fwd_done)
-                    obj = out["cls_logits"].detach().reshape(-1, 1).requires_grad_(True)
-                    dl = out["bbox_regression"].detach().reshape(-1, 4).requires_grad_(True)
-                    rpn_losses = self.rpn_targets.losses_prepared(obj, dl, rpn_side)
+                # (measured and removed: the RPN losses on this stream too, beside the proposal kernels - no gain, profiles/r03_ab_results.md)
         if not self.training and _RPN_FUSED and _ROI_DET_FUSED:
             det = self._detect_padded(out, plan, image_shapes)
             if det is not None:

@@ -4,7 +4,6 @@
   RoIHeads.postprocess_detections                           tvision/roi_heads.py:715-781
 Only index bookkeeping (gather by the selected indices, concatenation, ragged python lists) stays in torch."""
 import math
-import os
 
 import torch
 
@@ -14,7 +13,7 @@ from ._utils import BoxCoder
 
 
 _CLIP_LIMITS = {}
-_RETINA_FUSED = os.environ.get("MI355DET_RETINA_POST_FUSED", "1") != "0"      # 0: the torch-composed chain (A/B, tests)
+_RETINA_FUSED = True      # False (tests monkeypatch it): the torch-composed chain, the bit-exact reference of mi355det_retina_detections
 
 
 def _clip_limits(image_shapes, device, dtype):

@@ -96,8 +96,13 @@ def bn_name(conv_name):
 
 
 class YoloV3Engine:
-    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0, sync_bn=False, process_group=None, storage="bf16"):
-        """storage: format of every stored activation, activation gradient and packed weight - "bf16" (default) or "fp16", the format of the
+    def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0, sync_bn=False, process_group=None, storage="bf16",
+                 deterministic=True):
+        """deterministic (default): every kernel of the step sums in a fixed order - two runs of the same inputs under the same tune record give
+        bit-identical weights (tests/test_gpu_trajectory.py), like the reference's torch / cuDNN BatchNorm backward.  False: the BatchNorm-backward
+        sums end in fp32 atomics instead of a second small launch per layer (72 launches on the dependency chain: ~0.25 ms of a 28 ms step,
+        profiles/r04_ab_results.md); gradients then differ by ~6e-4 of max from run to run.
+        storage: format of every stored activation, activation gradient and packed weight - "bf16" (default) or "fp16", the format of the
         reference's mixed-precision recipe (apex O2: yolo/batch_files/sample.txt:28-44, initialize.py:44-45); accumulation, BatchNorm statistics,
         master weights and gradients stay fp32 either way.  fp16 has three more mantissa bits and five fewer exponent bits: train it with a loss
         scale (optim.DynamicLossScaler, train_step(..., grad_scale=S)) exactly as the reference does.  MI355DET_STORAGE overrides the default.
@@ -109,6 +114,7 @@ class YoloV3Engine:
         if storage not in ("bf16", "fp16"):
             raise ValueError("storage must be 'bf16' or 'fp16'")
         self.storage = storage
+        self.deterministic = bool(deterministic)
         self.L = _lib.storage_lib(storage)                 # entry points of this storage format (fp16: the *_f16 twins)
         self.adt = torch.float16 if storage == "fp16" else torch.bfloat16
         self.grad_fmt = 2 if storage == "fp16" else 1       # mi355det_yolo_loss_cfg.grad_is_bf16
@@ -586,7 +592,7 @@ class Plan:
                 self.fwd.append((L.mi355det_bn_finalize, (_vp(part), rows, 32, 32, pixels) + fin))
         fused = None
         l1_rows = L.mi355det_stem_l1_rows(n, H, W)
-        if self.training and l1_rows > 0 and os.environ.get("MI355DET_STEM_L1", "1") != "0":
+        if self.training and l1_rows > 0:
             # training: the activation is produced INSIDE the kernel that convolves it (layer1.ds_conv, 32 -> 64 stride 2) and written to HBM
             # only as a side output for that layer's weight gradient (csrc/stem_l1_kernels.hip)
             wf1, _ = eng.packed["backbone.layer1.ds_conv"]
@@ -595,7 +601,7 @@ class Plan:
                 self.fwd.append(img_call(L.mi355det_stem_l1_fwd, (_vp(wf), _vp(ss), SLOPE, _vp(wf1), a.ptr, a.ld, _vp(z1), 64, _vp(stats1), n, H, W,
                                                                   self.stream)))
             fused = (l1_rows, emit)
-        elif not self.training and l1_rows > 0 and os.environ.get("MI355DET_STEM_L1", "1") != "0":
+        elif not self.training and l1_rows > 0:
             # inference: the same launch with layer 1's folded BN + LeakyReLU in its epilogue; the stem activation is never stored
             wf1, _ = eng.packed["backbone.layer1.ds_conv"]
 
@@ -624,8 +630,8 @@ class Plan:
         # Opt-in until the prefetch is moved into the last k-steps.
         self.fuse_bn_reduce = os.environ.get("MI355DET_BN_FUSION", "0") == "1"
         main = torch.cuda.current_stream(dev)
-        # MI355DET_ONE_STREAM=1: every weight gradient on the step's own stream (A/B of the two-stream backward: profiles/r03_*)
-        self.side = main if os.environ.get("MI355DET_ONE_STREAM", "0") == "1" else torch.cuda.Stream(device=dev)
+        # (one stream for everything was the A/B of round 3: +1.0 ms per step, profiles/r03_ab_results.md)
+        self.side = torch.cuda.Stream(device=dev)
         side_ptr = C.c_void_p(self.side.cuda_stream)
         wg_done = [None, None]        # event: last wgrad that read dz2[i]
         flip = [0]
@@ -692,31 +698,19 @@ class Plan:
                 wf, _ = eng.packed[name]
                 sums = self.sums_all[sum_off[0]:sum_off[0] + 64]
                 sum_off[0] += 64
-                if os.environ.get("MI355DET_STEM_BWD_TWO_PASS", "0") == "1":
-                    # round-3 first form: two passes over the activation gradient (BN sums, then dz into the weight-gradient MFMA)
-                    part = torch.zeros((rows + 64, 2, 32), device=dev, dtype=torch.float32)
-                    slab = torch.zeros((rows, 1024), device=dev, dtype=torch.float32)
-                    self.keep += [part, slab]
-                    self.bwd.append(img_call(L.mi355det_stem_bwd_reduce, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(part), self.n, self.H, self.W,
-                                                                          self.stream)))
-                    self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), rows, 32, 32, _vp(sums), self.stream)))
-                    if self.sync_world > 1:
-                        py(self._sync_avg, sums)
-                    self.bwd.append(img_call(L.mi355det_stem_bwd_apply_wgrad, (_vp(wf), _vp(ss), _vp(sums), SLOPE, g.ptr, g.ld, _vp(slab),
-                                                                               _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
-                                                                               _vp(eng.grads[b + ".bias"]), self.n, self.H, self.W, self.stream)))
-                else:
-                    # ONE pass: A = dy^T [im2col | 1] and the Gram matrix of [im2col | 1] on MFMA; the BN sums and dW are linear in them
-                    slab = torch.zeros((rows, 2048), device=dev, dtype=torch.float32)
-                    ag = torch.zeros(2048, device=dev, dtype=torch.float32)
-                    self.keep += [slab, ag]
-                    self.bwd.append(img_call(L.mi355det_stem_bwd_fused, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(slab), _vp(ag), _vp(sums),
-                                                                         self.n, self.H, self.W, self.stream)))
-                    if self.sync_world > 1:
-                        py(self._sync_avg, sums)
-                    self.bwd.append((L.mi355det_stem_bwd_finish, (_vp(wf), _vp(ss), _vp(ag), _vp(sums), self.n * self.H * self.W,
-                                                                  _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
-                                                                  _vp(eng.grads[b + ".bias"]), self.stream)))
+                # (the round-3 two-pass form - BN sums, then dz into the weight-gradient MFMA - lost its A/B by 0.2-0.4 ms per step and is gone from the
+                #  engine; its entry points mi355det_stem_bwd_reduce / _apply_wgrad stay as the references of tests/test_gpu_stem.py)
+                # ONE pass: A = dy^T [im2col | 1] and the Gram matrix of [im2col | 1] on MFMA; the BN sums and dW are linear in them
+                slab = torch.zeros((rows, 2048), device=dev, dtype=torch.float32)
+                ag = torch.zeros(2048, device=dev, dtype=torch.float32)
+                self.keep += [slab, ag]
+                self.bwd.append(img_call(L.mi355det_stem_bwd_fused, (_vp(wf), _vp(ss), SLOPE, g.ptr, g.ld, _vp(slab), _vp(ag), _vp(sums),
+                                                                     self.n, self.H, self.W, self.stream)))
+                if self.sync_world > 1:
+                    py(self._sync_avg, sums)
+                self.bwd.append((L.mi355det_stem_bwd_finish, (_vp(wf), _vp(ss), _vp(ag), _vp(sums), self.n * self.H * self.W,
+                                                              _vp(eng.grads[name + ".weight"]), _vp(eng.grads[b + ".weight"]),
+                                                              _vp(eng.grads[b + ".bias"]), self.stream)))
                 ev_stem = torch.cuda.Event()
                 py(ev_stem.record, main)                  # the stem's gradients come from the main stream: the side stream (last
                 py(self.side.wait_event, ev_stem)         # gradient bucket) must see them
@@ -754,9 +748,12 @@ class Plan:
                 if "bn_partials" in rec:      # the dgrad that produced g already accumulated the per-channel partial sums
                     part, prows, cpad = rec["bn_partials"]
                     self.bwd.append((L.mi355det_bn_bwd_sum_partials, (_vp(part), prows, shp.cout, cpad, _vp(sums), self.stream)))
-                else:
+                elif eng.deterministic:
                     self.bwd.append((L.mi355det_bn_act_bwd_reduce_det, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
                                                                         _vp(sums), red_ptr, red_bytes, self.stream)))
+                else:
+                    self.bwd.append((L.mi355det_bn_act_bwd_reduce, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), shp.cout, pixels, SLOPE,
+                                                                    _vp(sums), self.stream)))
                 if self.sync_world > 1:
                     py(self._sync_avg, sums)              # SyncBN backward: (sum dy, sum dy*xhat) of the global batch
                 if wg_done[di] is not None:
@@ -764,23 +761,16 @@ class Plan:
                 self.bwd.append((L.mi355det_bn_act_bwd_apply, (g.ptr, g.ld, None, 0, _vp(z), shp.cout, _vp(ss), _vp(sums), None, shp.cout,
                                                                pixels, SLOPE, _vp(dzb), shp.cout, _vp(eng.grads[b + ".weight"]),
                                                                _vp(eng.grads[b + ".bias"]), self.stream)))
-                serial_hw = int(os.environ.get("MI355DET_WGRAD_SERIAL_HW", "0"))      # A/B: weight gradients of maps >= this size on the main stream
-                if serial_hw and shp.ho >= serial_hw:
-                    _, wd = eng.packed[name]
-                    emit_dgrad(shp, _vp(dzb), wd, x)
-                    self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
-                                                             ws_ptr, ws_bytes, self.stream)))
-                    wg_done[di] = None
-                else:
-                    ev_dz, ev_wg = torch.cuda.Event(), torch.cuda.Event()
-                    py(ev_dz.record, main)
-                    py(self.side.wait_event, ev_dz)
-                    self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
-                                                             ws_ptr, ws_bytes, side_ptr)))
-                    py(ev_wg.record, self.side)
-                    wg_done[di] = ev_wg
-                    _, wd = eng.packed[name]
-                    emit_dgrad(shp, _vp(dzb), wd, x)
+                # (measured and removed: the weight gradients of the large maps serial on the main stream - no gain, profiles/r03_ab_results.md)
+                ev_dz, ev_wg = torch.cuda.Event(), torch.cuda.Event()
+                py(ev_dz.record, main)
+                py(self.side.wait_event, ev_dz)
+                self.bwd.append((L.mi355det_conv_wgrad, (C.byref(shp), x.ptr, _vp(dzb), _vp(eng.grads[name + ".weight"]), None,
+                                                         ws_ptr, ws_bytes, side_ptr)))
+                py(ev_wg.record, self.side)
+                wg_done[di] = ev_wg
+                _, wd = eng.packed[name]
+                emit_dgrad(shp, _vp(dzb), wd, x)
             if rec["kind"] in ("out", "cbl", "stem"):
                 self.bwd_marks.append((len(self.bwd), first_off[rec["name"] + ".weight"]))
         ev_end = torch.cuda.Event()

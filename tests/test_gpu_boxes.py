@@ -143,6 +143,19 @@ def test_sigmoid_focal_loss_gpu():
     l, g = tv.sigmoid_focal_loss(x, t)
     np.testing.assert_allclose(loss.item(), l.astype(np.float64).sum(), rtol=1e-4)
     np.testing.assert_allclose(xt.grad.cpu().numpy(), g, rtol=1e-3, atol=1e-6)
+    # reduction='none' (torchvision's default argument) and 'mean': elementwise loss with autograd, any shape; a bad mode raises like torchvision
+    xn = T(x.reshape(40, 100, 91)).requires_grad_(True)
+    wts = T(detrand.uniform(13, (40, 100, 91), 0.5, 1.5))
+    ln = sigmoid_focal_loss(xn, T(t.reshape(40, 100, 91)))
+    assert ln.shape == xn.shape
+    np.testing.assert_allclose(ln.detach().cpu().numpy().reshape(4000, 91), l, rtol=1e-4, atol=1e-7)
+    (ln * wts).sum().backward()
+    np.testing.assert_allclose(xn.grad.cpu().numpy().reshape(4000, 91), g * wts.cpu().numpy().reshape(4000, 91), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(sigmoid_focal_loss(T(x), T(t), reduction="mean").item(), l.astype(np.float64).mean(), rtol=1e-4)
+    with pytest.raises(ValueError):
+        sigmoid_focal_loss(T(x), T(t), reduction="avg")
+    e = sigmoid_focal_loss(torch.zeros(0, 5, device=dev()), torch.zeros(0, 5, device=dev()))
+    assert e.shape == (0, 5)
 
 
 def test_retinanet_cls_loss_gpu(golden):

@@ -315,8 +315,8 @@ def _worker_multiplan(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["MI355DET_BN_FUSION"] = "1"      # fixed-order BatchNorm-backward sums: the two runs compared below are then reproducible (the default
-                                                # path ends in fp32 atomics, whose last-bit noise this random-weight net amplifies to ~1e-2 at 192 px)
+    # (every kernel of the step is fixed-order since round 4 - the BatchNorm-backward sums were the last atomics - so the two runs compared
+    #  below are reproducible on the default path; round 3 had to select the plain-store sums with MI355DET_BN_FUSION=1 here)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         dev = torch.device("cuda:0")

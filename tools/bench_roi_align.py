@@ -1,5 +1,5 @@
 """RoIAlign of the Faster R-CNN box head in isolation: 2048 RoIs (512 per image) on the four bf16 NHWC pyramid levels of a batch of 4 at
-800 px, 256 channels, 7x7, sampling_ratio 2; forward and backward, separable form vs per-sample form (MI355DET_ROI_ALIGN_PER_SAMPLE=1).
+800 px, 256 channels, 7x7, sampling_ratio 2; forward and backward, separable form (the per-sample form of round 3's A/B, 432 / 1326 us against 177 / 526, is no longer selectable).
     python tools/bench_roi_align.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,4 +27,4 @@ def timeit(fn, reps=20):
 f = timeit(lambda: ops.roi_align_nhwc(feats, rois, 7, scales, 2, False, 2, 5))
 b = timeit(lambda: ops.roi_align_nhwc(feats, rois, 7, scales, 2, False, 2, 5, grad_out=go))
 z = timeit(lambda: [torch.zeros((x.shape[0], x.shape[1], x.shape[2], c), device=dev) for x in feats])
-print(f"per-sample={os.environ.get('MI355DET_ROI_ALIGN_PER_SAMPLE', '0')}: forward {f:.1f} us, backward {b:.1f} us (of which zero-fill of the gradient maps {z:.1f} us)")
+print(f"separable form: forward {f:.1f} us, backward {b:.1f} us (of which zero-fill of the gradient maps {z:.1f} us)")
