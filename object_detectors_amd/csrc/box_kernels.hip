@@ -1224,8 +1224,8 @@ __global__ __launch_bounds__(256) void focal_elem_kernel(const float* __restrict
   } while (0)
 
 int mi355det_sigmoid_focal_loss_elem(const float* x, const float* t, int64_t n, float alpha, float gamma, float* loss, float* grad, void* stream) {
-  if (n < 0 || !x || !t || !loss) return fail(MI355DET_EINVAL, "%s: bad arguments", "sigmoid_focal_loss_elem");
   if (n == 0) return 0;
+  if (n < 0 || !x || !t || !loss) return fail(MI355DET_EINVAL, "%s: bad arguments", "sigmoid_focal_loss_elem");
   hipLaunchKernelGGL(focal_elem_kernel, dim3((int)min((long long)4096, (long long)((n + 255) / 256))), dim3(256), 0, S(stream), x, t, (long long)n, alpha, gamma,
                      loss, grad);
   return check_launch("sigmoid_focal_loss_elem");

@@ -49,8 +49,10 @@ struct WgradParams {
   int co_tiles, np_tiles, splits, chunk;                                // chunk = pixels per split (multiple of 64)
   int step_q, step_r;                                                   // 64 = step_q*Wo + step_r
   FastDiv dWo, dHo, dCin;
+  int ablate;   // diagnostic (mi355det_debug_set(6, v), timing only, results are garbage): 1 = no X-tile LDS-DMA after the first k-step, 2 = no dY-tile LDS-DMA, 4 = no MFMAs
 };
 
+int g_wgrad_ablate = 0;    // diagnostic (mi355det_debug_set(6, v)): WgradParams::ablate
 int g_wgrad_general = 0;   // diagnostic (mi355det_debug_set(1, v)): 1 = always the per-lane bookkeeping form (tests compare the two)
 
 namespace {
@@ -198,11 +200,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < 4; ++i) {
       const int instr = wid * 4 + i;
       const int ph = (i >> 1) & 1;
-      bufld16(rsrc_dy, sd + instr * 1024, dyv[i], 0);
+      if (!(p.ablate & 2) || m_base == mA) bufld16(rsrc_dy, sd + instr * 1024, dyv[i], 0);
       if (GRP4 == 3) {   // Wo % 16 == 0: the wave's four pieces are 16 consecutive pixels of ONE image row, one tracker serves them
         const int hs = g_hs[0], ws = g_ws[0] + i * 4 * p.stride;
         const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
-        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[0] + i * c_piece);
+        if (!(p.ablate & 1) || m_base == mA) bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[0] + i * c_piece);
         if (i < 3) continue;
       }
       const int ti = GRP4 == 3 ? 0 : i;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
       if (GRP4 == 3) {
       } else if (GRP4 == 1 || (ws + 4 * p.stride <= WoS && instr * 4 + 4 <= rem)) {   // wave-uniform: the piece's four pixels lie in one image row
         const bool ok = instr * 4 < rem && (unsigned)(hs + ty[ph]) < (unsigned)p.H && (unsigned)(ws + cx[ph]) < (unsigned)p.W;
-        bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[i]);
+        if (!(p.ablate & 1) || m_base == mA) bufld16(rsrc_x, sx + instr * 1024, ok ? lc[ph] : OOB_VOFF, g_sb[i]);
       } else {
         // the piece straddles a row end (map widths that are not multiples of 4) or the end of the pixel range: lanes past the
         // row end move to the next row / image by a scalar byte delta
@@ -323,10 +325,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
           bfr[j][4 * h + 3] = v[3];
         }
       }
+      if (!(p.ablate & 4)) {
 #pragma unroll
-      for (int i = 0; i < CI; ++i)
+        for (int i = 0; i < CI; ++i)
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) acc[i][j] = MI355_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
+          for (int j = 0; j < CJ; ++j) acc[i][j] = MI355_MFMA_16x16x32(af[i], bfr[j], acc[i][j]);
+      } else {
+        acc[0][0][0] += (float)af[0][0] + (float)bfr[0][0];      // keep the fragment reads alive
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -699,6 +705,7 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   p.NP = p.T * p.Cin;
   p.co_tiles = (p.Cout + WG_TILE - 1) / WG_TILE;
   p.np_tiles = (p.NP + WG_TILE - 1) / WG_TILE;
+  p.ablate = g_wgrad_ablate;
   const int tiles = p.co_tiles * p.np_tiles;
   int splits = choose_splits(tiles, p.M, 4.0 * p.Cout * (double)p.NP);
   {

@@ -574,8 +574,15 @@ class RetinaPlan:
         def py(fn, *a):
             self.bwd.append((comm_hook, (fn,) + a))
 
+        # Every gradient buffer is OWNED by the plan (self.grad_bufs): the call list bakes raw device pointers, and a buffer that was only
+        # reachable through an activation's `parts` queue was freed as soon as the queue handed it to a call (residual of a data gradient,
+        # operand of an add) - the caching allocator then gave the block to whoever asked next (round 4 found the Faster R-CNN box head's
+        # weight packs, created in the first training call, overwritten by every later backward: tests/test_gpu_fullsize_tv.py).
+        self.grad_bufs = []
+
         def dense(a):
             g = Act(torch.zeros((a.n, a.h, a.w, a.c), device=dev, dtype=bf), a.n, a.h, a.w, a.c, a.c)
+            self.grad_bufs.append(g.buf)
             return g
 
         # ---- gradient bookkeeping: an activation's gradient is the sum of its consumers' contributions; tensors that already

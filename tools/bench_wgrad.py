@@ -1,0 +1,35 @@
+"""Isolated weight-gradient timing on the YOLOv3 @640 bs-32 shapes, with the ablation builds of wgrad_kernel (mi355det_debug_set(6, v):
+1 = no X-tile LDS-DMA, 2 = no dY-tile LDS-DMA, 4 = no MFMAs; timing only).      python tools/bench_wgrad.py [ablate ...]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detectors_amd import ops
+from object_detectors_amd._lib import lib
+import ctypes as C
+dev = torch.device('cuda:0')
+SHAPES = [(32, 80, 80, 128, 256, 3, 1), (32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (32, 40, 40, 512, 256, 1, 1),
+          (32, 80, 80, 256, 128, 1, 1), (32, 160, 160, 64, 128, 3, 1), (32, 320, 320, 32, 64, 3, 1)]
+abl = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4]
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+L = lib()
+for (n, h, w, cin, cout, k, s) in SHAPES:
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s)
+    x = torch.randn(n, h, w, cin, device=dev).bfloat16()
+    dy = torch.randn(n, shape.ho, shape.wo, cout, device=dev).bfloat16()
+    dw = torch.zeros(cout, k * k * cin, device=dev)
+    need = L.mi355det_conv_wgrad_workspace(C.byref(shape))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    sp = L.mi355det_conv_wgrad_autotune(C.byref(shape), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    fl = 2.0 * n * shape.ho * shape.wo * cout * cin * k * k
+    msg = f"{cin:4d}->{cout:4d} k{k} s{s} @{shape.ho:3d} splits {sp:3d}:"
+    for a in abl:
+        L.mi355det_debug_set(6, a)
+        t = min(timeit(lambda: ops.conv_wgrad(shape, x, dy, dw, workspace=ws)) for _ in range(3))
+        msg += f"  [abl {a}] {t:6.1f}us {fl / t / 1e6:5.0f}TF |"
+    L.mi355det_debug_set(6, 0)
+    print(msg, flush=True)
