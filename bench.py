@@ -67,7 +67,7 @@ def pmc_traffic(batch, px):
     """HBM bytes per forward-conv launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).
     PMC counters cannot be read from inside the process, so the figure is the one measured for bs=32 / 640 px."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
     if batch != 32 or px != 640 or not os.path.exists(path):
         return None, None, None
     d = json.load(open(path))
@@ -77,7 +77,7 @@ def pmc_traffic(batch, px):
             n += d[fam]["launches_per_step"]
             b += d[fam]["launches_per_step"] * (d[fam]["read_MB_per_launch"] + d[fam]["write_MB_per_launch"]) * 1e6
     mu = d.get("igemm fwd (BN partial stats)", {}).get("mfma_util_pct")
-    return (round(b / n) if n else None), "profiles/r03_pmc_summary.md", (round(mu, 1) if mu is not None else None)
+    return (round(b / n) if n else None), "profiles/r04_pmc_summary.md", (round(mu, 1) if mu is not None else None)
 
 
 def cpu_baseline(px, sample_bs=2, warmup=1, iters=5):

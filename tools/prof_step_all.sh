@@ -1,8 +1,8 @@
 # Evidence for the bench.py step: kernel trace -> step / layer tables + kernel stats; three separate --pmc passes -> HBM traffic summary.
-#   usage (on the GPU box, from the repo root): bash tools/prof_step_all.sh <tag>      -> gpurun_out/r3/<tag>_*
+#   usage (on the GPU box, from the repo root): bash tools/prof_step_all.sh <tag>      -> gpurun_out/r4/<tag>_* (OUTDIR overrides r4)
 set -e
 TAG=${1:-r03}
-O=gpurun_out/r3
+O=gpurun_out/${OUTDIR:-r4}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 CMD="python3 bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-events"
