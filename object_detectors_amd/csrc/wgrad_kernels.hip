@@ -732,6 +732,12 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   p.dWo = make_fastdiv((unsigned)p.Wo);
   p.dHo = make_fastdiv((unsigned)p.Ho);
   p.dCin = make_fastdiv((unsigned)p.Cin);
+  // (Measured and reverted, round 4: ONE workgroup per CU - 96 KB of dynamic LDS - for launches with many LONG workgroups.  The 1204-class
+  //  cls_logits weight gradient of RetinaNet-LVIS has 1530 tiles x 1250 k-steps = 1.6 ms per workgroup and no split fits the workspace; two of
+  //  them per CU leave 32 KB of LDS, so a 64 KB tile of the dependency-chain stream waits for a whole round: three FPN data gradients of
+  //  20-50 us each took 1.6 ms (round 3's "FPN dgrad 4.84 ms at 34 TFLOP/s", profiles/r04_retinanet_r101_timeline.md).  One per CU removed
+  //  that wait (FPN dgrad 5.15 -> 0.89 ms) but the step went 40.7 -> 42.3 ms: this kernel lost 12-48 %, and the wait moved to the next
+  //  small kernels of both streams.  The step is bound by the total work of the cls_logits kernels, not by who waits for whom.)
   const int lds = 2 * 2 * WG_BKP * WG_ROWB;
   // per-wave fragment counts: the four waves (2 x 2) split min(Cout,128) x min(NP,128) real channels
   const int ci = p.Cout <= 32 ? 1 : (p.Cout <= 64 ? 2 : 4), cj = p.NP <= 32 ? 1 : (p.NP <= 64 ? 2 : 4);

@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--px", type=int, default=800)
 ap.add_argument("--body", default="resnet50")
 ap.add_argument("--classes", type=int, default=91)
+ap.add_argument("--dump-us", type=float, default=0.0, help="also list every launch that took at least this many microseconds (stderr), in issue order")
 args = ap.parse_args()
 from object_detectors_amd._lib import check, lib  # noqa: E402
 from object_detectors_amd.optim import FlatSGD  # noqa: E402
@@ -59,6 +60,7 @@ for rec in plan.ops:
         for key in ("shp", "shp_f"):
             name_of[C.addressof(rec[key])] = fam
 events = []
+detail = []
 
 
 def run_with_events(calls):
@@ -79,6 +81,7 @@ def run_with_events(calls):
             e1.record(stream)
             fl = 2.0 * shp.n * shp.ho * shp.wo * shp.cout * shp.cin * shp.ksize * shp.ksize
             events.append((kind, name_of.get(C.addressof(shp), f"{shp.cin}->{shp.cout} k{shp.ksize}"), fl, e0, e1, shp.ho))
+            detail.append((kind, fn.__name__, name_of.get(C.addressof(shp), "?"), (shp.n, shp.h, shp.w, shp.cin, shp.ho, shp.wo, shp.cout, shp.ksize, shp.stride)))
         if st != 0:
             check(st, fn.__name__)
 
@@ -90,6 +93,11 @@ eng.train_step(imgs, targets)
 opt.step()
 t1.record()
 torch.cuda.synchronize()
+if args.dump_us > 0:
+    for (kind, fam, fl, e0, e1, ho), d in zip(events, detail):
+        t = e0.elapsed_time(e1) * 1e3
+        if t >= args.dump_us:
+            print(f"{t:9.1f} us  {d[0]:5s} {d[1]:28s} {d[2]:40s} n,h,w,cin,ho,wo,cout,k,s = {d[3]}", file=sys.stderr)
 agg = collections.OrderedDict()
 lev = collections.OrderedDict()
 for kind, fam, fl, e0, e1, ho in events:

@@ -24,11 +24,12 @@ for r in seg:
     queues.setdefault(r[qkey], []).append(r)
 print(f"step: {len(seg)} launches, {(int(seg[-1]['End_Timestamp']) - t0) / 1e6:.2f} ms, queues: " + ", ".join(f"{q}: {len(v)} launches, busy {sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in v) / 1e6:.2f} ms" for q, v in queues.items()))
 for q, v in queues.items():
-    print(f"\n## queue {q}\n\n| start ms | dur us | gap before us | kernel |\n|---|---|---|---|")
+    print(f"\n## queue {q}\n\n| start ms | dur us | gap before us | workgroups | kernel |\n|---|---|---|---|---|")
     prev_end = None
     for r in v:
         st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = 0 if prev_end is None else (st - prev_end) / 1e3
         prev_end = max(prev_end or 0, en)
         if (en - st) / 1e3 >= a.min_us or gap >= a.min_us:
-            print(f"| {(st - t0) / 1e6:.3f} | {(en - st) / 1e3:.0f} | {gap:.0f} | {r['Kernel_Name'][:110]} |")
+            wg = int(r.get("Grid_Size", 0) or 0) // max(1, int(r.get("Workgroup_Size", 1) or 1))
+            print(f"| {(st - t0) / 1e6:.3f} | {(en - st) / 1e3:.0f} | {gap:.0f} | {wg} | {r['Kernel_Name'].replace('void (anonymous namespace)::', '')[:90]} |")
