@@ -97,11 +97,14 @@ def bn_name(conv_name):
 
 class YoloV3Engine:
     def __init__(self, backbone="darknet_53", num_anchors=3, num_classes=80, device=None, seed=0, sync_bn=False, process_group=None, storage="bf16",
-                 deterministic=True):
+                 deterministic=True, fuse_bn_reduce=False):
         """deterministic (default): every kernel of the step sums in a fixed order - two runs of the same inputs under the same tune record give
         bit-identical weights (tests/test_gpu_trajectory.py), like the reference's torch / cuDNN BatchNorm backward.  False: the BatchNorm-backward
         sums end in fp32 atomics instead of a second small launch per layer (72 launches on the dependency chain: ~0.25 ms of a 28 ms step,
         profiles/r04_ab_results.md); gradients then differ by ~6e-4 of max from run to run.
+        fuse_bn_reduce (experimental): the BatchNorm-backward sums in the epilogue of the data gradient that produces the activation
+        gradient (mi355det_conv_dgrad_bn) instead of a separate pass; correct and tested, 0.7 ms slower per step (the epilogue's z-tile reads are not
+        prefetched), off by default.
         storage: format of every stored activation, activation gradient and packed weight - "bf16" (default) or "fp16", the format of the
         reference's mixed-precision recipe (apex O2: yolo/batch_files/sample.txt:28-44, initialize.py:44-45); accumulation, BatchNorm statistics,
         master weights and gradients stay fp32 either way.  fp16 has three more mantissa bits and five fewer exponent bits: train it with a loss
@@ -115,6 +118,7 @@ class YoloV3Engine:
             raise ValueError("storage must be 'bf16' or 'fp16'")
         self.storage = storage
         self.deterministic = bool(deterministic)
+        self.fuse_bn_reduce = bool(fuse_bn_reduce)
         self.L = _lib.storage_lib(storage)                 # entry points of this storage format (fp16: the *_f16 twins)
         self.adt = torch.float16 if storage == "fp16" else torch.bfloat16
         self.grad_fmt = 2 if storage == "fp16" else 1       # mi355det_yolo_loss_cfg.grad_is_bf16
@@ -628,7 +632,7 @@ class Plan:
         # BN-backward reduction fused into the producing dgrad's epilogue (mi355det_conv_dgrad_bn): correct and tested, but measured
         # SLOWER end to end in round 1 (849 vs 871 img/s): the z tile is read at the tile's end where nothing hides the HBM latency.
         # Opt-in until the prefetch is moved into the last k-steps.
-        self.fuse_bn_reduce = os.environ.get("MI355DET_BN_FUSION", "0") == "1"
+        self.fuse_bn_reduce = eng.fuse_bn_reduce
         main = torch.cuda.current_stream(dev)
         # (one stream for everything was the A/B of round 3: +1.0 ms per step, profiles/r03_ab_results.md)
         self.side = torch.cuda.Stream(device=dev)

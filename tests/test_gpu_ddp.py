@@ -202,6 +202,13 @@ def _worker_syncbn(rank, world, port, q):
             worst.sort()
             res["worst"] = worst[:6]
             res["best"] = worst[-3:]
+            # sharp, layer-local check of the FORWARD exchange: the stem's statistics depend on the images alone (no upstream rounding
+            # noise), so its finalised rows (scale, shift, mean, invstd) over the all-reduced fp64 sums must equal the whole-batch run's to fp32
+            # accuracy - a wrong count, a missed rank or a swapped row cannot hide here as it could behind the 40-layer bars below
+            ss_s, ss_r = plan.layers["backbone.conv1"]["ss"].double(), ref._last_plan.layers["backbone.conv1"]["ss"].double()
+            res["ss_stem"] = float(((ss_s - ss_r).abs() / (ss_r.abs() + 1e-3)).max())
+            res["rm_stem"] = rel(eng.buffers["backbone.bn1.running_mean"], ref.buffers["backbone.bn1.running_mean"])
+            res["rv_stem"] = rel(eng.buffers["backbone.bn1.running_var"], ref.buffers["backbone.bn1.running_var"])
             res["rm"] = rel(eng.buffers["backbone.layer3.residual_0.bn1.running_mean"], ref.buffers["backbone.layer3.residual_0.bn1.running_mean"])
             res["rv"] = rel(eng.buffers["backbone.layer3.residual_0.bn1.running_var"], ref.buffers["backbone.layer3.residual_0.bn1.running_var"])
         q.put(res)
@@ -237,6 +244,7 @@ def test_two_rank_sync_batchnorm_equals_whole_batch():
     for r in res:
         assert r["dz_global"] < 2e-3 and r["dz_local"] > 10 * r["dz_global"], r     # zero-sum over the GLOBAL batch only
     assert r0["rm"] < 2e-2 and r0["rv"] < 2e-2, r0
+    assert r0["ss_stem"] < 1e-5 and r0["rm_stem"] < 1e-5 and r0["rv_stem"] < 1e-5, r0
 
 
 def _worker_rccl(rank, world, port, q):
