@@ -258,8 +258,10 @@ class RetinaNetEngine:
             while len(self.plans) >= self.MAX_PLANS:
                 torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
                 self.plans.pop(next(iter(self.plans)))
-            # (tune.plan_build: MI355DET_TUNE_LOAD / _SAVE; for N > 1 rank 0's timing choices are broadcast - training plans only)
-            p = tune.plan_build(lambda: RetinaPlan(self, n, H, W, training, key[-1]), share=None if training else False)
+            # (tune.plan_build: MI355DET_TUNE_LOAD / _SAVE; for N > 1 rank 0's timing choices are broadcast - a collective, so only for training
+            #  plans of an engine with a GradSync attached: plans every rank is known to build)
+            dp = bool(training and getattr(self, "grad_syncs", ()))
+            p = tune.plan_build(lambda: RetinaPlan(self, n, H, W, training, key[-1]), share=None if dp else False)
             if training:
                 for gs in getattr(self, "grad_syncs", ()):       # parallel.GradSync.attach(): every plan gets the bucket hooks
                     gs.install(p)

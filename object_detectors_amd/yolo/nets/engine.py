@@ -333,9 +333,12 @@ class YoloV3Engine:
             while len(self.plans) >= self.MAX_PLANS:
                 torch.cuda.current_stream().synchronize()           # nothing of the evicted plan may still be running
                 self.plans.pop(next(iter(self.plans)))
-            # (tune.plan_build: MI355DET_TUNE_LOAD / _SAVE, and for N > 1 rank 0's timing choices broadcast to every rank - training plans only:
-            #  an evaluation loop may run on a subset of the ranks)
-            p = tune.plan_build(lambda: Plan(self, n, H, W, training, key[-1]), group=None, share=None if training else False)
+            # (tune.plan_build: MI355DET_TUNE_LOAD / _SAVE, and for N > 1 rank 0's timing choices broadcast to every rank.  The broadcast is a
+            #  collective, so it runs only for plans every rank is known to build: training plans of an engine that takes part in data-parallel
+            #  training - a GradSync is attached or SyncBN is on.  An evaluation loop, or a second engine that one rank builds for itself, may
+            #  exist on a subset of the ranks)
+            dp = bool(training and (self.sync_bn or getattr(self, "grad_syncs", ())))
+            p = tune.plan_build(lambda: Plan(self, n, H, W, training, key[-1]), group=None, share=None if dp else False)
             if training:
                 for gs in getattr(self, "grad_syncs", ()):       # parallel.GradSync.attach(): every plan gets the bucket hooks
                     gs.install(p)
