@@ -196,6 +196,10 @@ def main():
     ap.add_argument("--px", type=int, default=640)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-record", default="auto",
+                    help="tune record to load (locked) before the plan build: a path, 'none' (time everything on this box), or 'auto' = "
+                         "object_detectors_amd/tune_records/yolov3_d53_bs<batch>_<px>_<storage>.json when it exists (the committed step-level record: the "
+                         "same kernels, summation orders and choices on every box and rank; tools/tune_step.py)")
     ap.add_argument("--storage", choices=["bf16", "fp16"], default="bf16",
                     help="format of stored activations / gradients / packed weights (fp16: the reference's apex-O2 format, with a loss scale of 1024)")
     ap.add_argument("--atomic-bn-sums", action="store_true",
@@ -249,6 +253,14 @@ def main():
     from object_detectors_amd.yolo.nets.engine import YoloV3Engine
     from object_detectors_amd.yolo.nets.yolo_forw import YOLOForw
 
+    rec_path = args.tune_record
+    if rec_path == "auto":
+        rec_path = os.path.join(ROOT, "object_detectors_amd", "tune_records", f"yolov3_d53_bs{args.batch}_{args.px}_{args.storage}.json")
+        if not os.path.exists(rec_path) or os.environ.get("MI355DET_TUNE_LOAD"):
+            rec_path = "none"
+    if rec_path != "none":
+        from object_detectors_amd import tune
+        tune.load(rec_path, replace=False, lock=True)
     eng = YoloV3Engine("darknet_53", 3, 80, device=dev, seed=0, storage=args.storage, deterministic=not args.atomic_bn_sums)
     loss_scale = 1024.0 if eng.storage == "fp16" else 1.0      # apex-style static scale for the timing run (train_one_epoch.py:88-94)
     crit = YOLOForw(anchors=ANCHORS, num_classes=80, img_size=args.px).to(dev)
@@ -350,7 +362,7 @@ def main():
             "metric": f"images/sec (fwd+bwd) YOLOv3 {args.px}px bs={args.batch}", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": eng.storage, "data": "synthetic",
-            "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+loss+bwd{'+grad all-reduce' if world > 1 else ''}+SGD step), "
+            "tune_record": (os.path.relpath(rec_path, ROOT) if rec_path != "none" else None), "config": {"workload": f"YOLOv3 Darknet-53 training step (fwd+loss+bwd{'+grad all-reduce' if world > 1 else ''}+SGD step), "
                                    f"synthetic COCO {args.px}px, per-GPU bs={args.batch}, 7 GT/img, random-init weights",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "loss_first": round(loss0, 4), "loss_last": round(loss1, 4), "weights_in_sync_across_ranks": in_sync,

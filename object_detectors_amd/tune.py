@@ -143,3 +143,99 @@ def plan_build(build, group=None, share=None):
     if path and rank == 0:
         save(path)
     return out
+
+
+# ---- step-level refinement ------------------------------------------------------------------------------------------------------------
+IGEMM_CANDIDATES = (1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28, 40, 44, 45)      # conv_kernels.hip:autotune_igemm cands[]
+_NARROW = {0: (29, 30, 31), 29: (0,), 30: (0,), 31: (0,)}
+
+
+def _alternatives(table, v):
+    if table == "igemm":
+        return _NARROW[v] if v in _NARROW else tuple(c for c in IGEMM_CANDIDATES if c != v)
+    if table == "s2cat":
+        return (1 - v,)
+    out = []
+    for f in (0.5, 0.67, 0.8, 1.25, 1.5, 2.0):
+        w = max(1, int(round(v * f)))
+        if w != v and w not in out:
+            out.append(w)
+    return tuple(out)
+
+
+def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budget_s=900.0, skip=0, log=print, checkpoint=None):
+    """Coordinate descent on the WHOLE STEP over the current tune record (tools/tune_step.py is the command line for the YOLO bench).
+
+    The plan build times every candidate alone - back to back with itself, warm caches, the whole chip.  Inside a training step a data gradient
+    shares the chip with a weight gradient on the other stream and every forward convolution starts behind a streaming BatchNorm pass, so the
+    isolated winner is not always the step's winner (round 4: halving one weight-gradient split count and changing two tile configurations took
+    0.44 ms off a 29.1 ms step).  `step()` runs one complete training step of an engine whose plans are already built; for one entry at a time
+    (a shape: every layer of that shape moves together) the other legal values are tried, and a value is kept only if the step got faster by
+    more than `min_gain_us`, confirmed against a fresh measurement of the incumbent.  Choices are looked up in the library at launch time, so a
+    trial is an import of a modified record + `steps` steps: no plan rebuild.  Leaves the refined record imported and locked; returns
+    (start_us, final_us, number of entries changed).  Entries of the other storage format are left alone."""
+    import time
+
+    import torch
+
+    def measure(reps):
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / steps * 1e6)
+        return min(ts)
+
+    cur = {(t, k): v for t, k, v in to_entries(export_bytes())}
+    fmt_bit = 1 if storage == "fp16" else 0
+
+    def mine(t, k):      # the igemm / wgrad keys end in the format bit, the s2cat key carries it in bit 61 (csrc: igemm_key, wgrad_key)
+        return ((k >> 61) & 1) == fmt_bit if t == "s2cat" else (k & 1) == fmt_bit
+
+    def apply(d):
+        import_bytes(from_entries([(t, k, v) for (t, k), v in d.items()]), replace=True, lock=True)
+
+    apply(cur)
+    base = start = measure(5)
+    log(f"start: {base:.0f} us per step")
+    t_begin, kept = time.time(), 0
+    order = sorted(cur, key=lambda e: (("wgrad", "igemm", "s2cat").index(e[0]), e[1]))
+    for rnd in range(rounds):
+        changed = False
+        for pos, (t, k) in enumerate(order):
+            if not mine(t, k) or time.time() - t_begin > budget_s or (rnd == 0 and pos < skip):
+                continue
+            v0 = cur[(t, k)]
+            log(f"  [{time.time() - t_begin:5.0f} s] round {rnd} entry {pos}: {t} {k} (now {v0}; step {base:.0f} us)")
+            best_v, best_t = v0, base
+            for v in _alternatives(t, v0):
+                trial = dict(cur)
+                trial[(t, k)] = v
+                apply(trial)
+                tm = measure(2)
+                if tm < best_t - min_gain_us:
+                    best_v, best_t = v, tm
+            if best_v != v0:
+                trial = dict(cur)
+                trial[(t, k)] = best_v
+                apply(trial)
+                conf = measure(4)
+                apply(cur)
+                inc = measure(4)
+                if conf < inc - min_gain_us:
+                    cur[(t, k)] = best_v
+                    base, kept, changed = conf, kept + 1, True
+                    log(f"round {rnd}: {t} {k}: {v0} -> {best_v}  ({inc:.0f} -> {conf:.0f} us per step)")
+                    if checkpoint:
+                        apply(cur)
+                        save(checkpoint)
+            apply(cur)
+        if not changed:
+            break
+    apply(cur)
+    final = measure(5)
+    log(f"final: {final:.0f} us per step; {kept} entries changed; {time.time() - t_begin:.0f} s of search")
+    return start, final, kept

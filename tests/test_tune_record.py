@@ -117,3 +117,15 @@ def test_rank0_record_is_broadcast_world2_gloo():
     want1 = dict(((t, k), v) for t, k, v in REC_B)
     want1.update(want0)
     assert res[1][1] == want1 and res[1][2] is True
+
+
+def test_refinement_candidates():
+    """tune.refine_step's neighbourhood of a choice: every other wide tile configuration, plain <-> shared-pixel-tile for the narrow outputs, the
+    other stride-2 form, split counts around the current one (the library falls back to the nearest valid split)."""
+    from object_detectors_amd import tune
+    assert set(tune._alternatives("igemm", 40)) == set(tune.IGEMM_CANDIDATES) - {40} and 44 in tune._alternatives("igemm", 1)
+    assert tune._alternatives("igemm", 0) == (29, 30, 31) and tune._alternatives("igemm", 30) == (0,)
+    assert tune._alternatives("s2cat", 1) == (0,) and tune._alternatives("s2cat", 0) == (1,)
+    alt = tune._alternatives("wgrad", 48)
+    assert 24 in alt and 96 in alt and 48 not in alt and all(a >= 1 for a in alt)
+    assert tune._alternatives("wgrad", 1) == (2,)
