@@ -21,7 +21,20 @@ def main():
     ap.add_argument("--no-fwd-only", action="store_true", help="skip the trailing forward-only timing (profiling passes: the trace then ends with whole steps)")
     ap.add_argument("--body", default="resnet50")
     ap.add_argument("--classes", type=int, default=91)
+    ap.add_argument("--tune-record", default="auto", help="tune record to load locked before the plan build: a path, 'none', or 'auto' = "
+                    "object_detectors_amd/tune_records/retinanet_<body>_<classes>cls_bs<batch>_<px>.json when it exists (tune.refine_step)")
+    ap.add_argument("--refine", default=None, metavar="OUT.json", help="refine the record on the whole step (tune.refine_step) and write it there")
+    ap.add_argument("--refine-budget-s", type=float, default=600.0)
     args = ap.parse_args()
+    from object_detectors_amd import tune
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = args.tune_record
+    if rec == "auto":
+        rec = os.path.join(root, "object_detectors_amd", "tune_records", f"retinanet_{args.body}_{args.classes}cls_bs{args.batch}_{args.px}.json")
+        if not os.path.exists(rec):
+            rec = "none"
+    if rec != "none":
+        tune.load(rec, replace=False, lock=True)
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.tvision.engine import RetinaNetEngine
     dev = torch.device("cuda:0")
@@ -52,6 +65,12 @@ def main():
         l0 = step()
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t0
+    if args.refine:
+        os.makedirs(os.path.dirname(os.path.abspath(args.refine)), exist_ok=True)
+        a, b, kept = tune.refine_step(step, rounds=2, steps=4, min_gain_us=40.0, budget_s=args.refine_budget_s,
+                                      log=lambda m: print(m, file=sys.stderr, flush=True), checkpoint=args.refine)
+        tune.save(args.refine)
+        print(f"refined: {a:.0f} -> {b:.0f} us per step, {kept} entries changed", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         l1 = step()
@@ -66,7 +85,7 @@ def main():
     print(json.dumps({"bench": f"retinanet_{args.body}_fpn_train_step_{args.classes}cls", "batch": args.batch, "px": args.px, "images_per_s": round(args.batch / dt, 2),
                       "ms_per_step": round(dt * 1e3, 3), "fwd_ms": round(df * 1e3, 3), "plan_build_s": round(t_build, 1),
                       "loss_first": [round(float(v), 4) for v in l0], "loss_last": [round(float(v), 4) for v in l1],
-                      "trainable_params": int(eng.flat_w.numel()), "anchors_per_image": int(eng._last_plan.rows)}))
+                      "tune_record": (os.path.relpath(rec, root) if rec != "none" else None), "trainable_params": int(eng.flat_w.numel()), "anchors_per_image": int(eng._last_plan.rows)}))
 
 
 if __name__ == "__main__":
