@@ -112,3 +112,27 @@ def test_weight_gradient_forms_bit_identical_full_size():
     ref = torch.einsum("pc,pk->ck", gy.view(-1, cout)[:, :8].double(), x.view(-1, cin).double())
     got = outs[1].view(cout, 9, cin)[:8, 4, :].double()
     assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("storage", ["bf16", "fp16"])
+def test_committed_bench_tune_record_covers_the_bench_plan(storage):
+    """object_detectors_amd/tune_records/yolov3_d53_bs32_640_<storage>.json (the step-refined record bench.py loads by default) must cover every
+    shape the bench's plan tunes: after loading it locked, building the batch-32 / 640-px training plan adds no entry and changes none.  A
+    record that went stale (a changed shape key, a new tunable) would not break anything - the missing shapes are timed on the box - but the
+    bench would silently lose its refined, box-independent choices."""
+    import os
+    from object_detectors_amd import tune
+    from object_detectors_amd.yolo.nets.engine import YoloV3Engine
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "object_detectors_amd", "tune_records",
+                        f"yolov3_d53_bs32_640_{storage}.json")
+    assert os.path.exists(path)
+    tune.clear()
+    try:
+        rec = tune.load(path, replace=True, lock=True)
+        eng = YoloV3Engine("darknet_53", 3, 80, device=dev(), seed=0, storage=storage)
+        eng.plan(32, 640, 640, True)
+        torch.cuda.synchronize()
+        after = tune.export_bytes()
+        assert after == rec, sorted(set(tune.to_entries(after)) - set(tune.to_entries(rec)))[:8]
+    finally:
+        tune.clear()

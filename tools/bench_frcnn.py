@@ -20,7 +20,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reuse-rpn-targets", action="store_true", help="MEASUREMENT ONLY: prepare the RPN targets once and reuse them (the "
                     "targets are constant in this bench) - the step time that kernels for RPNTargets.prepare could reach at most; not a valid step")
+    ap.add_argument("--tune-record", default="auto", help="tune record to load locked before the plan build: a path, 'none', or 'auto' = "
+                    "object_detectors_amd/tune_records/fasterrcnn_resnet50_bs<batch>_<px>.json when it exists (tune.refine_step)")
+    ap.add_argument("--refine", default=None, metavar="OUT.json", help="refine the record on the whole training step (tune.refine_step) and write it there")
+    ap.add_argument("--refine-budget-s", type=float, default=600.0)
     args = ap.parse_args()
+    from object_detectors_amd import tune
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = args.tune_record
+    if rec == "auto":
+        rec = os.path.join(root, "object_detectors_amd", "tune_records", f"fasterrcnn_resnet50_bs{args.batch}_{args.px}.json")
+        if not os.path.exists(rec):
+            rec = "none"
+    if rec != "none":
+        tune.load(rec, replace=False, lock=True)
     from object_detectors_amd.optim import FlatSGD
     from object_detectors_amd.tvision.frcnn import fasterrcnn_resnet50_fpn
     dev = torch.device("cuda:0")
@@ -56,6 +69,12 @@ def main():
     for _ in range(args.warmup):
         l0 = step()
     torch.cuda.synchronize()
+    if args.refine:
+        os.makedirs(os.path.dirname(os.path.abspath(args.refine)), exist_ok=True)
+        a, b, kept = tune.refine_step(step, rounds=2, steps=6, min_gain_us=30.0, budget_s=args.refine_budget_s,
+                                      log=lambda m: print(m, file=sys.stderr, flush=True), checkpoint=args.refine)
+        tune.save(args.refine)
+        print(f"refined: {a:.0f} -> {b:.0f} us per step, {kept} entries changed", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         l1 = step()
@@ -73,7 +92,8 @@ def main():
     print(json.dumps({"bench": "fasterrcnn_resnet50_fpn" + ("_REUSED_RPN_TARGETS_not_a_valid_step" if args.reuse_rpn_targets else ""), "batch": args.batch, "px": args.px, "train_images_per_s": round(args.batch / dt, 2),
                       "train_ms_per_step": round(dt * 1e3, 2), "eval_images_per_s": round(args.batch / de, 2), "eval_ms_per_batch": round(de * 1e3, 2),
                       "losses_first": {k: round(float(v), 4) for k, v in l0.items()}, "losses_last": {k: round(float(v), 4) for k, v in l1.items()},
-                      "detections_img0": int(det[0]["boxes"].shape[0])}))
+                      "detections_img0": int(det[0]["boxes"].shape[0]),
+                      "tune_record": (os.path.relpath(rec, root) if rec != "none" else None)}))
 
 
 if __name__ == "__main__":
