@@ -25,6 +25,9 @@ def main():
                     "object_detectors_amd/tune_records/retinanet_<body>_<classes>cls_bs<batch>_<px>.json when it exists (tune.refine_step)")
     ap.add_argument("--refine", default=None, metavar="OUT.json", help="refine the record on the whole step (tune.refine_step) and write it there")
     ap.add_argument("--refine-budget-s", type=float, default=600.0)
+    ap.add_argument("--refine-min-gain-us", type=float, default=40.0, help="a change is kept only if the step gets faster by more than this (long steps are noisier: "
+                    "the first R101-LVIS record, refined with 40 us on a 40 ms step, was 1 %% SLOWER than no record on another box)")
+    ap.add_argument("--refine-steps", type=int, default=4)
     args = ap.parse_args()
     from object_detectors_amd import tune
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,7 +70,7 @@ def main():
     t_build = time.perf_counter() - t0
     if args.refine:
         os.makedirs(os.path.dirname(os.path.abspath(args.refine)), exist_ok=True)
-        a, b, kept = tune.refine_step(step, rounds=2, steps=4, min_gain_us=40.0, budget_s=args.refine_budget_s,
+        a, b, kept = tune.refine_step(step, rounds=2, steps=args.refine_steps, min_gain_us=args.refine_min_gain_us, budget_s=args.refine_budget_s,
                                       log=lambda m: print(m, file=sys.stderr, flush=True), checkpoint=args.refine)
         tune.save(args.refine)
         print(f"refined: {a:.0f} -> {b:.0f} us per step, {kept} entries changed", file=sys.stderr, flush=True)
