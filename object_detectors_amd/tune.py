@@ -163,7 +163,7 @@ def _alternatives(table, v):
     return tuple(out)
 
 
-def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budget_s=900.0, skip=0, log=print, checkpoint=None):
+def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budget_s=900.0, skip=0, log=print, checkpoint=None, timer=None):
     """Coordinate descent on the WHOLE STEP over the current tune record (tools/tune_step.py is the command line for the YOLO bench).
 
     The plan build times every candidate alone - back to back with itself, warm caches, the whole chip.  Inside a training step a data gradient
@@ -173,21 +173,26 @@ def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budge
     (a shape: every layer of that shape moves together) the other legal values are tried, and a value is kept only if the step got faster by
     more than `min_gain_us`, confirmed against a fresh measurement of the incumbent.  Choices are looked up in the library at launch time, so a
     trial is an import of a modified record + `steps` steps: no plan rebuild.  Leaves the refined record imported and locked; returns
-    (start_us, final_us, number of entries changed).  Entries of the other storage format are left alone."""
+    (start_us, final_us, number of entries changed).  Entries of the other storage format are left alone.
+
+    `min_gain_us` has to sit above the run-to-run spread of `steps` steps: 40 us is right for the 28 ms YOLO step; the 40 ms RetinaNet-R101-LVIS
+    step refined with 40 us collected 53 "improvements" that were 1 % SLOWER than no record on another box (150 us: profiles/r04_ab_results.md §7).
+    `timer(step, steps) -> us per step` replaces the device-synchronised wall clock (tests/test_tune_record.py drives the search on a cost model)."""
     import time
 
-    import torch
+    def wall(step, steps):
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    timer = timer or wall
 
     def measure(reps):
-        ts = []
-        for _ in range(reps):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) / steps * 1e6)
-        return min(ts)
+        return min(timer(step, steps) for _ in range(reps))
 
     cur = {(t, k): v for t, k, v in to_entries(export_bytes())}
     fmt_bit = 1 if storage == "fp16" else 0

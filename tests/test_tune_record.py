@@ -129,3 +129,36 @@ def test_refinement_candidates():
     alt = tune._alternatives("wgrad", 48)
     assert 24 in alt and 96 in alt and 48 not in alt and all(a >= 1 for a in alt)
     assert tune._alternatives("wgrad", 1) == (2,)
+
+
+def test_refine_step_on_a_cost_model(tmp_path):
+    """The search of tune.refine_step on a synthetic step whose time is a function of the record: a change worth more than `min_gain_us` is found
+    and kept, one worth less is not, entries of the other storage format are never touched, the refined record is left imported and locked, and
+    the checkpoint file holds it."""
+    import random
+    from object_detectors_amd import tune
+    tune.clear()
+    K_W, K_I, K_S, K_F16 = 1000 * 2, 2000 * 2, 7, 3000 * 2 + 1            # keys end in the format bit (bf16 = 0); the s2cat key carries it in bit 61
+    start = [("wgrad", K_W, 64), ("igemm", K_I, 40), ("s2cat", K_S, 1), ("wgrad", K_F16, 64)]
+    tune.import_bytes(tune.from_entries(start), replace=True, lock=True)
+    rng = random.Random(0)
+    seen_f16 = set()
+
+    def cost():      # us per step: wgrad split 32 is 300 us better than 64, 16 is worse again; igemm 44 is 20 us better than 40 (below the bar)
+        rec = {(t, k): v for t, k, v in tune.to_entries(tune.export_bytes())}
+        seen_f16.add(rec[("wgrad", K_F16)])
+        c = 28000.0 + {64: 300.0, 32: 0.0}.get(rec[("wgrad", K_W)], 500.0) + (0.0 if rec[("igemm", K_I)] == 44 else 20.0)
+        c += 200.0 if rec[("s2cat", K_S)] == 0 else 0.0
+        return c + rng.uniform(0.0, 10.0)
+
+    ck = str(tmp_path / "ck.json")
+    lines = []
+    s_us, f_us, kept = tune.refine_step(lambda: None, rounds=2, steps=1, min_gain_us=40.0, budget_s=60.0, log=lines.append, checkpoint=ck,
+                                        timer=lambda step, steps: cost())
+    got = {(t, k): v for t, k, v in tune.to_entries(tune.export_bytes())}
+    assert got == {("wgrad", K_W): 32, ("igemm", K_I): 40, ("s2cat", K_S): 1, ("wgrad", K_F16): 64}
+    assert kept == 1 and s_us - f_us > 250.0 and seen_f16 == {64}
+    assert tune.lock(False) is True
+    assert {(t, k): v for t, k, v in tune.to_entries(tune.loads(open(ck).read()))} == got
+    assert any("64 -> 32" in l for l in lines)
+    tune.clear()
