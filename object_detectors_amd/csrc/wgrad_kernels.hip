@@ -7,8 +7,9 @@
 // [pixel][channel] with LDS-DMA (coalesced 256-B rows) and read column-wise without any shuffle.
 // 32-byte blocks of every LDS row are XOR-swizzled (on the source side) so the 8 rows a half-wave
 // touches in one transposed read land on distinct banks.
-// Split over the pixel axis; partial tiles are accumulated with fp32 atomics (256 B per wave row
-// segment), sized so atomic bytes stay far below the MFMA time (wgrad).
+// Split over the pixel axis; every split writes its partial tile to an fp32 slab (plain stores) and a second launch adds the slabs
+// in a fixed order (bit-reproducible).  Two kernels: wgrad_kernel (128 x 128 tile, 4 waves, two workgroups per CU) and wgrad8_kernel
+// (256 x 256 tile, 8 waves, the phase-staggered schedule of igemm8_kernel); same products in the same order for the same split count.
 #include "common.h"
 
 #include <cstdlib>
@@ -54,6 +55,7 @@ struct WgradParams {
 
 int g_wgrad_ablate = 0;    // diagnostic (mi355det_debug_set(6, v)): WgradParams::ablate
 int g_wgrad_general = 0;   // diagnostic (mi355det_debug_set(1, v)): 1 = always the per-lane bookkeeping form (tests compare the two)
+int g_wgrad_force_dbg = 0; // diagnostic (mi355det_debug_set(7, v)): split count (+ 65536: the 256 x 256 phase-staggered kernel) for every launch; 0 = tuned
 
 namespace {
 
@@ -368,6 +370,331 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Phase-staggered form (round 4): 256 co x 256 n' x 64 pixels per workgroup, 8 waves = 2 (n' halves, 128 each) x 4 (co quarters, 64
+// each), one workgroup per CU (128 KB LDS) - the schedule of igemm8_kernel (igemm8_kernels.hip) on transposed operands.
+//
+// Why: the 128 x 128 kernel above is LDS-bound.  Per 64-pixel k-step its four 64 x 64 wave tiles read 64 KB of fragments and the LDS-DMA
+// writes 32 KB for 128 MFMAs: 768 LDS cycles (128 B / clk) against 512 cycles of matrix pipe, and every wave runs DMA issue -> full
+// vmcnt(0) -> barrier -> reads -> MFMAs in the same order (profiles/r04_wgrad_ablations.txt: without ANY operand traffic +18-24 %, without
+// MFMAs +16-24 %: the k-step structure is the bound).  Here a wave tile is 128 x 64 (25 % fewer fragment bytes and 25 % fewer DMA bytes
+// per MFMA), the DMA is waited for with counted vmcnt, and the two waves of a SIMD run one barrier apart, so one is in its MFMA segment
+// while its partner issues DMA and waits.
+//
+// LDS: two k-step buffers of [X0 | X1 | D0 | D1], each a [64 pixels][256 B] half-tile in the layout of the kernel above (32-byte blocks
+// XOR-swizzled with rowf(pixel row), fragments by ds_read_b64_tr_b16).  Half h of the X tile holds the n' columns every wave multiplies in
+// its sub-phase h (n' = np0 + wm * 128 + h * 64 + 0..63 for wm = 0, 1: logical block b = wm * 4 + jj), half h of the dY tile the co
+// columns co0 + wn * 64 + h * 32 + 0..31 (b = wn * 2 + ii), so a half is free for re-staging as soon as its sub-phase has been read.
+// Phases, counted waits and the WAR / RAW argument are igemm8_kernel's (X = the 128-wide operand, D = its "W"):
+//   phase 1: MFMA (D0, X0) + reads D0k1 D1k0 D1k1      issues D1 of k-step t+1
+//   phase 2: MFMA (D1, X0) + reads X1                  issues X1 of t+1
+//   phase 3: MFMA (D1, X1)                             issues X0 of t+2
+//   phase 4: MFMA (D0, X1) + reads X0, D0k0 of t+1     issues D0 of t+2
+// A wave stages pixel rows wid * 8 .. + 7 of every half-tile (two 4-pixel pieces), so rowf() of its rows is a lane constant, and one pair
+// of scalar (n, ho, wo) trackers serves all four half-tiles.  Requires Wo % 4 == 0 (a piece never straddles an image row).
+// The partial tiles go to the slabs in the 128 x 128 layout of the kernel above: wgrad_reduce*_kernel is shared.
+constexpr int W8_HALF = WG_BKP * WG_ROWB;      // 16 KB
+constexpr int W8_STAGE = 4 * W8_HALF;          // 64 KB: one k-step
+constexpr int W8_LDS = 2 * W8_STAGE;           // 128 KB
+constexpr int W8_TILE = 256;
+
+template <int N>
+__device__ __forceinline__ void w8_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void w8_bar() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;     // waves 0-3 = n' half 0, waves 4-7 = n' half 1 (their SIMD partners)
+
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int co_tiles8 = (p.Cout + W8_TILE - 1) / W8_TILE, np_tiles8 = (p.NP + W8_TILE - 1) / W8_TILE;
+  const int tiles8 = co_tiles8 * np_tiles8;
+  const int split = bid / tiles8, tile = bid - split * tiles8;
+  const int CT = tile % co_tiles8, NT = tile / co_tiles8;
+  const int co0 = CT * W8_TILE, np0 = NT * W8_TILE;
+  const int mA = split * p.chunk, mB = min(p.M, mA + p.chunk);
+  if (mA >= mB) return;
+  const int mlen = mB - mA;
+
+  // ---- staging roles: a piece = 4 pixel rows x 256 B; this wave's pieces of every half-tile are rows wid * 8 + i * 4 + lrow
+  const int lrow = lane >> 4, cpos = lane & 15;
+  const int fst = lrow | ((wid & 1) << 2);                       // rowf() of the rows this lane stages
+  const int gchunk = (((cpos >> 1) ^ fst) << 1) | (cpos & 1);    // logical 16-byte chunk that lands at this lane's LDS position
+  int dyv[2][2], lc[2], ty[2], cx[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int co = co0 + (gchunk >> 2) * 64 + h * 32 + (gchunk & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dyv[h][i] = co < p.Cout ? ((wid * 8 + i * 4 + lrow) * p.lddy + co) * 2 : OOB_VOFF;
+    const int np = np0 + (gchunk >> 3) * 128 + h * 64 + (gchunk & 7) * 8;
+    const bool x_ok = np < p.NP;
+    const int t = x_ok ? (int)fdiv((unsigned)np, p.dCin) : 0;
+    const int ci = np - t * p.Cin;
+    const int kh = t / p.ks, kw = t - kh * p.ks;
+    // address = x - bias + [((n*H + ho*s)*W + wo*s) * ldx] + [((kh*W + lrow*s + kw) * ldx + ci)], bias = (pad*W + pad) * ldx
+    lc[h] = ((kh * p.W + lrow * p.stride + kw) * p.ldx + ci) * 2;
+    ty[h] = x_ok ? kh - p.pad : -(1 << 24);
+    cx[h] = lrow * p.stride + kw - p.pad;
+  }
+  const srd_t rsrc_x = make_srd(p.x - (p.pad * p.W + p.pad) * p.ldx, 0x7FFFFFF0u);
+  const srd_t rsrc_dy = make_srd(p.dy + (long long)mA * p.lddy, (unsigned)((long long)mlen * p.lddy * 2));      // rows past the range read zeros
+
+  // scalar (ho * stride, wo * stride, byte offset) of the first pixel of the wave's two pieces, advanced by 64 pixels per k-step
+  const int WoS = p.Wo * p.stride, HoS = p.Ho * p.stride;
+  const int c_ws = p.step_r * p.stride, c_hs = p.step_q * p.stride;
+  const int c_sb = (c_hs * p.W + c_ws) * p.ldx * 2;
+  const int c_row = (p.stride * p.W - WoS) * p.ldx * 2;
+  const int c_img = (p.H - HoS) * p.W * p.ldx * 2;
+  int g_hs[2], g_ws[2], g_sb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned um = (unsigned)(mA + wid * 8 + i * 4);
+    const unsigned q1 = fdiv(um, p.dWo);
+    const int wo = (int)(um - q1 * p.Wo);
+    const unsigned n = fdiv(q1, p.dHo);
+    const int ho = (int)(q1 - n * p.Ho);
+    g_hs[i] = ho * p.stride;
+    g_ws[i] = wo * p.stride;
+    g_sb[i] = (((int)n * p.H + g_hs[i]) * p.W + g_ws[i]) * p.ldx * 2;
+  }
+  struct Slot { int hs[2], ws[2], sb[2], dyoff, rem; };
+  int pf = 0;                                   // pixel offset (from mA) of the next k-step to set up
+  auto next_slot = [&]() {
+    Slot s;
+    s.rem = mlen - pf;                          // <= 0: a dead k-step stages zeros (the counted waits stay uniform)
+    s.dyoff = pf * p.lddy * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      s.hs[i] = g_hs[i];
+      s.ws[i] = g_ws[i];
+      s.sb[i] = g_sb[i];
+      g_ws[i] += c_ws;
+      g_hs[i] += c_hs;
+      g_sb[i] += c_sb;
+      if (g_ws[i] >= WoS) {
+        g_ws[i] -= WoS;
+        g_hs[i] += p.stride;
+        g_sb[i] += c_row;
+      }
+      if (g_hs[i] >= HoS) {                      // a single wrap: the host picks this kernel only when 64 pixels span at most Ho - 1 rows
+        g_hs[i] -= HoS;
+        g_sb[i] += c_img;
+      }
+    }
+    pf += WG_BKP;
+    return s;
+  };
+  auto issue_x = [&](const Slot& s, int h, int buf) {
+    char* dst = smem + buf * W8_STAGE + h * W8_HALF + (2 * wid) * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = wid * 8 + i * 4 < s.rem && (unsigned)(s.hs[i] + ty[h]) < (unsigned)p.H && (unsigned)(s.ws[i] + cx[h]) < (unsigned)p.W;
+      bufld16(rsrc_x, dst + i * 1024, ok ? lc[h] : OOB_VOFF, s.sb[i]);
+    }
+  };
+  auto issue_d = [&](const Slot& s, int h, int buf) {
+    char* dst = smem + buf * W8_STAGE + (2 + h) * W8_HALF + (2 * wid) * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bufld16(rsrc_dy, dst + i * 1024, s.rem > 0 ? dyv[h][i] + s.dyoff : OOB_VOFF, 0);
+  };
+
+  // ---- fragment read addresses: 16-lane group g covers pixels 8g..8g+7 of a 32-pixel sub-step, lane 4q+pp supplies row q, columns
+  //      4pp..4pp+3 of the 16-column block; rowf() of those rows is q | (g & 1) << 2 (immediates: + h * W8_HALF + ks * 32 rows + hh * 4 rows)
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int frd = q | ((g & 1) << 2);
+  int xrd[4], drd[2];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) xrd[jj] = (8 * g + q) * WG_ROWB + pp * 8 + (((wm * 4 + jj) ^ frd) << 5);
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) drd[ii] = 2 * W8_HALF + (8 * g + q) * WG_ROWB + pp * 8 + (((wn * 2 + ii) ^ frd) << 5);
+
+  f32x4_t acc[4][8];      // [co fragment hw * 2 + ii][n' fragment hx * 4 + jj]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+  const int ksteps = (mlen + WG_BKP - 1) / WG_BKP;
+  // ---- prologue: X0(0) D0(0) D1(0) X1(0) X0(1) D0(1), the steady-state issue order
+  Slot s1 = next_slot();
+  issue_x(s1, 0, 0);
+  issue_d(s1, 0, 0);
+  issue_d(s1, 1, 0);
+  issue_x(s1, 1, 0);
+  s1 = next_slot();
+  issue_x(s1, 0, 1);
+  issue_d(s1, 0, 1);
+  Slot s2 = next_slot();
+  w8_wait_vm<6>();
+  w8_bar();
+  if (wm == 1) w8_bar();          // the second n' half runs one barrier behind
+
+  st16x8_t xf[2][4][2], df[2][2][2];      // [half][fragment][k-substep]
+  auto rdd = [&](int h, int ks, bool nxt) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const st16x4_t v = lds_tr(smem + (nxt ? (drd[ii] ^ W8_STAGE) : drd[ii]) + h * W8_HALF + (ks * 32 + hh * 4) * WG_ROWB);
+        df[h][ii][ks][4 * hh + 0] = v[0];
+        df[h][ii][ks][4 * hh + 1] = v[1];
+        df[h][ii][ks][4 * hh + 2] = v[2];
+        df[h][ii][ks][4 * hh + 3] = v[3];
+      }
+  };
+  auto rdx = [&](int h, int ks, bool nxt) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const st16x4_t v = lds_tr(smem + (nxt ? (xrd[jj] ^ W8_STAGE) : xrd[jj]) + h * W8_HALF + (ks * 32 + hh * 4) * WG_ROWB);
+        xf[h][jj][ks][4 * hh + 0] = v[0];
+        xf[h][jj][ks][4 * hh + 1] = v[1];
+        xf[h][jj][ks][4 * hh + 2] = v[2];
+        xf[h][jj][ks][4 * hh + 3] = v[3];
+      }
+  };
+  auto mf = [&](int hd, int hx, int ks) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        acc[hd * 2 + ii][hx * 4 + jj] = MI355_MFMA_16x16x32(df[hd][ii][ks], xf[hx][jj][ks], acc[hd * 2 + ii][hx * 4 + jj]);
+  };
+#define W8_INTERLEAVE(nm, nr)                                                      \
+  do {                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < ((nr) < (nm) ? (nr) : (nm)); ++q_) {   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                          \
+    }                                                                             \
+    if constexpr ((nm) > (nr)) __builtin_amdgcn_sched_group_barrier(0x008, (nm) > (nr) ? (nm) - (nr) : 0, 0); \
+    if constexpr ((nr) > (nm)) __builtin_amdgcn_sched_group_barrier(0x100, (nr) > (nm) ? (nr) - (nm) : 0, 0); \
+  } while (0)
+
+  rdd(0, 0, false);
+  rdx(0, 0, false);
+  rdx(0, 1, false);
+  int buf = 0;
+  for (int t = 0; t < ksteps; ++t) {
+    // ---- phase 1
+    issue_d(s1, 1, buf ^ 1);
+    w8_wait_vm<8>();
+    w8_bar();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    rdd(0, 1, false);
+    rdd(1, 0, false);
+    mf(0, 0, 0);
+    W8_INTERLEAVE(8, 8);
+    rdd(1, 1, false);
+    mf(0, 0, 1);
+    W8_INTERLEAVE(8, 4);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    w8_wait_vm<6>();                // the partner half reads, right after this barrier, fragments of tiles this wave helped to stage
+    w8_bar();
+    // ---- phase 2
+    issue_x(s1, 1, buf ^ 1);
+    w8_wait_vm<8>();
+    w8_bar();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    rdx(1, 0, false);
+    mf(1, 0, 0);
+    W8_INTERLEAVE(8, 8);
+    rdx(1, 1, false);
+    mf(1, 0, 1);
+    W8_INTERLEAVE(8, 8);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    w8_wait_vm<6>();
+    w8_bar();
+    // ---- phase 3
+    issue_x(s2, 0, buf);
+    w8_wait_vm<8>();
+    w8_bar();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    mf(1, 1, 0);
+    mf(1, 1, 1);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    w8_wait_vm<6>();
+    w8_bar();
+    // ---- phase 4 (its wait publishes D0 / X0 of the next k-step: their fragments are fetched here, from the other buffer)
+    issue_d(s2, 0, buf);
+    w8_wait_vm<8>();
+    w8_bar();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    rdx(0, 0, true);
+    mf(0, 1, 0);
+    W8_INTERLEAVE(8, 8);
+    rdd(0, 0, true);
+    rdx(0, 1, true);
+    mf(0, 1, 1);
+    W8_INTERLEAVE(8, 12);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    w8_wait_vm<6>();
+    w8_bar();
+    s1 = s2;
+    s2 = next_slot();
+    buf ^= 1;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) xrd[jj] ^= W8_STAGE;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) drd[ii] ^= W8_STAGE;
+  }
+#undef W8_INTERLEAVE
+  if (wm == 0) w8_bar();          // re-align the two halves
+  w8_wait_vm<0>();                // the zero-fill pieces of the dead k-steps
+
+  // D[row = co][col = n']: lane holds rows fq*4+r, column fr of every 16 x 16 fragment
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nt128 = NT * 2 + wm;                                   // the wave's 128 n' columns are one 128-tile of the slab layout
+  if (nt128 >= p.np_tiles) return;
+  if (p.slab) {
+    const int tiles = p.co_tiles * p.np_tiles;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int col = wn * 64 + (a >> 1) * 32 + (a & 1) * 16;      // co offset of fragment a inside the 256-tile
+      const int ct128 = CT * 2 + (col >> 7);
+      if (ct128 >= p.co_tiles) continue;
+      float* dst = p.slab + ((size_t)split * tiles + (size_t)nt128 * p.co_tiles + ct128) * (WG_TILE * WG_TILE);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) dst[((col & 127) + fq * 4 + r) * WG_TILE + (b >> 2) * 64 + (b & 3) * 16 + fr] = acc[a][b][r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + wn * 64 + (a >> 1) * 32 + (a & 1) * 16 + fq * 4 + r;
+      if (co >= p.Cout) continue;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int np = np0 + wm * 128 + (b >> 2) * 64 + (b & 3) * 16 + fr;
+        if (np < p.NP) p.dw[(long long)co * p.NP + np] += acc[a][b][r];      // single split: this workgroup owns the tile
+      }
+    }
+}
+
 // dW[co][np] += sum_split slab[split][tile(co,np)][...]   (float4 per thread, coalesced over np).
 // blockIdx.y strides over groups of 8 splits (8 independent loads in flight per lane); a single group adds
 // into dW directly (deterministic), several groups combine with a few fp32 atomics.
@@ -596,8 +923,10 @@ int choose_splits(int tiles, int M, double out_bytes) {
   return sp;
 }
 
-TuneMap& g_wgrad_tuned = tune_table(TUNE_WGRAD);   // shape key -> split count found by mi355det_conv_autotune (part of the tune record)
+// shape key -> split count found by mi355det_conv_autotune (part of the tune record); + WG_FORM8 = the 256 x 256 phase-staggered kernel
+TuneMap& g_wgrad_tuned = tune_table(TUNE_WGRAD);
 int g_wgrad_force = 0;
+constexpr int WG_FORM8 = 1 << 16;
 
 unsigned long long wgrad_key(const mi355det_conv_shape* s) {
   unsigned long long k = (unsigned long long)(s->n * s->ho * s->wo);
@@ -620,6 +949,14 @@ int ensure_zero_page_w() {
   if (hipMalloc(&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess) return fail(MI355DET_ELAUNCH, "%s: zero page alloc failed", "wgrad");
   g_zero_page_w = (bf16_t*)p;
   return 0;
+}
+
+// wgrad8_kernel: pieces of 4 pixels inside one image row, one wrap per 64-pixel advance, 31-bit byte offsets, whole 256-wide co tiles
+// (a narrower output would multiply zero fragments: the 128 x 128 kernel is the better tile there)
+bool wgrad8_applicable(const mi355det_conv_shape* s) {
+  const long long NP = (long long)s->ksize * s->ksize * s->cin;
+  if (s->wo % 4 != 0 || WG_BKP / s->wo + 1 > s->ho || s->cout % 256 != 0 || NP < 256 || s->cin % 8 != 0) return false;
+  return ((long long)s->n * s->h * s->w + (long long)s->pad * (s->w + 1)) * s->in_ld * 2 < 0x7FFFFFF0ll;
 }
 
 }  // namespace
@@ -680,6 +1017,40 @@ int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, co
       best = sp;
     }
   }
+  // the phase-staggered 256 x 256 form: one or two whole rounds of one-workgroup-per-CU launches
+  int best8 = -1;
+  float best8_ms = 1e30f;
+  if (wgrad8_applicable(s)) {
+    const int t8 = (int)(((s->cout + 255) / 256) * ((s->ksize * s->ksize * s->cin + 255) / 256));
+    int c8[4] = {256 / t8, 512 / t8, 128 / t8, 768 / t8};
+    for (int a = 0; a < 4; ++a) {
+      const int sp = c8[a];
+      bool dup = sp < 1;
+      for (int b = 0; b < a; ++b) dup = dup || c8[b] == sp;
+      if (dup || (sp > 1 && (sp * per_split > workspace_bytes || M / sp < 512)) || !split_valid(M, sp)) continue;
+      g_wgrad_force = sp | WG_FORM8;
+      if (int e = mi355det_conv_wgrad(s, x, dy, dw, nullptr, workspace, workspace_bytes, stream)) {
+        g_wgrad_force = 0;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return e;
+      }
+      float ms = 1e30f;
+      for (int b = 0; b < 2; ++b) {
+        (void)hipEventRecord(e0, S(stream));
+        for (int r = 0; r < 3; ++r) (void)mi355det_conv_wgrad(s, x, dy, dw, nullptr, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(e1, S(stream));
+        (void)hipEventSynchronize(e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        if (t < ms) ms = t;
+      }
+      if (ms < best8_ms) {
+        best8_ms = ms;
+        best8 = sp;
+      }
+    }
+  }
   // Beside the data-gradient stream fewer, longer workgroups and less slab traffic win over the split count that is fastest alone (the step-level
   // refinement of round 4 halved the split counts of the big layers: profiles/r04_ab_results.md 7): take the SMALLEST split count within 4 % of
   // the fastest one.
@@ -688,6 +1059,7 @@ int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, co
       best = tried[i];
       break;
     }
+  if (best8 > 0 && best8_ms < best_ms * 0.97f) best = best8 | WG_FORM8;
   g_wgrad_force = 0;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
@@ -720,10 +1092,22 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   p.ablate = g_wgrad_ablate;
   const int tiles = p.co_tiles * p.np_tiles;
   int splits = choose_splits(tiles, p.M, 4.0 * p.Cout * (double)p.NP);
+  bool form8 = false;
   {
     auto it = g_wgrad_tuned.find(wgrad_key(s));
-    if (it != g_wgrad_tuned.end()) splits = it->second;
-    if (g_wgrad_force > 0 && split_valid(p.M, g_wgrad_force)) splits = g_wgrad_force;
+    if (it != g_wgrad_tuned.end()) {
+      splits = it->second & (WG_FORM8 - 1);
+      form8 = (it->second & WG_FORM8) != 0;
+    }
+    const int force = g_wgrad_force > 0 ? g_wgrad_force : g_wgrad_force_dbg;
+    if (force > 0 && split_valid(p.M, force & (WG_FORM8 - 1))) {
+      splits = force & (WG_FORM8 - 1);
+      form8 = (force & WG_FORM8) != 0;
+    }
+    if (splits < 1) splits = 1;
+    if (g_wgrad_force <= 0 && (g_wgrad_force_dbg & WG_FORM8) && !(form8 && wgrad8_applicable(s)))      // the diagnostic switch must not fall back silently
+      return fail(MI355DET_EINVAL, "%s: the phase-staggered kernel was forced (debug key 7) for a shape or split count it does not take", "conv_wgrad");
+    form8 = form8 && wgrad8_applicable(s);      // (a record written for another build: fall back to the 128 x 128 kernel, same split count)
     const size_t per_split = (size_t)tiles * WG_TILE * WG_TILE * sizeof(float);
     while (splits > 1 && (splits * per_split > workspace_bytes || !split_valid(p.M, splits))) --splits;
   }
@@ -762,6 +1146,12 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   const bool fits =
                     ((long long)s->n * p.H * p.W + (long long)p.pad * (p.W + 1)) * p.ldx * 2 < 0x7FFFFFF0ll &&
                     (long long)chunk * p.lddy * 2 < 0x7FFFFFF0ll;
+  if (form8 && fits) {
+    const int tiles8 = ((p.Cout + W8_TILE - 1) / W8_TILE) * ((p.NP + W8_TILE - 1) / W8_TILE);
+    static DeviceOnce attr8;
+    attr8.once([&] { (void)hipFuncSetAttribute((const void*)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS); });
+    hipLaunchKernelGGL(wgrad8_kernel, dim3(tiles8 * splits), dim3(512), W8_LDS, S(stream), p);
+  } else
 #define WG_GO(a, b) (!fits || grp4 == 0 ? go(wgrad_kernel<a, b, 0>) : grp4 == 1 ? go(wgrad_kernel<a, b, 1>) : grp4 == 2 ? go(wgrad_kernel<a, b, 2>) : go(wgrad_kernel<a, b, 3>))
   switch (ci * 8 + cj) {
     case 1 * 8 + 1: WG_GO(1, 1); break;

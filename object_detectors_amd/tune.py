@@ -147,7 +147,23 @@ def plan_build(build, group=None, share=None):
 
 # ---- step-level refinement ------------------------------------------------------------------------------------------------------------
 IGEMM_CANDIDATES = (1, 2, 3, 4, 5, 6, 15, 16, 17, 18, 19, 26, 27, 28, 40, 44, 45)      # conv_kernels.hip:autotune_igemm cands[]
+WGRAD_FORM8 = 1 << 16
 _NARROW = {0: (29, 30, 31), 29: (0,), 30: (0,), 31: (0,)}
+
+
+def wgrad_key_fields(key):
+    """(pixels n*ho*wo, cout, cin, ksize, stride, fp16 storage) of a weight-gradient key (csrc/wgrad_kernels.hip: wgrad_key)."""
+    f16, key = key % 2, key // 2
+    ks, key = key % 17, key // 17
+    cin, key = key % 4099, key // 4099
+    cout, m = key % 4099, key // 4099
+    return m, cout, cin, ks // 4, ks % 4, bool(f16)
+
+
+def wgrad_split_valid(m, sp):
+    """csrc/wgrad_kernels.hip: split_valid - the pixel axis is cut into `sp` chunks of whole 64-pixel k-steps, none of them empty."""
+    chunk = ((m + sp - 1) // sp + 63) // 64 * 64
+    return sp >= 1 and (m + chunk - 1) // chunk == sp
 
 
 def _alternatives(table, v):
@@ -155,11 +171,20 @@ def _alternatives(table, v):
         return _NARROW[v] if v in _NARROW else tuple(c for c in IGEMM_CANDIDATES if c != v)
     if table == "s2cat":
         return (1 - v,)
+    # weight gradient: split count, + WGRAD_FORM8 = the 256 x 256 phase-staggered kernel (csrc/wgrad_kernels.hip: WG_FORM8; the library falls
+    # back to the 128 x 128 kernel for shapes the other one does not take, and to the nearest valid split count)
+    form, sp = v & WGRAD_FORM8, v & (WGRAD_FORM8 - 1)
     out = []
     for f in (0.5, 0.67, 0.8, 1.25, 1.5, 2.0):
-        w = max(1, int(round(v * f)))
-        if w != v and w not in out:
-            out.append(w)
+        w = max(1, int(round(sp * f)))
+        if w != sp and (w | form) not in out:
+            out.append(w | form)
+    if form:
+        out.append(sp)
+    else:      # (a wasted trial where the library falls back: same kernel, same time)
+        for w in (sp | WGRAD_FORM8, max(1, sp // 2) | WGRAD_FORM8):
+            if w not in out:
+                out.append(w)
     return tuple(out)
 
 

@@ -769,6 +769,9 @@ class Plan:
                                                                pixels, SLOPE, _vp(dzb), shp.cout, _vp(eng.grads[b + ".weight"]),
                                                                _vp(eng.grads[b + ".bias"]), self.stream)))
                 # (measured and removed: the weight gradients of the large maps serial on the main stream - no gain, profiles/r03_ab_results.md)
+                # (measured and removed, round 4: the weight gradient started only when its layer's data gradient has finished, so that it runs beside
+                #  the next BatchNorm passes instead of beside the data gradient: 28.17 -> 29.85 ms, profiles/r04_ab_results.md 8 - the two GEMMs
+                #  side by side fill each other's tails; serialised they do not)
                 ev_dz, ev_wg = torch.cuda.Event(), torch.cuda.Event()
                 py(ev_dz.record, main)
                 py(self.side.wait_event, ev_dz)

@@ -484,6 +484,43 @@ def test_wgrad_scalar_bookkeeping_form_is_bit_identical(case):
     assert (got - wz.grad).abs().max().item() < 1e-2 * wz.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(2, 40, 40, 128, 256, 3, 1, 128, 256, (1, 3, 10)),      # NP = 1152: the fifth 256-wide n' tile is half empty
+                                  (3, 20, 20, 256, 512, 3, 1, 256, 512, (1, 2, 5)),         # map width 20: the two 4-pixel pieces of a wave lie in different rows
+                                  (2, 24, 16, 64, 256, 3, 2, 72, 264, (1, 2)),              # stride 2, Cin = 64 (four taps per 256 n' columns), pitch padding
+                                  (3, 20, 12, 512, 256, 1, 1, 512, 256, (1, 4)),            # 1x1; M = 720: the last k-step has 16 live pixels
+                                  (1, 12, 12, 256, 256, 3, 1, 256, 256, (1,)),              # one workgroup per tile walks all the pixels (direct += epilogue)
+                                  (2, 16, 32, 32, 256, 3, 1, 32, 256, (1, 2))])             # Cin = 32: NP = 288, taps change inside a 64-column half
+def test_wgrad_phase_staggered_kernel_is_bit_identical(case):
+    """wgrad8_kernel (256 x 256 x 64, the igemm8 schedule on transposed operands) adds the same products in the same order as the 128 x 128
+    kernel for the same split count: bit-identical dW for every split count, and equal to autograd within the storage rounding."""
+    from object_detectors_amd import ops
+    from object_detectors_amd._lib import lib
+    n, h, w, cin, cout, k, s, ldx, lddy, split_counts = case
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s, in_ld=ldx, out_ld=lddy)
+    x = nhwc(rnd((n, cin, h, w), 31), ldx)
+    gy = nhwc(rnd((n, cout, shape.ho, shape.wo), 32), lddy)
+    x[..., cin:] = 7.0
+    gy[..., cout:] = 7.0
+    ref = None
+    try:
+        for sp in split_counts:
+            outs = []
+            for form in (0, 65536):
+                lib().mi355det_debug_set(7, sp + form)
+                dw = torch.full((cout, k * k * cin), 0.25, device=dev())      # the kernel ADDS into dW
+                ops.conv_wgrad(shape, x, gy, dw)
+                outs.append(dw.cpu())
+            assert torch.equal(outs[0], outs[1]), sp
+            ref = outs[1]
+    finally:
+        lib().mi355det_debug_set(7, 0)
+    wz = torch.zeros(cout, cin, k, k, requires_grad=True)
+    y = torch.nn.functional.conv2d(x[..., :cin].float().permute(0, 3, 1, 2).cpu(), wz, stride=s, padding=(k - 1) // 2)
+    y.backward(gy[..., :cout].float().permute(0, 3, 1, 2).cpu())
+    got = (ref - 0.25).view(cout, k, k, cin).permute(0, 3, 1, 2)
+    assert (got - wz.grad).abs().max().item() < 1e-2 * wz.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("case", [(2, 8, 128, 32, 64, 32, 64, False), (1, 6, 64, 32, 64, 40, 64, True), (2, 4, 64, 64, 64, 64, 64, True),
                                   (1, 10, 256, 64, 64, 64, 72, False), (3, 4, 128, 32, 64, 32, 80, True), (2, 4, 64, 64, 128, 64, 128, True)])
 def test_stride2_dgrad_single_launch_matches_class_launches(case):

@@ -128,7 +128,9 @@ def test_refinement_candidates():
     assert tune._alternatives("s2cat", 1) == (0,) and tune._alternatives("s2cat", 0) == (1,)
     alt = tune._alternatives("wgrad", 48)
     assert 24 in alt and 96 in alt and 48 not in alt and all(a >= 1 for a in alt)
-    assert tune._alternatives("wgrad", 1) == (2,)
+    assert tune._alternatives("wgrad", 1) == (2, tune.WGRAD_FORM8 + 1)
+    alt8 = tune._alternatives("wgrad", tune.WGRAD_FORM8 + 14)      # the 256 x 256 weight-gradient kernel: its own split counts, and the other kernel
+    assert tune.WGRAD_FORM8 + 7 in alt8 and tune.WGRAD_FORM8 + 28 in alt8 and 14 in alt8 and tune.WGRAD_FORM8 + 14 not in alt8
 
 
 def test_refine_step_on_a_cost_model(tmp_path):

@@ -33,3 +33,23 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
         msg += f"  [abl {a}] {t:6.1f}us {fl / t / 1e6:5.0f}TF |"
     L.mi355det_debug_set(6, 0)
     print(msg, flush=True)
+    # the 256 x 256 phase-staggered kernel (forced through debug key 7: split + 65536) against the 128 x 128 kernel at the same split counts
+    if cout % 256 == 0 and k * k * cin >= 256 and shape.wo % 4 == 0:
+        t8 = (cout // 256) * ((k * k * cin + 255) // 256)
+        msg = "      form8 / form128 by splits:"
+        M = n * shape.ho * shape.wo
+        def valid(sp):      # csrc/wgrad_kernels.hip: split_valid (chunks are whole 64-pixel k-steps)
+            chunk = ((M + sp - 1) // sp + 63) // 64 * 64
+            return (M + chunk - 1) // chunk == sp
+        def near(sp):
+            while sp > 1 and not valid(sp):
+                sp -= 1
+            return max(1, sp)
+        for spc in sorted({near(128 // t8), near(256 // t8), near(512 // t8), near(768 // t8)}):
+            ts = []
+            for form in (65536, 0):
+                L.mi355det_debug_set(7, spc + form)
+                ts.append(min(timeit(lambda: ops.conv_wgrad(shape, x, dy, dw, workspace=ws)) for _ in range(3)))
+            msg += f"  sp {spc:3d}: {ts[0]:6.1f} / {ts[1]:6.1f} us ({fl / ts[0] / 1e6:4.0f} TF)"
+        L.mi355det_debug_set(7, 0)
+        print(msg, flush=True)
