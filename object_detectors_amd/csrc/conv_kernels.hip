@@ -28,6 +28,7 @@ using namespace mi355;
 
 extern int g_wgrad_general;
 extern int g_wgrad_force_dbg;
+extern int g_wgrad8_off;
 extern int g_wgrad_ablate;   // wgrad_kernels.hip
 extern int g_dgrad_s2_off;     // dgrad_s2_kernels.hip
 int mi355det_internal_dgrad_s2(const mi355det_conv_shape* s, const void* dy, const void* wt, void* dx, const void* residual, int32_t residual_ld,
@@ -1146,6 +1147,7 @@ int mi355det_debug_set(int key, int value) {
   if (key == 1) g_wgrad_general = value;
   if (key == 2) g_dgrad_s2_off = value;
   if (key == 3) igemm8_set_dbg_mode(value);      // 1 = phase stamps, 2 = k-step starts only (tools/prof_ig8.py)
+  if (key == 8) g_wgrad8_off = value;            // 1 = the weight-gradient tuner leaves the 256 x 256 phase-staggered kernel out (A/B)
   if (key == 7) g_wgrad_force_dbg = value;       // weight gradient: split count (+ 65536 = the 256 x 256 phase-staggered kernel) for every launch, 0 = tuned
   if (key == 6) g_wgrad_ablate = value;          // weight-gradient ablation builds (timing only): wgrad_kernels.hip
   if (key == 5) g_s2cat_force = value;           // stride-2 data gradient: 1 = class-concatenated form, 0 = four class launches, -1 = tuned choice

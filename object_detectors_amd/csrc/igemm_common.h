@@ -226,7 +226,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
   }
   if (!consumer) return;
   if (EPI == EPI_F32) {
-    // head conv_out: fp32 + bias, 255 channels (tiny layers): direct stores from the accumulator layout
+    // head conv_out: fp32 + bias straight from the accumulator layout: a lane holds 4 consecutive channels of one pixel = one 16-byte store
+    // where the group lies inside the real channels and the address is aligned (every group but the last of a 255-channel YOLO head, whose
+    // rows have a 256-float pitch); the scalar form - 4-byte pieces scattered over 16 rows per instruction - wrote the 209 MB of the 80 x 80
+    // head at 1.9 TB/s including the reads.  Per-channel scale / shift are fetched once per channel group, not per pixel.
+    float e_sc[TN][4], e_sh[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = n0 + wn * (TN * 16) + i * 16 + fq * 4 + r;
+        e_sc[i][r] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
+        e_sh[i][r] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
+      }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int m = m0 + wbase + j * 16 + fr;
@@ -241,16 +253,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4_t (&a
         const int co = n0 + wn * (TN * 16) + i * 16 + fq * 4;
         if (co >= p.Cout) continue;
         float* o = orow + co;
+        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (co + r < p.Cout) {
-            float v = acc[i][j][r];
-            if (p.scale) v *= p.scale[co + r];
-            if (p.bias) v += p.bias[co + r];
-            if (p.relu == 1) v = fmaxf(v, 0.f);
-            else if (p.relu == 2) v = v > 0.f ? v : v * p.slope;
-            o[r] = v;
-          }
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] * e_sc[i][r] + e_sh[i][r];
+          if (p.relu == 1) v[r] = fmaxf(v[r], 0.f);
+          else if (p.relu == 2) v[r] = v[r] > 0.f ? v[r] : v[r] * p.slope;
+        }
+        if (co + 3 < p.Cout && (((unsigned long long)o) & 15ull) == 0) {
+          *(f32x4_t*)o = f32x4_t{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (co + r < p.Cout) o[r] = v[r];
+        }
       }
     }
     return;

@@ -56,6 +56,7 @@ struct WgradParams {
 int g_wgrad_ablate = 0;    // diagnostic (mi355det_debug_set(6, v)): WgradParams::ablate
 int g_wgrad_general = 0;   // diagnostic (mi355det_debug_set(1, v)): 1 = always the per-lane bookkeeping form (tests compare the two)
 int g_wgrad_force_dbg = 0; // diagnostic (mi355det_debug_set(7, v)): split count (+ 65536: the 256 x 256 phase-staggered kernel) for every launch; 0 = tuned
+int g_wgrad8_off = 0;      // diagnostic (mi355det_debug_set(8, v)): 1 = the tuner does not time the 256 x 256 phase-staggered kernel (same-box A/B of the two kernels)
 
 namespace {
 
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 //   phase 3: MFMA (D1, X1)                             issues X0 of t+2
 //   phase 4: MFMA (D0, X1) + reads X0, D0k0 of t+1     issues D0 of t+2
 // A wave stages pixel rows wid * 8 .. + 7 of every half-tile (two 4-pixel pieces), so rowf() of its rows is a lane constant, and one pair
-// of scalar (n, ho, wo) trackers serves all four half-tiles.  Requires Wo % 4 == 0 (a piece never straddles an image row).
+// of scalar (n, ho, wo) trackers serves all four half-tiles.  STRADDLE = false requires Wo % 4 == 0 (a piece never crosses a row end).
 // The partial tiles go to the slabs in the 128 x 128 layout of the kernel above: wgrad_reduce*_kernel is shared.
 constexpr int W8_HALF = WG_BKP * WG_ROWB;      // 16 KB
 constexpr int W8_STAGE = 4 * W8_HALF;          // 64 KB: one k-step
@@ -408,6 +409,7 @@ __device__ __forceinline__ void w8_bar() {
   asm volatile("" ::: "memory");
 }
 
+template <bool STRADDLE>      // true: map widths that are not multiples of 4 - a 4-pixel piece may cross a row end (per-lane select of the next row's scalars)
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -500,8 +502,21 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradParams p) {
     char* dst = smem + buf * W8_STAGE + h * W8_HALF + (2 * wid) * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const bool ok = wid * 8 + i * 4 < s.rem && (unsigned)(s.hs[i] + ty[h]) < (unsigned)p.H && (unsigned)(s.ws[i] + cx[h]) < (unsigned)p.W;
-      bufld16(rsrc_x, dst + i * 1024, ok ? lc[h] : OOB_VOFF, s.sb[i]);
+      const int row0 = wid * 8 + i * 4;
+      if (!STRADDLE || (s.ws[i] + 4 * p.stride <= WoS && row0 + 4 <= s.rem) || row0 >= s.rem) {      // wave-uniform: the piece lies in one image row (or is dead)
+        const bool ok = row0 < s.rem && (unsigned)(s.hs[i] + ty[h]) < (unsigned)p.H && (unsigned)(s.ws[i] + cx[h]) < (unsigned)p.W;
+        bufld16(rsrc_x, dst + i * 1024, ok ? lc[h] : OOB_VOFF, s.sb[i]);
+      } else {
+        // the piece crosses a row end or the end of the pixel range: lanes past the row end move to the next row / image by a scalar byte delta
+        const bool last_row = s.hs[i] + p.stride == HoS;
+        const int hs1 = last_row ? 0 : s.hs[i] + p.stride;
+        const int ex1 = c_row + (last_row ? c_img : 0);
+        const bool wr = s.ws[i] + lrow * p.stride >= WoS;
+        const int iy = (wr ? hs1 : s.hs[i]) + ty[h];
+        const int ix = s.ws[i] + cx[h] - (wr ? WoS : 0);
+        const bool ok = row0 + lrow < s.rem && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        bufld16(rsrc_x, dst + i * 1024, ok ? lc[h] + (wr ? ex1 : 0) : OOB_VOFF, s.sb[i]);
+      }
     }
   };
   auto issue_d = [&](const Slot& s, int h, int buf) {
@@ -951,11 +966,12 @@ int ensure_zero_page_w() {
   return 0;
 }
 
-// wgrad8_kernel: pieces of 4 pixels inside one image row, one wrap per 64-pixel advance, 31-bit byte offsets, whole 256-wide co tiles
-// (a narrower output would multiply zero fragments: the 128 x 128 kernel is the better tile there)
+// wgrad8_kernel: pieces of 4 pixels spanning at most two image rows, one wrap per 64-pixel advance, 31-bit byte offsets, at least one whole 256-wide
+// tile in both directions (a narrower output would multiply zero fragments: the 128 x 128 kernel is the better tile there; the last co tile
+// of a wide output may be partial - the 10 836 channels of the 1204-class cls_logits are 42.3 tiles)
 bool wgrad8_applicable(const mi355det_conv_shape* s) {
   const long long NP = (long long)s->ksize * s->ksize * s->cin;
-  if (s->wo % 4 != 0 || WG_BKP / s->wo + 1 > s->ho || s->cout % 256 != 0 || NP < 256 || s->cin % 8 != 0) return false;
+  if (s->wo < 4 || WG_BKP / s->wo + 1 > s->ho || s->cout < 256 || NP < 256 || s->cin % 8 != 0) return false;
   return ((long long)s->n * s->h * s->w + (long long)s->pad * (s->w + 1)) * s->in_ld * 2 < 0x7FFFFFF0ll;
 }
 
@@ -965,11 +981,12 @@ extern "C" {
 
 size_t mi355det_conv_wgrad_workspace(const mi355det_conv_shape* s) {
   if (!s) return 0;
-  // room for the largest split count the autotuner may pick (capped at 128 MiB)
+  // room for the largest split count the autotuner may pick: capped at 128 MiB, but never below three splits (the 1204-class cls_logits has
+  // 100 MB of dW: its 387 tiles of 256 x 256 are 1.5 rounds of 256 CUs with one pixel range and 3.0 with two)
   const size_t tiles = (size_t)((s->cout + WG_TILE - 1) / WG_TILE) * (size_t)((s->ksize * s->ksize * s->cin + WG_TILE - 1) / WG_TILE);
   const size_t per_split = tiles * WG_TILE * WG_TILE * sizeof(float);
   size_t splits = 1024;
-  while (splits > 1 && splits * per_split > ((size_t)128 << 20)) --splits;
+  while (splits > 3 && splits * per_split > ((size_t)128 << 20)) --splits;
   return splits * per_split;
 }
 
@@ -1020,10 +1037,10 @@ int mi355det_conv_wgrad_autotune(const mi355det_conv_shape* s, const void* x, co
   // the phase-staggered 256 x 256 form: one or two whole rounds of one-workgroup-per-CU launches
   int best8 = -1;
   float best8_ms = 1e30f;
-  if (wgrad8_applicable(s)) {
+  if (wgrad8_applicable(s) && !g_wgrad8_off) {
     const int t8 = (int)(((s->cout + 255) / 256) * ((s->ksize * s->ksize * s->cin + 255) / 256));
-    int c8[4] = {256 / t8, 512 / t8, 128 / t8, 768 / t8};
-    for (int a = 0; a < 4; ++a) {
+    int c8[7] = {256 / t8, 512 / t8, 128 / t8, 768 / t8, 1, 2, 3};
+    for (int a = 0; a < 7; ++a) {
       const int sp = c8[a];
       bool dup = sp < 1;
       for (int b = 0; b < a; ++b) dup = dup || c8[b] == sp;
@@ -1149,8 +1166,12 @@ int mi355det_conv_wgrad(const mi355det_conv_shape* s, const void* x, const void*
   if (form8 && fits) {
     const int tiles8 = ((p.Cout + W8_TILE - 1) / W8_TILE) * ((p.NP + W8_TILE - 1) / W8_TILE);
     static DeviceOnce attr8;
-    attr8.once([&] { (void)hipFuncSetAttribute((const void*)wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS); });
-    hipLaunchKernelGGL(wgrad8_kernel, dim3(tiles8 * splits), dim3(512), W8_LDS, S(stream), p);
+    attr8.once([&] {
+      (void)hipFuncSetAttribute((const void*)wgrad8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+      (void)hipFuncSetAttribute((const void*)wgrad8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+    });
+    if (p.Wo % 4 == 0 && p.M % 4 == 0) hipLaunchKernelGGL(wgrad8_kernel<false>, dim3(tiles8 * splits), dim3(512), W8_LDS, S(stream), p);
+    else hipLaunchKernelGGL(wgrad8_kernel<true>, dim3(tiles8 * splits), dim3(512), W8_LDS, S(stream), p);
   } else
 #define WG_GO(a, b) (!fits || grp4 == 0 ? go(wgrad_kernel<a, b, 0>) : grp4 == 1 ? go(wgrad_kernel<a, b, 1>) : grp4 == 2 ? go(wgrad_kernel<a, b, 2>) : go(wgrad_kernel<a, b, 3>))
   switch (ci * 8 + cj) {

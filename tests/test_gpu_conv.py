@@ -489,7 +489,12 @@ def test_wgrad_scalar_bookkeeping_form_is_bit_identical(case):
                                   (2, 24, 16, 64, 256, 3, 2, 72, 264, (1, 2)),              # stride 2, Cin = 64 (four taps per 256 n' columns), pitch padding
                                   (3, 20, 12, 512, 256, 1, 1, 512, 256, (1, 4)),            # 1x1; M = 720: the last k-step has 16 live pixels
                                   (1, 12, 12, 256, 256, 3, 1, 256, 256, (1,)),              # one workgroup per tile walks all the pixels (direct += epilogue)
-                                  (2, 16, 32, 32, 256, 3, 1, 32, 256, (1, 2))])             # Cin = 32: NP = 288, taps change inside a 64-column half
+                                  (2, 16, 32, 32, 256, 3, 1, 32, 256, (1, 2)),              # Cin = 32: NP = 288, taps change inside a 64-column half
+                                  (2, 16, 16, 64, 324, 3, 1, 64, 336, (1, 2)),              # partial last co tile, Cout % 8 = 4 (the 10 836-channel cls_logits)
+                                  (2, 50, 50, 64, 256, 3, 1, 64, 256, (1, 3, 7)),           # map width 50: pieces cross row ends (the per-lane select form)
+                                  (3, 13, 13, 128, 256, 3, 1, 128, 256, (1, 2)),            # 507 pixels: not a multiple of 4, the last piece is partial
+                                  (2, 26, 26, 64, 256, 3, 2, 64, 256, (1, 2)),              # stride 2 onto a 13 x 13 map
+                                  (1, 25, 25, 256, 512, 1, 1, 256, 512, (1, 2))])           # 1x1 on a 25 x 25 map
 def test_wgrad_phase_staggered_kernel_is_bit_identical(case):
     """wgrad8_kernel (256 x 256 x 64, the igemm8 schedule on transposed operands) adds the same products in the same order as the 128 x 128
     kernel for the same split count: bit-identical dW for every split count, and equal to autograd within the storage rounding."""

@@ -24,7 +24,11 @@ def main():
                     "object_detectors_amd/tune_records/fasterrcnn_resnet50_bs<batch>_<px>.json when it exists (tune.refine_step)")
     ap.add_argument("--refine", default=None, metavar="OUT.json", help="refine the record on the whole training step (tune.refine_step) and write it there")
     ap.add_argument("--refine-budget-s", type=float, default=600.0)
+    ap.add_argument("--no-wgrad8", action="store_true", help="A/B: the weight-gradient tuner leaves the 256 x 256 phase-staggered kernel out (debug key 8)")
     args = ap.parse_args()
+    if args.no_wgrad8:
+        from object_detectors_amd._lib import lib
+        lib().mi355det_debug_set(8, 1)
     from object_detectors_amd import tune
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rec = args.tune_record

@@ -28,7 +28,11 @@ def main():
     ap.add_argument("--refine-min-gain-us", type=float, default=40.0, help="a change is kept only if the step gets faster by more than this (long steps are noisier: "
                     "the first R101-LVIS record, refined with 40 us on a 40 ms step, was 1 %% SLOWER than no record on another box)")
     ap.add_argument("--refine-steps", type=int, default=4)
+    ap.add_argument("--no-wgrad8", action="store_true", help="A/B: the weight-gradient tuner leaves the 256 x 256 phase-staggered kernel out (debug key 8)")
     args = ap.parse_args()
+    if args.no_wgrad8:
+        from object_detectors_amd._lib import lib
+        lib().mi355det_debug_set(8, 1)
     from object_detectors_amd import tune
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rec = args.tune_record

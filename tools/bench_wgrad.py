@@ -8,6 +8,9 @@ import ctypes as C
 dev = torch.device('cuda:0')
 SHAPES = [(32, 80, 80, 128, 256, 3, 1), (32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (32, 40, 40, 512, 256, 1, 1),
           (32, 80, 80, 256, 128, 1, 1), (32, 160, 160, 64, 128, 3, 1), (32, 320, 320, 32, 64, 3, 1)]
+if "retina" in sys.argv[1:]:      # RetinaNet-R101-LVIS bs 8 @800: cls_logits (10 836 channels, pitch 10 880) and a tower convolution on the 100 x 100 level
+    SHAPES = [(8, 100, 100, 256, 10836, 3, 1), (8, 100, 100, 256, 256, 3, 1), (16, 100, 100, 256, 819, 3, 1)]
+    sys.argv.remove("retina")
 abl = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4]
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
@@ -18,9 +21,10 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 L = lib()
 for (n, h, w, cin, cout, k, s) in SHAPES:
-    shape = ops.conv_shape(n, h, w, cin, cout, k, s)
+    ld = (cout + 63) // 64 * 64
+    shape = ops.conv_shape(n, h, w, cin, cout, k, s, out_ld=ld)
     x = torch.randn(n, h, w, cin, device=dev).bfloat16()
-    dy = torch.randn(n, shape.ho, shape.wo, cout, device=dev).bfloat16()
+    dy = torch.randn(n, shape.ho, shape.wo, ld, device=dev).bfloat16()
     dw = torch.zeros(cout, k * k * cin, device=dev)
     need = L.mi355det_conv_wgrad_workspace(C.byref(shape))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
@@ -34,8 +38,8 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
     L.mi355det_debug_set(6, 0)
     print(msg, flush=True)
     # the 256 x 256 phase-staggered kernel (forced through debug key 7: split + 65536) against the 128 x 128 kernel at the same split counts
-    if cout % 256 == 0 and k * k * cin >= 256 and shape.wo % 4 == 0:
-        t8 = (cout // 256) * ((k * k * cin + 255) // 256)
+    if cout >= 256 and k * k * cin >= 256 and shape.wo % 4 == 0:
+        t8 = ((cout + 255) // 256) * ((k * k * cin + 255) // 256)
         msg = "      form8 / form128 by splits:"
         M = n * shape.ho * shape.wo
         def valid(sp):      # csrc/wgrad_kernels.hip: split_valid (chunks are whole 64-pixel k-steps)
@@ -45,7 +49,7 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
             while sp > 1 and not valid(sp):
                 sp -= 1
             return max(1, sp)
-        for spc in sorted({near(128 // t8), near(256 // t8), near(512 // t8), near(768 // t8)}):
+        for spc in sorted({near(128 // t8), near(256 // t8), near(512 // t8), near(768 // t8)} | ({1, 2, 3} if t8 > 128 else set())):
             ts = []
             for form in (65536, 0):
                 L.mi355det_debug_set(7, spc + form)

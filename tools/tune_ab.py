@@ -27,8 +27,8 @@ for t, k, v in ents:
     if a.wgrad8:
         if t == "wgrad":
             m, cout, cin, ks, stride, _ = tune.wgrad_key_fields(k)
-            if ks == 3 and cout % 256 == 0 and cout >= a.wgrad8:
-                t8 = (cout // 256) * ((9 * cin + 255) // 256)
+            if ks == 3 and cout >= max(256, a.wgrad8):
+                t8 = ((cout + 255) // 256) * ((9 * cin + 255) // 256)
                 sp = max(1, a.rounds // t8)
                 while sp > 1 and not tune.wgrad_split_valid(m, sp):
                     sp -= 1
