@@ -36,7 +36,10 @@ extern "C" {
 
 const char* mi355det_last_error(void);
 int mi355det_debug_set(int key, int value);   /* bring-up / test knobs: key 0 = force a conv tile configuration (0 = tuned), 1 = weight gradient
-                                                 with per-lane bookkeeping, 2 = stride-2 data gradient as four class launches (tests compare the forms) */
+                                                 with per-lane bookkeeping, 2 = stride-2 data gradient as four class launches (tests compare the forms),
+                                                 3 = diagnostic build of the phase-staggered conv, 5 = stride-2 data-gradient form, 6 = weight-gradient
+                                                 ablations (timing only), 7 = weight-gradient split count for every launch (+ 65536: the 256 x 256
+                                                 phase-staggered kernel; fails for shapes it does not take), 8 = 1: the tuner leaves that kernel out */
 int mi355det_debug_ptr(int key, void* ptr);   /* key 0 = device buffer for the diagnostic (phase-stamp) conv build */
 int mi355det_version(void);
 

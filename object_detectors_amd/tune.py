@@ -202,6 +202,8 @@ def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budge
 
     `min_gain_us` has to sit above the run-to-run spread of `steps` steps: 40 us is right for the 28 ms YOLO step; the 40 ms RetinaNet-R101-LVIS
     step refined with 40 us collected 53 "improvements" that were 1 % SLOWER than no record on another box (150 us: profiles/r04_ab_results.md §7).
+    `step` has to be STATIONARY (learning rate 0): a sweep runs thousands of steps on one batch, a model that diverges meanwhile runs on NaN operands,
+    and those steps are faster (RetinaNet-R101-LVIS: 33.3 against 36 ms) - two records of round 4 were refined on such a model and withdrawn.
     `timer(step, steps) -> us per step` replaces the device-synchronised wall clock (tests/test_tune_record.py drives the search on a cost model)."""
     import time
 

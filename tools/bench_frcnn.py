@@ -75,8 +75,16 @@ def main():
     torch.cuda.synchronize()
     if args.refine:
         os.makedirs(os.path.dirname(os.path.abspath(args.refine)), exist_ok=True)
+        # learning rate 0 while refining (see tools/bench_retina.py: a model that diverges on one repeated batch changes the timing)
+        lr0 = opt.param_groups[0]["lr"]
+        opt.param_groups[0]["lr"] = 0.0
+        for gq in opt_head.param_groups:
+            gq["lr"] = 0.0
         a, b, kept = tune.refine_step(step, rounds=2, steps=6, min_gain_us=30.0, budget_s=args.refine_budget_s,
                                       log=lambda m: print(m, file=sys.stderr, flush=True), checkpoint=args.refine)
+        opt.param_groups[0]["lr"] = lr0
+        for gq in opt_head.param_groups:
+            gq["lr"] = lr0
         tune.save(args.refine)
         print(f"refined: {a:.0f} -> {b:.0f} us per step, {kept} entries changed", file=sys.stderr, flush=True)
     t0 = time.perf_counter()

@@ -9,7 +9,8 @@ dev = torch.device('cuda:0')
 SHAPES = [(32, 80, 80, 128, 256, 3, 1), (32, 40, 40, 256, 512, 3, 1), (32, 20, 20, 512, 1024, 3, 1), (32, 40, 40, 512, 256, 1, 1),
           (32, 80, 80, 256, 128, 1, 1), (32, 160, 160, 64, 128, 3, 1), (32, 320, 320, 32, 64, 3, 1)]
 if "retina" in sys.argv[1:]:      # RetinaNet-R101-LVIS bs 8 @800: cls_logits (10 836 channels, pitch 10 880) and a tower convolution on the 100 x 100 level
-    SHAPES = [(8, 100, 100, 256, 10836, 3, 1), (8, 100, 100, 256, 256, 3, 1), (16, 100, 100, 256, 819, 3, 1)]
+    SHAPES = [(8, 100, 100, 256, 10836, 3, 1), (8, 100, 100, 256, 256, 3, 1), (16, 100, 100, 256, 819, 3, 1),
+              (8, 50, 50, 256, 10836, 3, 1), (8, 25, 25, 256, 10836, 3, 1), (8, 50, 50, 256, 256, 3, 1)]
     sys.argv.remove("retina")
 abl = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4]
 def timeit(fn, iters=10):
@@ -38,7 +39,7 @@ for (n, h, w, cin, cout, k, s) in SHAPES:
     L.mi355det_debug_set(6, 0)
     print(msg, flush=True)
     # the 256 x 256 phase-staggered kernel (forced through debug key 7: split + 65536) against the 128 x 128 kernel at the same split counts
-    if cout >= 256 and k * k * cin >= 256 and shape.wo % 4 == 0:
+    if cout >= 256 and k * k * cin >= 256 and shape.wo >= 4:
         t8 = ((cout + 255) // 256) * ((k * k * cin + 255) // 256)
         msg = "      form8 / form128 by splits:"
         M = n * shape.ho * shape.wo

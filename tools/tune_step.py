@@ -50,7 +50,7 @@ def main():
     eng = YoloV3Engine("darknet_53", 3, 80, device=dev, seed=0, storage=args.storage)
     crit = YOLOForw(anchors=bench.ANCHORS, num_classes=80, img_size=args.px).to(dev)
     imgs, targets = bench.synth_batch(args.batch, args.px, 0, dev)
-    opt = FlatSGD.for_engine(eng, lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    opt = FlatSGD.for_engine(eng, lr=0.0, momentum=0.9, weight_decay=5e-4)      # lr 0: the model must not drift (or diverge) over the thousands of steps of a sweep
     S = 1024.0 if args.storage == "fp16" else 1.0
 
     def step():
