@@ -10,7 +10,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 python3 tools/step_table.py $O/prof_step 5 > $O/${TAG}_bench_step_table.md
 python3 tools/layer_table.py $O/prof_step > $O/${TAG}_bench_layer_table.txt
 python3 tools/summarize_rocprof.py $O/prof_step $O/${TAG}_bench_kernel_stats.md "rocprofv3 --kernel-trace --stats -- $CMD"
-tail -1 $O/prof_step.log > $O/${TAG}_bench_line_under_rocprof.json
+grep "^{\"metric\"" $O/prof_step.log | tail -1 > $O/${TAG}_bench_line_under_rocprof.json
 if [ "$2" != "nopmc" ]; then
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-events > $O/pmc_$c.log 2>&1
