@@ -342,6 +342,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   }
 
   // D[row = co][col = n']: lane holds rows fq*4+r, column fr
+  // (measured and removed, round 4: the X fragment as the row operand, so that a lane holds four consecutive n' and the slab leaves in 16-byte stores -
+  //  bit-identical, equal alone, SLOWER in the step: RetinaNet-R101-LVIS 35.6 -> 36.6 ms, profiles/r04_ab_results.md 11)
   const int fr = lane & 15, fq = lane >> 4;
   if (p.slab) {
     // split-K: plain stores of the partial tile (6 TB/s class) instead of fp32 atomics (1.3 TB/s class, contended);
