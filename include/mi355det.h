@@ -379,7 +379,8 @@ int mi355det_conv_autotune_mode(int on);
  *   clear    drops every choice and the lock (the next plan build times everything)
  * Host mirror: object_detectors_amd/tune.py (JSON files, MI355DET_TUNE_SAVE / MI355DET_TUNE_LOAD, rank-0 broadcast for N > 1). */
 typedef struct {
-  uint32_t table;   /* 0 implicit-GEMM tile configuration, 1 stride-2 data-gradient form, 2 weight-gradient split count */
+  uint32_t table;   /* 0 implicit-GEMM tile configuration, 1 stride-2 data-gradient form, 2 weight-gradient split count (+ 65536: the 256 x 256
+                       phase-staggered kernel; a shape it does not take falls back to the 128 x 128 kernel with the same split count) */
   int32_t value;
   uint64_t key;     /* shape key of that table */
 } mi355det_tune_entry;
