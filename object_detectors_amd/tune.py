@@ -152,7 +152,8 @@ _NARROW = {0: (29, 30, 31), 29: (0,), 30: (0,), 31: (0,)}
 
 
 def wgrad_key_fields(key):
-    """(pixels n*ho*wo, cout, cin, ksize, stride, fp16 storage) of a weight-gradient key (csrc/wgrad_kernels.hip: wgrad_key)."""
+    """(pixels n*ho*wo, cout, cin, ksize, stride, fp16 storage) of a weight-gradient key (csrc/wgrad_kernels.hip: wgrad_key).  Defined for channel
+    counts below 4099 (the key's radix): larger ones carry into the next field - the key is still a usable hash, but not decodable."""
     f16, key = key % 2, key // 2
     ks, key = key % 17, key // 17
     cin, key = key % 4099, key // 4099

@@ -164,3 +164,30 @@ def test_refine_step_on_a_cost_model(tmp_path):
     assert {(t, k): v for t, k, v in tune.to_entries(tune.loads(open(ck).read()))} == got
     assert any("64 -> 32" in l for l in lines)
     tune.clear()
+
+
+def test_weight_gradient_key_fields_and_split_rule():
+    """tune.wgrad_key_fields inverts the library's weight-gradient key (csrc/wgrad_kernels.hip:wgrad_key: pixels, cout, cin, ksize * 4 + stride, format
+    bit), and tune.wgrad_split_valid is the library's rule for a split count (chunks of whole 64-pixel k-steps, none empty) - the two helpers the
+    A/B record tools (tools/tune_ab.py --wgrad8, tools/tune_drop.py) stand on."""
+    from object_detectors_amd import tune
+
+    def key(m, cout, cin, ks, stride, f16):      # the arithmetic of wgrad_key, restated
+        k = m
+        k = k * 4099 + cout
+        k = k * 4099 + cin
+        k = k * 17 + ks * 4 + stride
+        return k * 2 + int(f16)
+    for f in [(204800, 256, 128, 3, 1, False), (51200, 512, 256, 3, 2, True), (80000, 819, 256, 3, 1, False), (12800, 255, 1024, 1, 1, False), (392, 36, 256, 3, 1, True)]:
+        assert tune.wgrad_key_fields(key(*f)) == f
+    # channel counts from 4099 up (the 10 836-channel cls_logits) carry into the pixel field: the key stays a fine hash, the decoding is not defined
+    assert tune.wgrad_key_fields(key(80000, 10836, 256, 3, 1, False))[0] != 80000
+    # the committed bench record decodes into the YOLOv3 @640 bs-32 weight-gradient shapes
+    rec = os.path.join(ROOT, "object_detectors_amd", "tune_records", "yolov3_d53_bs32_640_bf16.json")
+    fields = [tune.wgrad_key_fields(k) for t, k, v in tune.to_entries(tune.loads(open(rec).read())) if t == "wgrad"]
+    assert (51200, 512, 256, 3, 1, False) in fields and (204800, 256, 128, 3, 1, False) in fields and all(not f[5] for f in fields)
+    for m in (64, 507, 3200, 12800, 80000):
+        for sp in range(1, 40):
+            chunks = [min(m, (i + 1) * (((m + sp - 1) // sp + 63) // 64 * 64)) - i * (((m + sp - 1) // sp + 63) // 64 * 64) for i in range(sp)]
+            assert tune.wgrad_split_valid(m, sp) == all(c > 0 for c in chunks), (m, sp)
+    assert not tune.wgrad_split_valid(64, 0)
