@@ -163,8 +163,10 @@ def wgrad_key_fields(key):
 
 def wgrad_split_valid(m, sp):
     """csrc/wgrad_kernels.hip: split_valid - the pixel axis is cut into `sp` chunks of whole 64-pixel k-steps, none of them empty."""
+    if sp < 1:
+        return False
     chunk = ((m + sp - 1) // sp + 63) // 64 * 64
-    return sp >= 1 and (m + chunk - 1) // chunk == sp
+    return (m + chunk - 1) // chunk == sp
 
 
 def _alternatives(table, v):
