@@ -201,7 +201,8 @@ def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budge
     (a shape: every layer of that shape moves together) the other legal values are tried, and a value is kept only if the step got faster by
     more than `min_gain_us`, confirmed against a fresh measurement of the incumbent.  Choices are looked up in the library at launch time, so a
     trial is an import of a modified record + `steps` steps: no plan rebuild.  Leaves the refined record imported and locked; returns
-    (start_us, final_us, number of entries changed).  Entries of the other storage format are left alone.
+    (start_us, final_us, number of entries changed); `refine_step.last_drift_us` = the start record re-measured at the end minus its first measurement
+    (a warning is logged when that exceeds 3 bars).  Entries of the other storage format are left alone.
 
     `min_gain_us` has to sit above the run-to-run spread of `steps` steps: 40 us is right for the 28 ms YOLO step; the 40 ms RetinaNet-R101-LVIS
     step refined with 40 us collected 53 "improvements" that were 1 % SLOWER than no record on another box (150 us: profiles/r04_ab_results.md §7).
@@ -234,6 +235,7 @@ def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budge
         import_bytes(from_entries([(t, k, v) for (t, k), v in d.items()]), replace=True, lock=True)
 
     apply(cur)
+    first = dict(cur)
     base = start = measure(5)
     log(f"start: {base:.0f} us per step")
     t_begin, kept = time.time(), 0
@@ -270,6 +272,14 @@ def refine_step(step, storage="bf16", rounds=1, steps=6, min_gain_us=40.0, budge
             apply(cur)
         if not changed:
             break
+    # drift check: the START record again, at the end.  A step that got faster or slower by itself during the sweep (a model diverging on the repeated
+    # batch, a clock that moved) makes every acceptance above suspect - round 4 lost three records to exactly this.
+    apply(first)
+    again = measure(5)
+    refine_step.last_drift_us = again - start
+    if abs(again - start) > 3.0 * min_gain_us:
+        log(f"WARNING: the start record measures {again:.0f} us now against {start:.0f} us at the beginning: the step drifted by itself "
+            f"({again - start:+.0f} us); do not trust this sweep (is the learning rate 0?)")
     apply(cur)
     final = measure(5)
     log(f"final: {final:.0f} us per step; {kept} entries changed; {time.time() - t_begin:.0f} s of search")

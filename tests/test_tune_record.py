@@ -163,6 +163,17 @@ def test_refine_step_on_a_cost_model(tmp_path):
     assert tune.lock(False) is True
     assert {(t, k): v for t, k, v in tune.to_entries(tune.loads(open(ck).read()))} == got
     assert any("64 -> 32" in l for l in lines)
+    assert abs(tune.refine_step.last_drift_us) < 20.0 and not any("WARNING" in l for l in lines)
+    # a step that gets faster by itself while the sweep runs (round 4: a model diverging on the repeated batch) is reported
+    tune.import_bytes(tune.from_entries(start), replace=True, lock=True)
+    calls = [0]
+
+    def drifting(step, steps):
+        calls[0] += 1
+        return cost() - 4.0 * calls[0]
+    lines2 = []
+    tune.refine_step(lambda: None, rounds=1, steps=1, min_gain_us=40.0, budget_s=60.0, log=lines2.append, timer=drifting)
+    assert tune.refine_step.last_drift_us < -120.0 and any("WARNING" in l and "drifted" in l for l in lines2)
     tune.clear()
 
 
